@@ -1,0 +1,224 @@
+// Frequency + multiresolution hash-grid encoding, forward and backward.
+// Replaces tcnn Encoding{Frequency,Grid} called at autolabel/models.py:51-59 (HGFreqEncoder.forward),
+// :25-27 (FreqEncoder.forward).  Spec: oracle/nerf_oracle.py (grid_corner_indices, hashgrid_encode,
+// freq_encode).  Index arithmetic is bit-exact to the oracle (unfused fp32 pos, uint32 hash).
+//
+// HBM-bound kernel.  Work mapping: a 256-thread block owns a tile of 64 consecutive rows (samples of
+// one ray are consecutive, so a wave's 64 lanes walk along a ray: coarse levels hit the same few cache
+// lines, fine levels are random 4-byte gathers served by L2/Infinity Cache -- the fp16 table is
+// 28.5 MB).  Wave w handles levels w, w+4, ...; results are staged in LDS and the tile is written as
+// ONE contiguous span (64 rows * enc_pad halves) with 16-byte stores.
+#include "common.h"
+#include <math.h>
+
+#define ENC_TILE 64
+#define PRIME_Y 2654435761u
+#define PRIME_Z 805459861u
+
+struct EncParams {
+  AlnEncDesc e;
+  const uint32_t* table;  // fp16x2 per entry
+  const float* rays_o; const float* rays_d; const float* z; const float* xyz;
+  int rows, rays_stride;
+};
+
+__device__ inline void row_position(const EncParams& p, int row, float* x) {
+  if (p.xyz) {
+    x[0] = p.xyz[3 * (size_t)row]; x[1] = p.xyz[3 * (size_t)row + 1]; x[2] = p.xyz[3 * (size_t)row + 2];
+  } else {
+    int ray = row / p.rays_stride;
+    aln_sample_xyz(p.rays_o + 3 * (size_t)ray, p.rays_d + 3 * (size_t)ray, p.z[row], p.e.bound, x);
+  }
+}
+
+__device__ inline void normalize_pos(const float* x, float bound, bool clip, float* xn) {
+  float two_b = 2.0f * bound;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = __fdiv_rn(__fadd_rn(x[k], bound), two_b);
+    xn[k] = clip ? fminf(fmaxf(v, 0.0f), 1.0f) : v;
+  }
+}
+
+// level-local corner indices + trilinear weights (oracle: grid_corner_indices)
+__device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn, uint32_t* idx, float* w) {
+  float scale = g.scale[l];
+  uint32_t res = g.res[l], size = g.size[l];
+  bool dense = g.dense[l] != 0;
+  uint32_t gi[3]; float fr[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float pos = __fadd_rn(__fmul_rn(xn[k], scale), 0.5f);
+    float fl = floorf(pos);
+    gi[k] = (uint32_t)(int)fl;
+    fr[k] = __fsub_rn(pos, fl);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float ww = 1.0f; uint32_t cg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (c & (1 << k)) { ww = __fmul_rn(ww, fr[k]); cg[k] = gi[k] + 1u; }
+      else { ww = __fmul_rn(ww, __fsub_rn(1.0f, fr[k])); cg[k] = gi[k]; }
+    }
+    uint32_t i = dense ? (cg[0] + cg[1] * res + cg[2] * res * res) : (cg[0] ^ (cg[1] * PRIME_Y) ^ (cg[2] * PRIME_Z));
+    idx[c] = i % size;
+    w[c] = ww;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* tile = (h16*)smem;  // [ENC_TILE][enc_pad]
+  const int pad = p.e.enc_pad;
+  const int fdim = 3 * 2 * p.e.n_freq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = (p.rows + ENC_TILE - 1) / ENC_TILE;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int row = t * ENC_TILE + lane;
+    bool valid = row < p.rows;
+    float x[3] = {0, 0, 0}, xn[3];
+    if (valid) row_position(p, row, x);
+    if (p.e.use_grid) {
+      normalize_pos(x, p.e.bound, true, xn);
+      for (int l = wave; l < p.e.grid.n_levels; l += 4) {
+        uint32_t idx[8]; float w[8];
+        grid_corners(p.e.grid, l, xn, idx, w);
+        const uint32_t* tab = p.table + p.e.grid.offset[l];
+        uint32_t v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = valid ? tab[idx[c]] : 0u;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          h16x2 hv = *(h16x2*)&v[c];
+          a0 = __fadd_rn(a0, __fmul_rn(w[c], (float)hv[0]));
+          a1 = __fadd_rn(a1, __fmul_rn(w[c], (float)hv[1]));
+        }
+        h16x2 o; o[0] = (h16)a0; o[1] = (h16)a1;
+        *(h16x2*)&tile[lane * pad + fdim + 2 * l] = o;
+      }
+    }
+    // frequency part + ones padding: (row, j) pairs spread over the block
+    const int extra0 = p.e.enc_dim;  // padding starts here
+    const int nfj = fdim + (pad - extra0);
+    for (int i = threadIdx.x; i < ENC_TILE * nfj; i += 256) {
+      int r = i / nfj, j = i % nfj;
+      if (j >= fdim) { tile[r * pad + extra0 + (j - fdim)] = (h16)1.0f; continue; }
+      int rr = t * ENC_TILE + r;
+      float xr[3] = {0, 0, 0};
+      if (rr < p.rows) row_position(p, rr, xr);
+      if (p.e.freq_normalized) { float q[3]; normalize_pos(xr, p.e.bound, false, q); xr[0] = q[0]; xr[1] = q[1]; xr[2] = q[2]; }
+      int d = j / (2 * p.e.n_freq), k = (j / 2) % p.e.n_freq;
+      float arg = __fmul_rn(__fmul_rn(xr[d], (float)(1 << k)), 3.14159265358979323846f);
+      if (j & 1) arg = __fadd_rn(arg, 1.57079632679489661923f);
+      tile[r * pad + j] = (h16)sinf(arg);
+    }
+    __syncthreads();
+    // coalesced write-out of the whole tile (rows are contiguous in memory)
+    int rows_here = min(ENC_TILE, p.rows - t * ENC_TILE);
+    int n16 = rows_here * pad / 8;
+    uint4* dst = (uint4*)(out + (size_t)t * ENC_TILE * pad);
+    const uint4* src = (const uint4*)tile;
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_encode_bwd(EncParams p, const h16* __restrict__ d_enc, float* __restrict__ grad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* tile = (h16*)smem;
+  const int pad = p.e.enc_pad;
+  const int fdim = 3 * 2 * p.e.n_freq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = (p.rows + ENC_TILE - 1) / ENC_TILE;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int rows_here = min(ENC_TILE, p.rows - t * ENC_TILE);
+    int n16 = rows_here * pad / 8;
+    const uint4* src = (const uint4*)(d_enc + (size_t)t * ENC_TILE * pad);
+    uint4* dst = (uint4*)tile;
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __syncthreads();
+    int row = t * ENC_TILE + lane;
+    if (row < p.rows) {
+      float x[3], xn[3];
+      row_position(p, row, x);
+      normalize_pos(x, p.e.bound, true, xn);
+      for (int l = wave; l < p.e.grid.n_levels; l += 4) {
+        h16x2 g = *(h16x2*)&tile[lane * pad + fdim + 2 * l];
+        float g0 = (float)g[0], g1 = (float)g[1];
+        if (g0 == 0.f && g1 == 0.f) continue;
+        uint32_t idx[8]; float w[8];
+        grid_corners(p.e.grid, l, xn, idx, w);
+        float* gt = grad + 2 * (size_t)p.e.grid.offset[l];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          unsafeAtomicAdd(gt + 2 * (size_t)idx[c], w[c] * g0);
+          unsafeAtomicAdd(gt + 2 * (size_t)idx[c] + 1, w[c] * g1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static int fill_params(EncParams& p, const AlnEncDesc* e, const void* table, const float* rays_o, const float* rays_d,
+                       const float* z, const float* xyz, int rows, int stride) {
+  ALN_REQUIRE(e && rows >= 0, "encode: bad arguments");
+  ALN_REQUIRE(xyz || (rays_o && rays_d && z && stride > 0), "encode: need xyz or rays+z");
+  ALN_REQUIRE(e->enc_pad % 8 == 0 && e->enc_pad >= e->enc_dim, "encode: enc_pad must be a multiple of 8");
+  ALN_REQUIRE(!e->use_grid || e->grid.n_features == 2, "encode: n_features_per_level must be 2");
+  ALN_REQUIRE(e->enc_dim == 6 * e->n_freq + (e->use_grid ? 2 * e->grid.n_levels : 0), "encode: enc_dim mismatch");
+  p.e = *e; p.table = (const uint32_t*)table; p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.xyz = xyz;
+  p.rows = rows; p.rays_stride = stride;
+  return 0;
+}
+
+extern "C" int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
+                              const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* enc_out,
+                              void* stream) {
+  EncParams p;
+  if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
+  ALN_REQUIRE(!e->use_grid || table_f16, "encode_fwd: table is NULL");
+  if (rows == 0) return 0;
+  int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
+  int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);
+  hipLaunchKernelGGL(k_encode_fwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (h16*)enc_out);
+  ALN_CHECK_LAUNCH("encode_fwd");
+  return 0;
+}
+
+extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                              const float* xyz, int32_t rows, int32_t rays_stride, const void* d_enc,
+                              float* grad_table, void* stream) {
+  EncParams p;
+  if (int rc = fill_params(p, e, nullptr, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
+  if (rows == 0 || !e->use_grid) return 0;
+  int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
+  int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);
+  hipLaunchKernelGGL(k_encode_bwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (const h16*)d_enc, grad_table);
+  ALN_CHECK_LAUNCH("encode_bwd");
+  return 0;
+}
+
+extern "C" int aln_grid_desc_init(AlnGridDesc* g) {
+  ALN_REQUIRE(g && g->n_levels > 0 && g->n_levels <= ALN_MAX_LEVELS, "grid_desc: n_levels out of range");
+  uint32_t offset = 0;
+  for (int l = 0; l < g->n_levels; ++l) {
+    // tcnn: scale = exp2(l * log2(pls)) * base - 1 (fp32); res = ceil(scale) + 1
+    float scale = exp2f((float)l * log2f(g->per_level_scale)) * (float)g->base_resolution - 1.0f;
+    uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    uint64_t dense = (uint64_t)res * res * res;
+    uint64_t size = dense > 0x7FFFFFFFull ? 0x7FFFFFFFull : dense;
+    size = (size + 7) / 8 * 8;
+    uint64_t cap = 1ull << g->log2_hashmap_size;
+    if (size > cap) size = cap;
+    g->scale[l] = scale; g->res[l] = res; g->size[l] = (uint32_t)size; g->offset[l] = offset;
+    g->dense[l] = dense <= size ? 1u : 0u;
+    offset += (uint32_t)size;
+  }
+  g->n_entries = offset;
+  return 0;
+}

@@ -1,0 +1,193 @@
+// Glue between the sigma MLP and the color / semantic heads: live-sample compaction, head input
+// assembly, and the matching gradient assembly.  Mirrors the tensor plumbing of
+// autolabel/models.py:175-188 (density: sigma = trunc_exp(h0), geo_feat = h[1:]), :190-220 (color: boolean-mask
+// gather, SH(dir) ++ geo_feat), :248-256 (semantic: cat[relu(f), geo_feat]).
+#include "common.h"
+#include <math.h>
+
+// sigma[row] = exp(h0)  (torch-ngp trunc_exp forward, fp32)
+__global__ void k_sigma_act(const h16* __restrict__ sigma_out, int rows, float* __restrict__ sigma) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x)
+    sigma[r] = expf((float)sigma_out[(size_t)r * 16]);
+}
+extern "C" int aln_sigma_act(const void* sigma_out, int32_t rows, float* sigma, void* stream) {
+  ALN_REQUIRE(sigma_out && sigma, "sigma_act: NULL pointer");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_sigma_act, dim3(aln_grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, (const h16*)sigma_out,
+                     rows, sigma);
+  ALN_CHECK_LAUNCH("sigma_act");
+  return 0;
+}
+
+// live = w > thresh (renderer: mask = weights > 1e-4).  Wave-ballot compaction, one atomic per wave.
+__global__ void k_compact_live(const float* __restrict__ w_row, int rows, float thresh, int* __restrict__ n_live,
+                               int* __restrict__ live_idx, int* __restrict__ cidx_row) {
+  const int lane = threadIdx.x & 63;
+  int nwork = (rows + 63) / 64 * 64;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nwork; r += gridDim.x * blockDim.x) {
+    bool live = r < rows && w_row[r] > thresh;
+    unsigned long long m = __ballot(live);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(n_live, __popcll(m));
+    base = __shfl(base, 0);
+    if (r < rows) {
+      int ci = live ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+      cidx_row[r] = ci;
+      if (live) live_idx[ci] = r;
+    }
+  }
+}
+extern "C" int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx,
+                                int32_t* cidx_row, void* stream) {
+  ALN_REQUIRE(w_row && n_live && live_idx && cidx_row, "compact_live: NULL pointer");
+  hipMemsetAsync(n_live, 0, sizeof(int), (hipStream_t)stream);
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_compact_live, dim3(aln_grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh,
+                     n_live, live_idx, cidx_row);
+  ALN_CHECK_LAUNCH("compact_live");
+  return 0;
+}
+
+// tcnn SphericalHarmonics degree 4 on d01 in [0,1] (models.py:205-207) -- oracle: sh4_encode
+__device__ inline void sh4(float x, float y, float z, float* o) {
+  float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y; o[2] = 0.48860251190291987f * z; o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy; o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f; o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2); o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2); o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2); o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// color_in[ci] = [SH16(dir(ray(row))), geo_feat[row] (G), 1...]   width in_pad
+__global__ void k_build_color_in(const int* __restrict__ live_idx, const int* __restrict__ n_live, int max_rows,
+                                 const float* __restrict__ rd, const float* __restrict__ dirs, int N, int S1, int S2,
+                                 const h16* __restrict__ sigma_out, int G, int in_pad, h16* __restrict__ cin) {
+  int n = live_idx ? min(*n_live, max_rows) : max_rows;
+  for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n; ci += gridDim.x * blockDim.x) {
+    int row = live_idx ? live_idx[ci] : ci;
+    const float* d;
+    if (dirs) d = dirs + 3 * (size_t)row;
+    else { int ray = row < N * S1 ? row / S1 : (row - N * S1) / S2; d = rd + 3 * (size_t)ray; }
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { float d01 = (d[k] + 1.0f) / 2.0f; v[k] = d01 * 2.0f - 1.0f; }
+    float sh[16];
+    sh4(v[0], v[1], v[2], sh);
+    h16* o = cin + (size_t)ci * in_pad;
+    for (int j = 0; j < 16; ++j) o[j] = (h16)sh[j];
+    for (int g = 0; g < G; ++g) o[16 + g] = sigma_out[(size_t)row * 16 + 1 + g];
+    for (int j = 16 + G; j < in_pad; ++j) o[j] = (h16)1.0f;
+  }
+}
+extern "C" int aln_build_color_in(const int32_t* live_idx, const int32_t* n_live, int32_t max_rows, const float* rays_d,
+                                  const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out, int32_t G,
+                                  int32_t in_pad, void* color_in, void* stream) {
+  ALN_REQUIRE((rays_d || dirs) && sigma_out && color_in && (!live_idx || n_live), "build_color_in: NULL pointer");
+  ALN_REQUIRE(G + 1 <= 16 && 16 + G <= in_pad, "build_color_in: geo_feat_dim %d unsupported", G);
+  if (max_rows <= 0) return 0;
+  hipLaunchKernelGGL(k_build_color_in, dim3(aln_grid_for(max_rows, 256)), dim3(256), 0, (hipStream_t)stream, live_idx, n_live,
+                     max_rows, rays_d, dirs, N, S1, S2, (const h16*)sigma_out, G, in_pad, (h16*)color_in);
+  ALN_CHECK_LAUNCH("build_color_in");
+  return 0;
+}
+
+// semf_in[row] = [geo_feat (G), 1...] (16 wide)
+__global__ void k_build_semf_in(const h16* __restrict__ sigma_out, int rows, int G, int in_pad, h16* __restrict__ o) {
+  size_t total = (size_t)rows * in_pad;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    size_t r = t / in_pad; int j = (int)(t % in_pad);
+    o[t] = j < G ? sigma_out[r * 16 + 1 + j] : (h16)1.0f;
+  }
+}
+// semo_in[row] = [relu(f) (D), geo_feat (G), 1...]
+__global__ void k_build_semo_in(const h16* __restrict__ f, const h16* __restrict__ sigma_out, int rows, int D, int G,
+                                int in_pad, h16* __restrict__ o) {
+  size_t total = (size_t)rows * in_pad;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    size_t r = t / in_pad; int j = (int)(t % in_pad);
+    h16 v;
+    if (j < D) { v = f[r * D + j]; if ((float)v < 0.f) v = (h16)0.f; }
+    else if (j < D + G) v = sigma_out[r * 16 + 1 + (j - D)];
+    else v = (h16)1.0f;
+    o[t] = v;
+  }
+}
+extern "C" int aln_build_sem_in(const void* sigma_out, const void* f, int32_t rows, int32_t D, int32_t G, int32_t semf_in_pad,
+                                int32_t semo_in_pad, void* semf_in, void* semo_in, void* stream) {
+  ALN_REQUIRE(sigma_out, "build_sem_in: NULL pointer");
+  if (rows <= 0) return 0;
+  if (semf_in) {
+    hipLaunchKernelGGL(k_build_semf_in, dim3(aln_grid_for((int64_t)rows * semf_in_pad, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const h16*)sigma_out, rows, G, semf_in_pad, (h16*)semf_in);
+    ALN_CHECK_LAUNCH("build_semf_in");
+  }
+  if (semo_in) {
+    ALN_REQUIRE(f, "build_sem_in: f is NULL");
+    hipLaunchKernelGGL(k_build_semo_in, dim3(aln_grid_for((int64_t)rows * semo_in_pad, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const h16*)f, (const h16*)sigma_out, rows, D, G, semo_in_pad, (h16*)semo_in);
+    ALN_CHECK_LAUNCH("build_semo_in");
+  }
+  return 0;
+}
+
+// d_f_total[row][d] = d_feat[row][d] + (f > 0 ? d_semo_in[row][d] : 0)      (in place into d_feat)
+__global__ void k_assemble_dsemf_out(h16* __restrict__ d_feat, const h16* __restrict__ f, const h16* __restrict__ d_semo_in,
+                                     int rows, int D, int semo_in_pad, int* __restrict__ found_inf) {
+  size_t total = (size_t)rows * D;
+  bool bad = false;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    size_t r = t / D; int d = (int)(t % D);
+    float g = (float)d_feat[t];
+    if ((float)f[t] > 0.f) g += (float)d_semo_in[r * semo_in_pad + d];
+    h16 gh = (h16)g; bad |= !(fabsf((float)gh) <= 65504.f);
+    d_feat[t] = gh;
+  }
+  if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
+}
+// d_sigma_out[row] = [d_h0, d_geo(semf_in) + d_geo(semo_in) + d_geo(color_in)] (16 wide)
+__global__ void k_assemble_dsigma_out(const float* __restrict__ d_h0, const h16* __restrict__ d_semf_in, int semf_in_pad,
+                                      const h16* __restrict__ d_semo_in, int semo_in_pad, int D, const h16* __restrict__ d_color_in,
+                                      int color_in_pad, const int* __restrict__ cidx_row, int rows, int G,
+                                      h16* __restrict__ d_sigma_out, int* __restrict__ found_inf) {
+  size_t total = (size_t)rows * 16;
+  bool bad = false;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    size_t r = t / 16; int j = (int)(t % 16);
+    float g = 0.f;
+    if (j == 0) g = d_h0[r];
+    else if (j <= G) {
+      int gi = j - 1;
+      if (d_semf_in) g += (float)d_semf_in[r * semf_in_pad + gi] + (float)d_semo_in[r * semo_in_pad + D + gi];
+      int ci = cidx_row ? cidx_row[r] : (int)r;
+      if (ci >= 0) g += (float)d_color_in[(size_t)ci * color_in_pad + 16 + gi];
+    }
+    h16 gh = (h16)g; bad |= !(fabsf((float)gh) <= 65504.f);
+    d_sigma_out[t] = gh;
+  }
+  if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
+}
+extern "C" int aln_assemble_grads(const float* d_h0, const void* d_semf_in, int32_t semf_in_pad, const void* d_semo_in,
+                                  int32_t semo_in_pad, int32_t D, const void* d_color_in, int32_t color_in_pad,
+                                  const int32_t* cidx_row, int32_t rows, int32_t G, void* d_sigma_out, int32_t* found_inf,
+                                  void* stream) {
+  ALN_REQUIRE(d_h0 && d_color_in && d_sigma_out && (!d_semf_in || d_semo_in), "assemble_grads: NULL pointer");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_assemble_dsigma_out, dim3(aln_grid_for((int64_t)rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, d_h0,
+                     (const h16*)d_semf_in, semf_in_pad, (const h16*)d_semo_in, semo_in_pad, D, (const h16*)d_color_in,
+                     color_in_pad, cidx_row, rows, G, (h16*)d_sigma_out, found_inf);
+  ALN_CHECK_LAUNCH("assemble_dsigma_out");
+  return 0;
+}
+extern "C" int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d_semo_in, int32_t rows, int32_t D,
+                                      int32_t semo_in_pad, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(d_feat && f && d_semo_in, "assemble_dsemf_out: NULL pointer");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_assemble_dsemf_out, dim3(aln_grid_for((int64_t)rows * D, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (h16*)d_feat, (const h16*)f, (const h16*)d_semo_in, rows, D, semo_in_pad, found_inf);
+  ALN_CHECK_LAUNCH("assemble_dsemf_out");
+  return 0;
+}

@@ -1,0 +1,420 @@
+// Bias-free ReLU MLPs on MFMA (v_mfma_f32_32x32x16_f16), forward + backward.
+// Replaces tcnn Network{FullyFusedMLP,CutlassMLP} instantiated at autolabel/models.py:84-136
+// (sigma_net 48->128->128->16, color_net 32->128->128->16, semantic_features 16->D->D->D,
+//  semantic_out (D+16)->64->Cpad).  Spec: oracle/nerf_oracle.py:mlp_forward (fp16 weights and
+// activations, fp32 accumulate, input padded with ones by the producer of x).
+//
+// Formulation: Out^T[n, s] = W[n, k] * Act^T[k, s].  A = weights (32 output features x 16 k),
+// B = activations (16 k x 32 samples): lane (s = l&31, hf = l>>5) owns sample s for the whole chain.
+// The C layout of one layer (lane owns features 32mb + 8q + 4hf + r of its sample) is consumed
+// directly as the B operand of the next layer -- the k index of an MFMA is only a summation index, so
+// the weights are pre-permuted ("chained kmap") instead of transposing activations through LDS.
+// Activations therefore never leave registers between layers; weights live in LDS in fragment order
+// (one conflict-free ds_read_b128 per lane per MFMA).
+#include "common.h"
+
+// ---------------------------------------------------------------- fragment bookkeeping
+struct MlpLayers {
+  int n;          // number of weight matrices (n_hidden + 1)
+  int in_[3], out_[3];
+  size_t w_off[3];  // offset of W_l in the fp32 master block
+};
+__host__ __device__ inline MlpLayers mlp_layers(int in_pad, int hid, int out_pad, int n_hidden) {
+  MlpLayers L; L.n = n_hidden + 1;
+  L.in_[0] = in_pad; L.out_[0] = hid;
+  if (n_hidden == 2) { L.in_[1] = hid; L.out_[1] = hid; }
+  L.in_[L.n - 1] = (L.n == 1) ? in_pad : hid; L.out_[L.n - 1] = out_pad;
+  size_t o = 0;
+  for (int l = 0; l < L.n; ++l) { L.w_off[l] = o; o += (size_t)L.in_[l] * L.out_[l]; }
+  return L;
+}
+__host__ __device__ inline int ceil32(int x) { return (x + 31) / 32; }
+// frag counts: forward layer l: ceil32(out) x in/16 ; backward layer l: ceil32(in) x out/16
+__host__ __device__ inline size_t fwd_frag_off(const MlpLayers& L, int l) {
+  size_t o = 0; for (int i = 0; i < l; ++i) o += (size_t)ceil32(L.out_[i]) * (L.in_[i] / 16); return o;
+}
+__host__ __device__ inline size_t bwd_frag_off(const MlpLayers& L, int l) {  // stored last layer first
+  size_t o = 0; for (int i = L.n - 1; i > l; --i) o += (size_t)ceil32(L.in_[i]) * (L.out_[i] / 16); return o;
+}
+__host__ __device__ inline int kmap_natural(int ks, int hf, int j) { return 16 * ks + 8 * hf + j; }
+__host__ __device__ inline int kmap_chained(int ks, int hf, int j) {
+  return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hf + (j & 3);
+}
+
+extern "C" int64_t aln_mlp_frag_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
+                                       int32_t backward) {
+  MlpLayers L = mlp_layers(in_pad, hidden, out_pad, n_hidden);
+  size_t frags = backward ? bwd_frag_off(L, -1) : fwd_frag_off(L, L.n);
+  return (int64_t)frags * 512;
+}
+
+__global__ void k_mlp_repack(const float* __restrict__ w, MlpLayers L, h16* __restrict__ wf, h16* __restrict__ wb) {
+  // one thread per (frag, lane, j)
+  size_t nf = fwd_frag_off(L, L.n) * 512, nb = bwd_frag_off(L, -1) * 512;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nf + nb; i += (size_t)gridDim.x * blockDim.x) {
+    bool bw = i >= nf;
+    size_t e = bw ? i - nf : i;
+    int j = e & 7, lane = (e >> 3) & 63; size_t frag = e >> 9;
+    int hf = lane >> 5, c = lane & 31;
+    int l = 0; size_t base = 0;
+    if (!bw) {
+      for (l = 0; l < L.n; ++l) { size_t cnt = (size_t)ceil32(L.out_[l]) * (L.in_[l] / 16); if (frag < base + cnt) break; base += cnt; }
+      int KS = L.in_[l] / 16; int mb = (frag - base) / KS, ks = (frag - base) % KS;
+      int o = 32 * mb + c, k = (l == 0) ? kmap_natural(ks, hf, j) : kmap_chained(ks, hf, j);
+      float v = (o < L.out_[l] && k < L.in_[l]) ? w[L.w_off[l] + (size_t)o * L.in_[l] + k] : 0.f;
+      wf[e] = (h16)v;
+    } else {
+      for (l = L.n - 1; l >= 0; --l) { size_t cnt = (size_t)ceil32(L.in_[l]) * (L.out_[l] / 16); if (frag < base + cnt) break; base += cnt; }
+      int KS = L.out_[l] / 16; int mb = (frag - base) / KS, ks = (frag - base) % KS;
+      int ii = 32 * mb + c, o = (l == L.n - 1) ? kmap_natural(ks, hf, j) : kmap_chained(ks, hf, j);
+      float v = (ii < L.in_[l] && o < L.out_[l]) ? w[L.w_off[l] + (size_t)o * L.in_[l] + ii] : 0.f;
+      wb[e] = (h16)v;
+    }
+  }
+}
+
+extern "C" int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
+                              void* wf, void* wb, void* stream) {
+  ALN_REQUIRE(w_master && wf && wb, "mlp_repack: NULL pointer");
+  ALN_REQUIRE(in_pad % 16 == 0 && out_pad % 16 == 0 && (hidden == 64 || hidden == 128) && (n_hidden == 1 || n_hidden == 2),
+              "mlp_repack: unsupported shape in=%d hid=%d out=%d nh=%d", in_pad, hidden, out_pad, n_hidden);
+  MlpLayers L = mlp_layers(in_pad, hidden, out_pad, n_hidden);
+  hipLaunchKernelGGL(k_mlp_repack, dim3(64), dim3(256), 0, (hipStream_t)stream, w_master, L, (h16*)wf, (h16*)wb);
+  ALN_CHECK_LAUNCH("mlp_repack");
+  return 0;
+}
+
+// ---------------------------------------------------------------- device helpers
+__device__ inline f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ inline void copy_to_lds(h16* lds, const h16* g, size_t halves) {
+  const uint4* s = (const uint4*)g; uint4* d = (uint4*)lds;
+  for (size_t i = threadIdx.x; i < halves / 8; i += blockDim.x) d[i] = s[i];
+}
+template <int NB>
+__device__ inline void zero_acc(f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int m = 0; m < NB; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+}
+// ReLU + fp16 pack of a layer's C registers into next-layer B fragments; optional natural-layout store
+template <int NB>
+__device__ inline void relu_pack_store(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], h16* dst_row /*row base or null*/, int hf) {
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[2 * m + (r >> 3)][r & 7] = (h16)fmaxf(acc[m][r], 0.f);
+    if (dst_row) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
+        v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
+        *(h16x4*)(dst_row + 32 * m + 8 * q + 4 * hf) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward
+template <int HID, int NHID>
+__global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
+                                                const h16* __restrict__ x, int rows, const int* __restrict__ rows_dev,
+                                                h16* __restrict__ h1, h16* __restrict__ h2, h16* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* wl = (h16*)smem;
+  copy_to_lds(wl, wf_g, wf_halves);
+  __syncthreads();
+  constexpr int NB = HID / 32, KS = HID / 16;
+  const h16x8* frag = (const h16x8*)wl;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
+  if (rows_dev) rows = min(rows, *rows_dev);
+  const int KS0 = in_pad / 16, OB = ceil32(out_pad);
+  const size_t f1 = (size_t)NB * KS0;                       // layer-1 frags start
+  const size_t fl = f1 + (NHID == 2 ? (size_t)NB * KS : 0); // last-layer frags start
+  const int ntiles = (rows + 31) / 32;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row = tile * 32 + c;
+    const bool valid = row < rows;
+    f32x16 acc[NB];
+    zero_acc(acc);
+    for (int ks = 0; ks < KS0; ++ks) {
+      h16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid) b = *(const h16x8*)(x + (size_t)row * in_pad + 16 * ks + 8 * hf);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KS0 + ks) * 64 + lane], b, acc[m]);
+    }
+    h16x8 p[KS];
+    relu_pack_store<NB>(acc, p, (valid && h1) ? h1 + (size_t)row * HID : nullptr, hf);
+    if (NHID == 2) {
+      zero_acc(acc);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[(f1 + (size_t)m * KS + ks) * 64 + lane], p[ks], acc[m]);
+      relu_pack_store<NB>(acc, p, (valid && h2) ? h2 + (size_t)row * HID : nullptr, hf);
+    }
+    for (int ob = 0; ob < OB; ++ob) {
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) o = mfma16(frag[(fl + (size_t)ob * KS + ks) * 64 + lane], p[ks], o);
+      if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int f = 32 * ob + 8 * q + 4 * hf;
+          if (f < out_pad) {
+            h16x4 v; v[0] = (h16)o[4 * q]; v[1] = (h16)o[4 * q + 1]; v[2] = (h16)o[4 * q + 2]; v[3] = (h16)o[4 * q + 3];
+            *(h16x4*)(out + (size_t)row * out_pad + f) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward (data path)
+template <int NB>
+__device__ inline bool mask_pack_store(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const h16* act_row, h16* dst_row, int hf,
+                                       bool valid) {
+  bool bad = false;
+#pragma unroll
+  for (int m = 0; m < NB; ++m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h16x4 a = {0, 0, 0, 0};
+      if (valid) a = *(const h16x4*)(act_row + 32 * m + 8 * q + 4 * hf);
+      h16x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float g = ((float)a[r] > 0.f) ? acc[m][4 * q + r] : 0.f;
+        h16 gh = (h16)g;
+        bad |= !(fabsf((float)gh) <= 65504.f);
+        v[r] = gh;
+        p[2 * m + (q >> 1)][4 * (q & 1) + r] = gh;
+      }
+      if (valid && dst_row) *(h16x4*)(dst_row + 32 * m + 8 * q + 4 * hf) = v;
+    }
+  }
+  return bad;
+}
+
+template <int HID, int NHID>
+__global__ __launch_bounds__(256) void k_mlp_bwd(const h16* __restrict__ wb_g, size_t wb_halves, int in_pad, int out_pad,
+                                                const h16* __restrict__ h1, const h16* __restrict__ h2,
+                                                const h16* __restrict__ d_out, int rows, const int* __restrict__ rows_dev,
+                                                h16* __restrict__ dA1, h16* __restrict__ dA2, h16* __restrict__ d_in,
+                                                int* __restrict__ found_inf) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* wl = (h16*)smem;
+  copy_to_lds(wl, wb_g, wb_halves);
+  __syncthreads();
+  constexpr int NB = HID / 32, KS = HID / 16;
+  const h16x8* frag = (const h16x8*)wl;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
+  if (rows_dev) rows = min(rows, *rows_dev);
+  const int KSO = out_pad / 16, IB = ceil32(in_pad);
+  const size_t f1 = (size_t)NB * KSO;
+  const size_t fl = f1 + (NHID == 2 ? (size_t)NB * KS : 0);
+  const int ntiles = (rows + 31) / 32;
+  bool bad = false;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row = tile * 32 + c;
+    const bool valid = row < rows;
+    f32x16 acc[NB];
+    zero_acc(acc);
+    for (int ks = 0; ks < KSO; ++ks) {
+      h16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid) b = *(const h16x8*)(d_out + (size_t)row * out_pad + 16 * ks + 8 * hf);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KSO + ks) * 64 + lane], b, acc[m]);
+    }
+    h16x8 p[KS];
+    const h16* hl = (NHID == 2) ? h2 : h1;
+    h16* dAl = (NHID == 2) ? dA2 : dA1;
+    bad |= mask_pack_store<NB>(acc, p, hl + (size_t)row * HID, dAl ? dAl + (size_t)row * HID : nullptr, hf, valid);
+    if (NHID == 2) {
+      zero_acc(acc);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[(f1 + (size_t)m * KS + ks) * 64 + lane], p[ks], acc[m]);
+      bad |= mask_pack_store<NB>(acc, p, h1 + (size_t)row * HID, dA1 ? dA1 + (size_t)row * HID : nullptr, hf, valid);
+    }
+    if (d_in) {
+      for (int ib = 0; ib < IB; ++ib) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) o = mfma16(frag[(fl + (size_t)ib * KS + ks) * 64 + lane], p[ks], o);
+        if (valid) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int f = 32 * ib + 8 * q + 4 * hf;
+            if (f < in_pad) {
+              h16x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] = (h16)o[4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
+              *(h16x4*)(d_in + (size_t)row * in_pad + f) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
+}
+
+// ---------------------------------------------------------------- weight gradients
+// dW[o][i] += sum_r dA[r][o] * X[r][i]   (contraction over rows).  A/B operands need 8 consecutive ROWS per
+// lane, i.e. a transposed read of the row-major tiles: staged in LDS, gathered with 16-bit reads.
+// HBM-bound (streams dA and X once); superseded by the fused backward once that lands.
+#define DW_ROWS 64
+__global__ __launch_bounds__(256) void k_dw_gemm(const h16* __restrict__ dA, int OW, const h16* __restrict__ X, int IW,
+                                                int rows, const int* __restrict__ rows_dev, float* __restrict__ dW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int OWp = ceil32(OW) * 32, IWp = ceil32(IW) * 32;
+  h16* tA = (h16*)smem;               // [DW_ROWS][OWp]
+  h16* tX = tA + DW_ROWS * OWp;       // [DW_ROWS][IWp]
+  if (rows_dev) rows = min(rows, *rows_dev);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
+  const int nob = OWp / 32, nib = IWp / 32, nblk = nob * nib;
+  f32x16 acc[4];
+  zero_acc(acc);
+  for (int i = threadIdx.x; i < DW_ROWS * (OWp + IWp); i += 256) tA[i] = (h16)0.f;
+  const int nchunks = (rows + DW_ROWS - 1) / DW_ROWS;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    __syncthreads();
+    const int r0 = ch * DW_ROWS;
+    for (int i = threadIdx.x; i < DW_ROWS * (OW / 8); i += 256) {
+      int r = i / (OW / 8), k = i % (OW / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r0 + r < rows) v = *(const uint4*)(dA + (size_t)(r0 + r) * OW + 8 * k);
+      *(uint4*)(tA + r * OWp + 8 * k) = v;
+    }
+    for (int i = threadIdx.x; i < DW_ROWS * (IW / 8); i += 256) {
+      int r = i / (IW / 8), k = i % (IW / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r0 + r < rows) v = *(const uint4*)(X + (size_t)(r0 + r) * IW + 8 * k);
+      *(uint4*)(tX + r * IWp + 8 * k) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int blk = wave + 4 * b;
+      if (blk < nblk) {
+        int ob = blk / nib, ib = blk % nib;
+#pragma unroll
+        for (int ks = 0; ks < DW_ROWS / 16; ++ks) {
+          h16x8 a, bb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            a[j] = tA[(16 * ks + 8 * hf + j) * OWp + 32 * ob + c];
+            bb[j] = tX[(16 * ks + 8 * hf + j) * IWp + 32 * ib + c];
+          }
+          acc[b] = mfma16(a, bb, acc[b]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    int blk = wave + 4 * b;
+    if (blk < nblk) {
+      int ob = blk / nib, ib = blk % nib;
+      int i = 32 * ib + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        if (o < OW && i < IW && acc[b][r] != 0.f) unsafeAtomicAdd(dW + (size_t)o * IW + i, acc[b][r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- launchers
+static int mlp_grid(int rows) {
+  int tiles = (rows + 127) / 128;
+  int g = tiles < 512 ? tiles : 512;
+  return g < 1 ? 1 : g;
+}
+
+extern "C" int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t* rows_dev, void* h1, void* h2,
+                           void* out, void* stream) {
+  ALN_REQUIRE(m && x && out && m->wf, "mlp_fwd: NULL pointer");
+  ALN_REQUIRE(m->in_pad % 16 == 0 && m->out_pad % 16 == 0, "mlp_fwd: widths must be multiples of 16");
+  if (rows <= 0) return 0;
+  size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 0);
+  size_t lds = halves * 2;
+  ALN_REQUIRE(lds <= 160 * 1024, "mlp_fwd: weights (%zu B) exceed LDS", lds);
+  dim3 g(mlp_grid(rows)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(H, N)                                                                                                   \
+  do {                                                                                                                 \
+    hipFuncSetAttribute((const void*)k_mlp_fwd<H, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    hipLaunchKernelGGL((k_mlp_fwd<H, N>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, (const h16*)x, \
+                       rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out);                                                 \
+  } while (0)
+  if (m->hidden == 128 && m->n_hidden == 2) LAUNCH(128, 2);
+  else if (m->hidden == 128 && m->n_hidden == 1) LAUNCH(128, 1);
+  else if (m->hidden == 64 && m->n_hidden == 2) LAUNCH(64, 2);
+  else if (m->hidden == 64 && m->n_hidden == 1) LAUNCH(64, 1);
+  else { aln_set_error("mlp_fwd: unsupported hidden=%d n_hidden=%d", m->hidden, m->n_hidden); return -1; }
+#undef LAUNCH
+  ALN_CHECK_LAUNCH("mlp_fwd");
+  return 0;
+}
+
+static int launch_dw(const h16* dA, int OW, const h16* X, int IW, int rows, const int* rows_dev, float* dW, hipStream_t s) {
+  size_t lds = (size_t)DW_ROWS * (ceil32(OW) * 32 + ceil32(IW) * 32) * 2;
+  ALN_REQUIRE(ceil32(OW) * ceil32(IW) <= 16, "dw_gemm: %dx%d exceeds 16 C-blocks", OW, IW);
+  int chunks = (rows + DW_ROWS - 1) / DW_ROWS;
+  int g = chunks < 256 ? chunks : 256;
+  hipFuncSetAttribute((const void*)k_dw_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_dw_gemm, dim3(g), dim3(256), lds, s, dA, OW, X, IW, rows, rows_dev, dW);
+  ALN_CHECK_LAUNCH("dw_gemm");
+  return 0;
+}
+
+extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out,
+                           int32_t rows, const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW,
+                           int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(m && d_out && h1 && m->wb, "mlp_bwd: NULL pointer");
+  ALN_REQUIRE(m->n_hidden == 1 || h2, "mlp_bwd: h2 required for 2 hidden layers");
+  ALN_REQUIRE(!dW || (x && dA1 && (m->n_hidden == 1 || dA2)), "mlp_bwd: dW needs x, dA1, dA2 buffers");
+  if (rows <= 0) return 0;
+  size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 1);
+  size_t lds = halves * 2;
+  ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd: weights (%zu B) exceed LDS", lds);
+  dim3 g(mlp_grid(rows)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(H, N)                                                                                                   \
+  do {                                                                                                                 \
+    hipFuncSetAttribute((const void*)k_mlp_bwd<H, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    hipLaunchKernelGGL((k_mlp_bwd<H, N>), g, b, lds, s, (const h16*)m->wb, halves, m->in_pad, m->out_pad, (const h16*)h1, \
+                       (const h16*)h2, (const h16*)d_out, rows, rows_dev, (h16*)dA1, (h16*)dA2, (h16*)d_in, found_inf); \
+  } while (0)
+  if (m->hidden == 128 && m->n_hidden == 2) LAUNCH(128, 2);
+  else if (m->hidden == 128 && m->n_hidden == 1) LAUNCH(128, 1);
+  else if (m->hidden == 64 && m->n_hidden == 2) LAUNCH(64, 2);
+  else if (m->hidden == 64 && m->n_hidden == 1) LAUNCH(64, 1);
+  else { aln_set_error("mlp_bwd: unsupported hidden=%d n_hidden=%d", m->hidden, m->n_hidden); return -1; }
+#undef LAUNCH
+  ALN_CHECK_LAUNCH("mlp_bwd");
+  if (dW) {
+    MlpLayers L = mlp_layers(m->in_pad, m->hidden, m->out_pad, m->n_hidden);
+    int rc;
+    // layer 0: dA1 x X
+    if ((rc = launch_dw((const h16*)dA1, m->hidden, (const h16*)x, m->in_pad, rows, rows_dev, dW + L.w_off[0], s))) return rc;
+    if (m->n_hidden == 2) {
+      if ((rc = launch_dw((const h16*)dA2, m->hidden, (const h16*)h1, m->hidden, rows, rows_dev, dW + L.w_off[1], s))) return rc;
+      if ((rc = launch_dw((const h16*)d_out, m->out_pad, (const h16*)h2, m->hidden, rows, rows_dev, dW + L.w_off[2], s))) return rc;
+    } else {
+      if ((rc = launch_dw((const h16*)d_out, m->out_pad, (const h16*)h1, m->hidden, rows, rows_dev, dW + L.w_off[1], s))) return rc;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,138 @@
+// Device-resident ray generation / batch assembly.
+// Replaces the host numpy+numba path autolabel/dataset.py:17-37 (_compute_direction), :182-242
+// (BaseDataset._next_train), :244-266 (_get_test).  Spec: oracle/raygen_oracle.py, pinned to the
+// reference's own outputs (tests/golden/raygen_f*.npz).
+#include "common.h"
+#include <math.h>
+
+// dataset.py:17-37.  The pinhole division runs in float64 (fx..cy are float64 scalars) and is rounded once
+// to float32; norm, normalisation and rotation are float32, unfused, in the order of the oracle.
+__device__ inline void pixel_direction(const float* __restrict__ R, int64_t idx, int w, double fx, double fy, double cx,
+                                       double cy, bool randomize, float jx, float jy, float* dir, float* norm_out) {
+  int64_t xi = idx % w;
+  float xs = (float)xi, ys = (float)((idx - xi) / w);
+  if (randomize) { xs = __fadd_rn(xs, jx); ys = __fadd_rn(ys, jy); }
+  else { xs = __fadd_rn(xs, 0.5f); ys = __fadd_rn(ys, 0.5f); }
+  float d0 = (float)(((double)xs - cx) / fx), d1 = (float)(((double)ys - cy) / fy), d2 = 1.0f;
+  float n = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+  d0 = __fdiv_rn(d0, n); d1 = __fdiv_rn(d1, n); d2 = __fdiv_rn(d2, n);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    dir[r] = __fadd_rn(__fadd_rn(__fmul_rn(R[3 * r], d0), __fmul_rn(R[3 * r + 1], d1)), __fmul_rn(R[3 * r + 2], d2));
+  *norm_out = n;
+}
+
+__global__ void k_compute_direction(const float* __restrict__ R, const int64_t* __restrict__ idx, int n, int w, double fx,
+                                    double fy, double cx, double cy, const float* __restrict__ jitter,
+                                    float* __restrict__ dirs, float* __restrict__ norms) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float d[3], nn;
+    pixel_direction(R, idx[i], w, fx, fy, cx, cy, jitter != nullptr, jitter ? jitter[2 * i] : 0.f,
+                    jitter ? jitter[2 * i + 1] : 0.f, d, &nn);
+    dirs[3 * (size_t)i] = d[0]; dirs[3 * (size_t)i + 1] = d[1]; dirs[3 * (size_t)i + 2] = d[2];
+    norms[i] = nn;
+  }
+}
+
+extern "C" int aln_compute_direction(const float* R_WC, const int64_t* idx, int32_t n, int32_t w, double fx, double fy,
+                                     double cx, double cy, const float* jitter, float* dirs, float* norms, void* stream) {
+  ALN_REQUIRE(R_WC && idx && dirs && norms && w > 0, "compute_direction: bad arguments");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_compute_direction, dim3(aln_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, R_WC, idx, n, w, fx,
+                     fy, cx, cy, jitter, dirs, norms);
+  ALN_CHECK_LAUNCH("compute_direction");
+  return 0;
+}
+
+struct RaygenArgs {
+  AlnFrames fr; AlnBatch out; int B, chunk, frame_lo, frame_hi;
+  uint32_t k_frame, k_pix, k_jx, k_jy;
+  const int* chunk_frames; const int* ray_idx; const float* jitter;
+};
+
+__device__ inline void gather_pixel(const AlnFrames& fr, const AlnBatch& out, int b, int frame, int64_t pix) {
+  size_t hw = (size_t)fr.w * fr.h;
+  size_t src = (size_t)frame * hw + pix;
+  if (out.pixels) {
+    out.pixels[3 * (size_t)b] = fr.images[3 * src]; out.pixels[3 * (size_t)b + 1] = fr.images[3 * src + 1];
+    out.pixels[3 * (size_t)b + 2] = fr.images[3 * src + 2];
+  }
+  if (out.depth) out.depth[b] = (float)((double)fr.depths[src] / 1000.0);       // dataset.py:220
+  if (out.semantic) out.semantic[b] = (int)fr.semantics[src] - 1;                // dataset.py:221-222
+  if (out.features && fr.features) {                                            // dataset.py:231-240
+    int64_t x = pix % fr.w, y = (pix - x) / fr.w;
+    int fx_ = (int)((double)x * ((double)fr.feat_w / (double)fr.w));
+    int fy_ = (int)((double)y * ((double)fr.feat_h / (double)fr.h));
+    const h16* f = (const h16*)fr.features + ((size_t)frame * fr.feat_w * fr.feat_h + (size_t)fy_ * fr.feat_w + fx_) * fr.feat_c;
+    for (int c = 0; c < fr.feat_c; ++c) out.features[(size_t)b * fr.feat_c + c] = (float)f[c];
+  }
+}
+
+__global__ void k_raygen_train(RaygenArgs a) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x) {
+    int ch = b / a.chunk;
+    int frame = a.chunk_frames ? a.chunk_frames[ch]
+                               : a.frame_lo + (int)(aln_rand_u32(a.k_frame, (uint32_t)ch) % (uint32_t)(a.frame_hi - a.frame_lo));
+    int64_t pix = a.ray_idx ? a.ray_idx[b] : a.fr.pixel_indices[aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)a.fr.n_pix];
+    float jx = a.jitter ? a.jitter[2 * b] : aln_rand_uniform(a.k_jx, (uint32_t)b);
+    float jy = a.jitter ? a.jitter[2 * b + 1] : aln_rand_uniform(a.k_jy, (uint32_t)b);
+    float d[3], nn;
+    pixel_direction(a.fr.rotations + 9 * (size_t)frame, pix, a.fr.w, a.fr.fx, a.fr.fy, a.fr.cx, a.fr.cy, true, jx, jy, d, &nn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      a.out.rays_d[3 * (size_t)b + k] = d[k];
+      a.out.rays_o[3 * (size_t)b + k] = a.fr.origins[3 * (size_t)frame + k];
+    }
+    a.out.norms[b] = nn;
+    gather_pixel(a.fr, a.out, b, frame, pix);
+  }
+}
+
+__global__ void k_raygen_frame(AlnFrames fr, AlnBatch out, int frame) {
+  int hw = fr.w * fr.h;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < hw; b += gridDim.x * blockDim.x) {
+    float d[3], nn;
+    pixel_direction(fr.rotations + 9 * (size_t)frame, b, fr.w, fr.fx, fr.fy, fr.cx, fr.cy, false, 0.f, 0.f, d, &nn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      out.rays_d[3 * (size_t)b + k] = d[k];
+      out.rays_o[3 * (size_t)b + k] = fr.origins[3 * (size_t)frame + k];
+    }
+    out.norms[b] = nn;
+    AlnBatch o2 = out; o2.features = nullptr;
+    gather_pixel(fr, o2, b, frame, b);
+  }
+}
+
+static int check_frames(const AlnFrames* fr, const AlnBatch* out) {
+  ALN_REQUIRE(fr && out, "raygen: NULL descriptor");
+  ALN_REQUIRE(fr->images && fr->depths && fr->semantics && fr->rotations && fr->origins, "raygen: NULL frame arrays");
+  ALN_REQUIRE(out->rays_o && out->rays_d && out->norms, "raygen: NULL outputs");
+  ALN_REQUIRE(fr->n_frames > 0 && fr->w > 0 && fr->h > 0, "raygen: empty frame set");
+  return 0;
+}
+
+extern "C" int aln_raygen_train(const AlnFrames* fr, const AlnBatch* out, int32_t B, int32_t chunk, int32_t frame_lo,
+                                int32_t frame_hi, uint32_t seed, uint32_t step, const int32_t* chunk_frames,
+                                const int32_t* ray_idx, const float* jitter, void* stream) {
+  if (int rc = check_frames(fr, out)) return rc;
+  ALN_REQUIRE(chunk > 0 && B % chunk == 0, "raygen_train: batch %d is not a multiple of chunk %d", B, chunk);
+  ALN_REQUIRE(chunk_frames || (0 <= frame_lo && frame_lo < frame_hi && frame_hi <= fr->n_frames), "raygen_train: bad frame range");
+  ALN_REQUIRE(ray_idx || (fr->pixel_indices && fr->n_pix > 0), "raygen_train: pixel_indices missing");
+  if (B <= 0) return 0;
+  RaygenArgs a{*fr, *out, B, chunk, frame_lo, frame_hi, aln_rand_key(seed, ALN_STREAM_FRAME, step),
+               aln_rand_key(seed, ALN_STREAM_PIXEL, step), aln_rand_key(seed, ALN_STREAM_JX, step),
+               aln_rand_key(seed, ALN_STREAM_JY, step), chunk_frames, ray_idx, jitter};
+  hipLaunchKernelGGL(k_raygen_train, dim3(aln_grid_for(B, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  ALN_CHECK_LAUNCH("raygen_train");
+  return 0;
+}
+
+extern "C" int aln_raygen_frame(const AlnFrames* fr, const AlnBatch* out, int32_t frame, void* stream) {
+  if (int rc = check_frames(fr, out)) return rc;
+  ALN_REQUIRE(frame >= 0 && frame < fr->n_frames, "raygen_frame: frame %d out of range", frame);
+  hipLaunchKernelGGL(k_raygen_frame, dim3(aln_grid_for((int64_t)fr->w * fr->h, 256)), dim3(256), 0, (hipStream_t)stream, *fr,
+                     *out, frame);
+  ALN_CHECK_LAUNCH("raygen_frame");
+  return 0;
+}

@@ -1,0 +1,460 @@
+// Ray sampling and volumetric compositing, forward + backward.
+// Replaces the PyTorch op chain of torch-ngp NeRFRenderer.run (fork) reached from
+// autolabel/trainer.py:64-70,102-107,127-133, scripts/export.py:83-89, scripts/render.py:96-102:
+// near_far_from_aabb, stratified coarse z, sample_pdf (cumsum/searchsorted), sort+gather merge,
+// alpha / cumprod weights, weighted sums.  Spec: oracle/nerf_oracle.py (OracleModel.run, sample_pdf).
+//
+// One wavefront (64-thread block) per ray: the per-ray scans (cumprod, cumsum, suffix sums) are
+// chunked scans -- each lane walks a contiguous chunk, lane totals are combined with wave shuffles;
+// the coarse/fine merge is a merge-path rank (binary search in LDS) instead of a generic sort.
+#include "common.h"
+#include <math.h>
+
+#define MAX_S 1024  // max samples per ray per pass
+
+// ------------------------------------------------------------------ coarse
+__global__ void k_sample_coarse(const float* __restrict__ ro, const float* __restrict__ rd, int N, int S1, float bound,
+                                float min_near, int perturb, uint32_t key, const float* __restrict__ noise,
+                                float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ z) {
+  size_t total = (size_t)N * S1;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    int ray = (int)(t / S1), i = (int)(t % S1);
+    float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float o = ro[3 * (size_t)ray + k], d = rd[3 * (size_t)ray + k];
+      float inv = __fdiv_rn(1.0f, d);
+      float t1 = __fmul_rn(__fsub_rn(-bound, o), inv), t2 = __fmul_rn(__fsub_rn(bound, o), inv);
+      tn = fmaxf(tn, fminf(t1, t2));
+      tf = fminf(tf, fmaxf(t1, t2));
+    }
+    bool miss = !(tn <= tf);
+    float near = miss ? min_near : fmaxf(tn, min_near);
+    float far = miss ? min_near : tf;
+    far = fmaxf(far, near);
+    if (i == 0) { nears[ray] = near; fars[ray] = far; }
+    float lin = __fdiv_rn((float)i, (float)(S1 > 1 ? S1 - 1 : 1));
+    float span = __fsub_rn(far, near);
+    float zz = __fadd_rn(near, __fmul_rn(span, lin));
+    if (perturb) {
+      float u = noise ? noise[t] : aln_rand_uniform(key, (uint32_t)t);
+      float sd = __fdiv_rn(span, (float)S1);
+      zz = __fadd_rn(zz, __fmul_rn(__fsub_rn(u, 0.5f), sd));
+    }
+    z[t] = zz;
+  }
+}
+
+extern "C" int aln_sample_coarse(const float* rays_o, const float* rays_d, int32_t N, int32_t S1, float bound,
+                                 float min_near, int32_t perturb, uint32_t seed, uint32_t step, const float* noise,
+                                 float* nears, float* fars, float* z, void* stream) {
+  ALN_REQUIRE(rays_o && rays_d && nears && fars && z && S1 > 0 && S1 <= MAX_S, "sample_coarse: bad arguments");
+  if (N <= 0) return 0;
+  uint32_t key = aln_rand_key(seed, ALN_STREAM_PERTURB, step);
+  hipLaunchKernelGGL(k_sample_coarse, dim3(aln_grid_for((int64_t)N * S1, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                     rays_d, N, S1, bound, min_near, perturb, key, noise, nears, fars, z);
+  ALN_CHECK_LAUNCH("sample_coarse");
+  return 0;
+}
+
+// ------------------------------------------------------------------ wave-level chunked scans over LDS arrays
+// T[i] = prod_{j<i} v[j]   (exclusive), one wave
+__device__ inline void scan_excl_prod(const float* v, float* T, int n, int lane) {
+  int ipl = (n + 63) / 64, s = lane * ipl, e = min(s + ipl, n);
+  float loc = 1.f;
+  for (int i = s; i < e; ++i) loc *= v[i];
+  float inc = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(inc, o); if (lane >= o) inc *= t; }
+  float run = __shfl_up(inc, 1);
+  if (lane == 0) run = 1.f;
+  for (int i = s; i < e; ++i) { T[i] = run; run *= v[i]; }
+}
+// C[i] = sum_{j<=i} v[j]  (inclusive)
+__device__ inline void scan_incl_sum(const float* v, float* C, int n, int lane) {
+  int ipl = (n + 63) / 64, s = lane * ipl, e = min(s + ipl, n);
+  float loc = 0.f;
+  for (int i = s; i < e; ++i) loc += v[i];
+  float inc = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+  float run = __shfl_up(inc, 1);
+  if (lane == 0) run = 0.f;
+  for (int i = s; i < e; ++i) { run += v[i]; C[i] = run; }
+}
+// R[i] = sum_{j>i} v[j]   (exclusive suffix)
+__device__ inline void scan_suffix_excl(const float* v, float* R, int n, int lane) {
+  int ipl = (n + 63) / 64, s = lane * ipl, e = min(s + ipl, n);
+  float loc = 0.f;
+  for (int i = s; i < e; ++i) loc += v[i];
+  float inc = loc;  // inclusive suffix over lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { float t = __shfl_down(inc, o); if (lane + o < 64) inc += t; }
+  float run = __shfl_down(inc, 1);
+  if (lane == 63) run = 0.f;
+  for (int i = e - 1; i >= s; --i) { R[i] = run; run += v[i]; }
+}
+
+// ------------------------------------------------------------------ fine (importance) samples
+__global__ __launch_bounds__(64) void k_sample_fine(const float* __restrict__ zc, const float* __restrict__ sigma,
+                                                   const float* __restrict__ nears, const float* __restrict__ fars, int N,
+                                                   int S1, int S2, float density_scale, int perturb, uint32_t key,
+                                                   const float* __restrict__ u_in, float* __restrict__ zf) {
+  extern __shared__ float sm[];
+  float* z = sm;            // [S1]
+  float* a = z + S1;        // [S1]  val / pdf scratch
+  float* b = a + S1;        // [S1]  T / cdf
+  float* w = b + S1;        // [S1]
+  int S2p = 1; while (S2p < S2) S2p <<= 1;
+  float* u = w + S1;        // [S2p]
+  const int lane = threadIdx.x;
+  for (int ray = blockIdx.x; ray < N; ray += gridDim.x) {
+    const float sd = __fdiv_rn(__fsub_rn(fars[ray], nears[ray]), (float)S1);
+    for (int i = lane; i < S1; i += 64) z[i] = zc[(size_t)ray * S1 + i];
+    __syncthreads();
+    for (int i = lane; i < S1; i += 64) {
+      float delta = (i + 1 < S1) ? z[i + 1] - z[i] : sd;
+      float alpha = 1.f - expf(-delta * density_scale * sigma[(size_t)ray * S1 + i]);
+      w[i] = alpha;
+      a[i] = 1.f - alpha + 1e-15f;
+    }
+    __syncthreads();
+    scan_excl_prod(a, b, S1, lane);
+    __syncthreads();
+    for (int i = lane; i < S1; i += 64) w[i] = w[i] * b[i];
+    __syncthreads();
+    // pdf over weights[1:-1] (+1e-5), cdf with leading 0 -> length S1-1
+    const int nb = S1 - 2;
+    float part = 0.f;
+    for (int k = lane; k < nb; k += 64) { a[k] = w[k + 1] + 1e-5f; part += a[k]; }
+    float tot = wave_sum(part);
+    __syncthreads();
+    for (int k = lane; k < nb; k += 64) a[k] = a[k] / tot;
+    __syncthreads();
+    scan_incl_sum(a, b + 1, nb, lane);
+    if (lane == 0) b[0] = 0.f;
+    // uniforms
+    for (int j = lane; j < S2p; j += 64) {
+      float v = INFINITY;
+      if (j < S2) {
+        if (!perturb) v = __fdiv_rn((float)j + 0.5f, (float)S2);
+        else v = u_in ? u_in[(size_t)ray * S2 + j] : aln_rand_uniform(key, (uint32_t)((size_t)ray * S2 + j));
+      }
+      u[j] = v;
+    }
+    __syncthreads();
+    if (perturb) {  // bitonic sort ascending
+      for (int k = 2; k <= S2p; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = lane; i < S2p; i += 64) {
+            int ixj = i ^ j;
+            if (ixj > i) {
+              float x = u[i], y = u[ixj];
+              bool up = (i & k) == 0;
+              if ((x > y) == up) { u[i] = y; u[ixj] = x; }
+            }
+          }
+          __syncthreads();
+        }
+    }
+    const int nc = S1 - 1;  // cdf / bins length
+    for (int j = lane; j < S2; j += 64) {
+      float uu = u[j];
+      int lo = 0, hi = nc;  // first index with cdf > u  (searchsorted right=True)
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (b[mid] > uu) hi = mid; else lo = mid + 1; }
+      int below = max(lo - 1, 0), above = min(lo, nc - 1);
+      float cb = b[below], ca = b[above];
+      float bb = z[below] + 0.5f * (z[below + 1] - z[below]);
+      float ba = z[above] + 0.5f * (z[above + 1] - z[above]);
+      float den = ca - cb;
+      if (den < 1e-5f) den = 1.f;
+      float t = (uu - cb) / den;
+      zf[(size_t)ray * S2 + j] = bb + t * (ba - bb);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int aln_sample_fine(const float* z_coarse, const float* sigma_coarse, const float* nears, const float* fars,
+                               int32_t N, int32_t S1, int32_t S2, float density_scale, int32_t perturb, uint32_t seed,
+                               uint32_t step, const float* u, float* z_fine, void* stream) {
+  ALN_REQUIRE(z_coarse && sigma_coarse && nears && fars && z_fine, "sample_fine: NULL pointer");
+  ALN_REQUIRE(S1 >= 3 && S1 <= MAX_S && S2 > 0 && S2 <= MAX_S, "sample_fine: S1=%d S2=%d out of range", S1, S2);
+  if (N <= 0) return 0;
+  int S2p = 1; while (S2p < S2) S2p <<= 1;
+  size_t lds = (size_t)(4 * S1 + S2p) * sizeof(float);
+  uint32_t key = aln_rand_key(seed, ALN_STREAM_PDF, step);
+  hipLaunchKernelGGL(k_sample_fine, dim3(N < 65535 ? N : 65535), dim3(64), lds, (hipStream_t)stream, z_coarse, sigma_coarse,
+                     nears, fars, N, S1, S2, density_scale, perturb, key, u, z_fine);
+  ALN_CHECK_LAUNCH("sample_fine");
+  return 0;
+}
+
+// ------------------------------------------------------------------ compositing
+// local sample id: < S1 coarse i, else fine j = id - S1.  row(ray, id) in pass-major order.
+__device__ inline size_t row_of(int ray, int id, int N, int S1, int S2) {
+  return id < S1 ? (size_t)ray * S1 + id : (size_t)N * S1 + (size_t)ray * S2 + (id - S1);
+}
+
+struct CompFwd {
+  const float* ro; const float* rd; const float* norms; const float* nears; const float* fars;
+  const float* z;      // [M] rows
+  const float* sigma;  // [M] rows
+  int N, S1, S2; float bound, density_scale;
+  uint16_t* perm;      // [N, S]
+  float* w_row; float* T_row; float* delta_row;  // [M]
+  float* wsum; float* depth; float* depth_var; float* coords;  // [N], [N], [N], [N,3]
+};
+
+__global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
+  extern __shared__ float sm[];
+  const int S = p.S1 + p.S2, lane = threadIdx.x;
+  float* zs = sm;          // sorted z [S]
+  float* sg = zs + S;      // sorted sigma
+  float* v = sg + S;       // 1-alpha+eps
+  float* T = v + S;
+  float* zin = T + S;      // unsorted z [S]
+  uint16_t* lid = (uint16_t*)(zin + S);  // [S]
+  for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
+    for (int i = lane; i < S; i += 64) zin[i] = p.z[row_of(ray, i, p.N, p.S1, p.S2)];
+    __syncthreads();
+    const float* zc = zin; const float* zf = zin + p.S1;
+    for (int i = lane; i < S; i += 64) {
+      int pos;
+      if (i < p.S1) {  // # fine strictly less
+        float x = zc[i]; int lo = 0, hi = p.S2;
+        while (lo < hi) { int m = (lo + hi) >> 1; if (zf[m] < x) lo = m + 1; else hi = m; }
+        pos = i + lo;
+      } else {  // # coarse <=
+        float x = zf[i - p.S1]; int lo = 0, hi = p.S1;
+        while (lo < hi) { int m = (lo + hi) >> 1; if (zc[m] <= x) lo = m + 1; else hi = m; }
+        pos = (i - p.S1) + lo;
+      }
+      zs[pos] = zin[i];
+      sg[pos] = p.sigma[row_of(ray, i, p.N, p.S1, p.S2)];
+      lid[pos] = (uint16_t)i;
+    }
+    __syncthreads();
+    const float sd = __fdiv_rn(__fsub_rn(p.fars[ray], p.nears[ray]), (float)p.S1);
+    for (int k = lane; k < S; k += 64) {
+      float delta = (k + 1 < S) ? zs[k + 1] - zs[k] : sd;
+      float alpha = 1.f - expf(-delta * p.density_scale * sg[k]);
+      v[k] = 1.f - alpha + 1e-15f;
+      sg[k] = alpha;       // reuse: alpha
+      zin[k] = delta;      // reuse: delta
+    }
+    __syncthreads();
+    scan_excl_prod(v, T, S, lane);
+    __syncthreads();
+    const float inv_norm = 1.0f / p.norms[ray];
+    float a_w = 0.f, a_d = 0.f, a_c[3] = {0, 0, 0};
+    for (int k = lane; k < S; k += 64) {
+      float w = sg[k] * T[k];
+      size_t row = row_of(ray, lid[k], p.N, p.S1, p.S2);
+      p.w_row[row] = w; p.T_row[row] = T[k]; p.delta_row[row] = zin[k];
+      p.perm[(size_t)ray * S + k] = lid[k];
+      float x[3];
+      aln_sample_xyz(p.ro + 3 * (size_t)ray, p.rd + 3 * (size_t)ray, zs[k], p.bound, x);
+      a_w += w; a_d += w * (zs[k] * inv_norm);
+      a_c[0] += w * x[0]; a_c[1] += w * x[1]; a_c[2] += w * x[2];
+      v[k] = w;  // keep for variance pass
+    }
+    a_w = wave_sum(a_w); a_d = wave_sum(a_d);
+    a_c[0] = wave_sum(a_c[0]); a_c[1] = wave_sum(a_c[1]); a_c[2] = wave_sum(a_c[2]);
+    float var = 0.f;
+    for (int k = lane; k < S; k += 64) { float e = zs[k] * inv_norm - a_d; var += v[k] * e * e; }
+    var = wave_sum(var);
+    if (lane == 0) {
+      p.wsum[ray] = a_w; p.depth[ray] = a_d; p.depth_var[ray] = var;
+      p.coords[3 * (size_t)ray] = a_c[0]; p.coords[3 * (size_t)ray + 1] = a_c[1]; p.coords[3 * (size_t)ray + 2] = a_c[2];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int aln_composite_fwd(const float* rays_o, const float* rays_d, const float* norms, const float* nears,
+                                 const float* fars, const float* z, const float* sigma, int32_t N, int32_t S1, int32_t S2,
+                                 float bound, float density_scale, uint16_t* perm, float* w_row, float* T_row,
+                                 float* delta_row, float* wsum, float* depth, float* depth_var, float* coords, void* stream) {
+  ALN_REQUIRE(rays_o && rays_d && norms && nears && fars && z && sigma && perm && w_row && T_row && delta_row && wsum &&
+                  depth && depth_var && coords, "composite_fwd: NULL pointer");
+  ALN_REQUIRE(S1 > 0 && S2 >= 0 && S1 + S2 <= 2 * MAX_S, "composite_fwd: sample counts out of range");
+  if (N <= 0) return 0;
+  CompFwd p{rays_o, rays_d, norms, nears, fars, z, sigma, N, S1, S2, bound, density_scale,
+            perm, w_row, T_row, delta_row, wsum, depth, depth_var, coords};
+  int S = S1 + S2;
+  size_t lds = (size_t)S * (5 * sizeof(float) + sizeof(uint16_t)) + 16;
+  hipLaunchKernelGGL(k_composite_fwd, dim3(N < 65535 ? N : 65535), dim3(64), lds, (hipStream_t)stream, p);
+  ALN_CHECK_LAUNCH("composite_fwd");
+  return 0;
+}
+
+// image / semantic / features sums.  color_out is the compacted color-MLP output (pre-sigmoid, fp16,
+// [n_live,16]); cidx_row maps row -> compact index (-1 = masked, contributes 0: models.py:195-203).
+struct CompOut {
+  const float* w_row; const int* cidx_row; const h16* color_out; const h16* logits; const h16* feat;
+  const float* wsum;
+  int N, S1, S2, C, Cpad, D; float bg;
+  float* image; float* semantic; float* features;
+};
+
+__global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
+  const int S = p.S1 + p.S2, lane = threadIdx.x;
+  for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
+    // rgb: lanes split the samples, wave-reduce
+    float c0 = 0, c1 = 0, c2 = 0;
+    for (int k = lane; k < S; k += 64) {
+      size_t row = row_of(ray, k, p.N, p.S1, p.S2);
+      int ci = p.cidx_row[row];
+      if (ci >= 0) {
+        float w = p.w_row[row];
+        h16x4 o = *(const h16x4*)(p.color_out + (size_t)ci * 16);
+        c0 += w / (1.f + expf(-(float)o[0])); c1 += w / (1.f + expf(-(float)o[1])); c2 += w / (1.f + expf(-(float)o[2]));
+      }
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+    if (lane == 0) {
+      float r = (1.f - p.wsum[ray]) * p.bg;
+      p.image[3 * (size_t)ray] = c0 + r; p.image[3 * (size_t)ray + 1] = c1 + r; p.image[3 * (size_t)ray + 2] = c2 + r;
+    }
+    // channel-parallel sums: lane = channel, sequential over samples (coalesced row reads)
+    if (p.logits) {
+      for (int c = lane; c < p.C; c += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < S; ++k) {
+          size_t row = row_of(ray, k, p.N, p.S1, p.S2);
+          acc += p.w_row[row] * (float)p.logits[row * p.Cpad + c];
+        }
+        p.semantic[(size_t)ray * p.C + c] = acc;
+      }
+      for (int d = lane; d < p.D; d += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < S; ++k) {
+          size_t row = row_of(ray, k, p.N, p.S1, p.S2);
+          acc += p.w_row[row] * (float)p.feat[row * p.D + d];
+        }
+        p.features[(size_t)ray * p.D + d] = acc;
+      }
+    }
+  }
+}
+
+extern "C" int aln_composite_out(const float* w_row, const int32_t* cidx_row, const void* color_out, const void* logits,
+                                 const void* feat, const float* wsum, int32_t N, int32_t S1, int32_t S2, int32_t C,
+                                 int32_t Cpad, int32_t D, float bg, float* image, float* semantic, float* features,
+                                 void* stream) {
+  ALN_REQUIRE(w_row && cidx_row && color_out && wsum && image, "composite_out: NULL pointer");
+  ALN_REQUIRE(!logits || (feat && semantic && features), "composite_out: semantic buffers missing");
+  if (N <= 0) return 0;
+  CompOut p{w_row, cidx_row, (const h16*)color_out, (const h16*)logits, (const h16*)feat, wsum, N, S1, S2, C, Cpad, D, bg,
+            image, semantic, features};
+  hipLaunchKernelGGL(k_composite_out, dim3(N < 65535 ? N : 65535), dim3(64), 0, (hipStream_t)stream, p);
+  ALN_CHECK_LAUNCH("composite_out");
+  return 0;
+}
+
+// ------------------------------------------------------------------ backward
+struct CompBwd {
+  const float* norms; const float* z; const float* sigma;
+  const uint16_t* perm; const float* w_row; const float* T_row; const float* delta_row;
+  const int* cidx_row; const h16* color_out; const h16* logits; const h16* feat; const h16* sigma_out;  // [M,16], col 0 = h0
+  const float* g_image; const float* g_depth; const float* g_sem; const float* g_feat;  // per ray, already loss-scaled
+  int N, S1, S2, C, Cpad, D, D_used; float bg, density_scale;
+  float* d_h0;         // [M] fp32
+  h16* d_color_out;    // [n_live,16]
+  h16* d_logits;       // [M,Cpad]
+  h16* d_feat;         // [M,D]
+  int* found_inf;
+};
+
+__global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
+  extern __shared__ float sm[];
+  const int S = p.S1 + p.S2, lane = threadIdx.x;
+  float* P = sm;          // sorted dw*w [S]
+  float* R = P + S;       // suffix
+  float* dws = R + S;     // sorted dw
+  float* gs = dws + S;    // g_sem [C]
+  float* gf = gs + p.Cpad;  // g_feat [D]
+  bool bad = false;
+  for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
+    const float gi0 = p.g_image[3 * (size_t)ray], gi1 = p.g_image[3 * (size_t)ray + 1], gi2 = p.g_image[3 * (size_t)ray + 2];
+    const float gd = p.g_depth[ray] / p.norms[ray];
+    if (p.logits) {
+      for (int c = lane; c < p.Cpad; c += 64) gs[c] = c < p.C ? p.g_sem[(size_t)ray * p.C + c] : 0.f;
+      for (int d = lane; d < p.D; d += 64) gf[d] = p.g_feat ? p.g_feat[(size_t)ray * p.D + d] : 0.f;
+    }
+    __syncthreads();
+    for (int k = lane; k < S; k += 64) {
+      int id = p.perm[(size_t)ray * S + k];
+      size_t row = row_of(ray, id, p.N, p.S1, p.S2);
+      float w = p.w_row[row];
+      float dw = -p.bg * (gi0 + gi1 + gi2) + p.z[row] * gd;
+      int ci = p.cidx_row[row];
+      if (ci >= 0) {
+        h16x4 o = *(const h16x4*)(p.color_out + (size_t)ci * 16);
+        float r0 = 1.f / (1.f + expf(-(float)o[0])), r1 = 1.f / (1.f + expf(-(float)o[1])), r2 = 1.f / (1.f + expf(-(float)o[2]));
+        dw += r0 * gi0 + r1 * gi1 + r2 * gi2;
+        h16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = lo;
+        lo[0] = (h16)(w * gi0 * r0 * (1.f - r0)); lo[1] = (h16)(w * gi1 * r1 * (1.f - r1)); lo[2] = (h16)(w * gi2 * r2 * (1.f - r2));
+        bad |= !(fabsf((float)lo[0]) <= 65504.f) | !(fabsf((float)lo[1]) <= 65504.f) | !(fabsf((float)lo[2]) <= 65504.f);
+        *(h16x8*)(p.d_color_out + (size_t)ci * 16) = lo;
+        *(h16x8*)(p.d_color_out + (size_t)ci * 16 + 8) = hi;
+      }
+      if (p.logits) {
+        const h16* lg = p.logits + row * p.Cpad; h16* dl = p.d_logits + row * p.Cpad;
+        for (int c = 0; c < p.Cpad; c += 8) {
+          h16x8 v = *(const h16x8*)(lg + c), o8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dw += (float)v[j] * gs[c + j]; o8[j] = (h16)(w * gs[c + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
+          *(h16x8*)(dl + c) = o8;
+        }
+        const h16* ft = p.feat + row * p.D; h16* df = p.d_feat + row * p.D;
+        for (int d = 0; d < p.D; d += 8) {
+          h16x8 v = *(const h16x8*)(ft + d), o8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dw += (float)v[j] * gf[d + j]; o8[j] = (h16)(w * gf[d + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
+          *(h16x8*)(df + d) = o8;
+        }
+      }
+      dws[k] = dw; P[k] = dw * w;
+    }
+    __syncthreads();
+    scan_suffix_excl(P, R, S, lane);
+    __syncthreads();
+    for (int k = lane; k < S; k += 64) {
+      int id = p.perm[(size_t)ray * S + k];
+      size_t row = row_of(ray, id, p.N, p.S1, p.S2);
+      float delta = p.delta_row[row], T = p.T_row[row];
+      float om = expf(-delta * p.density_scale * p.sigma[row]);  // 1 - alpha
+      float dsig = delta * p.density_scale * om * (dws[k] * T - R[k] / (om + 1e-15f));
+      float h0 = (float)p.sigma_out[row * 16];
+      float g = dsig * expf(fminf(fmaxf(h0, -15.f), 15.f));
+      bad |= !(fabsf(g) <= 65504.f);
+      p.d_h0[row] = g;
+    }
+    __syncthreads();
+  }
+  if (p.found_inf && __any(bad) && lane == 0) atomicOr(p.found_inf, 1);
+}
+
+extern "C" int aln_composite_bwd(const float* norms, const float* z, const float* sigma, const uint16_t* perm,
+                                 const float* w_row, const float* T_row, const float* delta_row, const int32_t* cidx_row,
+                                 const void* color_out, const void* logits, const void* feat, const void* sigma_out,
+                                 const float* g_image, const float* g_depth, const float* g_sem, const float* g_feat,
+                                 int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad, int32_t D, float bg,
+                                 float density_scale, float* d_h0, void* d_color_out, void* d_logits, void* d_feat,
+                                 int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(norms && z && sigma && perm && w_row && T_row && delta_row && cidx_row && color_out && sigma_out && g_image &&
+                  g_depth && d_h0 && d_color_out, "composite_bwd: NULL pointer");
+  ALN_REQUIRE(!logits || (feat && g_sem && d_logits && d_feat), "composite_bwd: semantic buffers missing");
+  ALN_REQUIRE(Cpad % 8 == 0 && D % 8 == 0, "composite_bwd: Cpad and D must be multiples of 8");
+  if (N <= 0) return 0;
+  CompBwd p{norms, z, sigma, perm, w_row, T_row, delta_row, cidx_row, (const h16*)color_out, (const h16*)logits,
+            (const h16*)feat, (const h16*)sigma_out, g_image, g_depth, g_sem, g_feat, N, S1, S2, C, Cpad, D, D, bg,
+            density_scale, d_h0, (h16*)d_color_out, (h16*)d_logits, (h16*)d_feat, found_inf};
+  int S = S1 + S2;
+  size_t lds = (size_t)(3 * S + Cpad + D) * sizeof(float);
+  hipLaunchKernelGGL(k_composite_bwd, dim3(N < 65535 ? N : 65535), dim3(64), lds, (hipStream_t)stream, p);
+  ALN_CHECK_LAUNCH("composite_bwd");
+  return 0;
+}

@@ -1,0 +1,256 @@
+"""Host-side orchestration of the HIP kernels for one render / training pass.
+
+This is the glue the reference gets from torch-ngp's ``NeRFRenderer.run`` (a chain of PyTorch ops) plus
+tinycudann's module wrappers; here it is a fixed sequence of C-ABI launches on the current HIP stream
+with caller-owned workspaces (no allocation inside the step once shapes are warm, no host sync).
+
+Parameter memory: one flat fp32 master buffer ``[hash-grid table | sigma | color | semf | semo]`` with a
+matching flat gradient buffer (a single RCCL all-reduce covers every gradient), an fp16 shadow of the
+table (what the gather kernel reads) and fp16 MFMA-fragment copies of the MLP weights.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import hip as H
+
+
+def pad16(n):
+    return (n + 15) // 16 * 16
+
+
+class MlpSpec:
+    """Padded shape of one bias-free ReLU MLP (tcnn Network; autolabel/models.py:84-136)."""
+
+    def __init__(self, name, n_in, hidden, n_out, n_hidden):
+        self.name, self.n_in, self.hidden, self.n_out, self.n_hidden = name, n_in, hidden, n_out, n_hidden
+        self.in_pad, self.out_pad = pad16(n_in), pad16(n_out)
+        self.shapes = [(hidden, self.in_pad)] + [(hidden, hidden)] * (n_hidden - 1) + [(self.out_pad, hidden)]
+        self.n_params = sum(o * i for o, i in self.shapes)
+        if hidden not in (64, 128) or n_hidden not in (1, 2):
+            raise NotImplementedError(f'{name}: hidden={hidden}, n_hidden={n_hidden} has no HIP kernel yet '
+                                      '(supported: hidden in {64,128}, 1-2 hidden layers)')
+
+
+class ModelLayout:
+    """Flat parameter layout for ALNetwork (sizes from autolabel/model_utils.py:61-74)."""
+
+    def __init__(self, encoding, geo_feat_dim, hidden_dim, hidden_dim_color, hidden_dim_semantic, semantic_classes,
+                 num_layers=2, num_layers_color=2, bound=1.0, grid=None):
+        self.enc = H.make_enc_desc(encoding, float(bound), grid)
+        self.G, self.D, self.C = geo_feat_dim, hidden_dim_semantic, semantic_classes
+        if geo_feat_dim != 15:
+            raise NotImplementedError('geo_feat_dim != 15 is not supported by the HIP heads (sigma output is 16 wide)')
+        self.n_grid = int(self.enc.grid.n_entries) * 2 if self.enc.use_grid else 0
+        self.nets = {
+            'sigma': MlpSpec('sigma', self.enc.enc_dim, hidden_dim, 1 + geo_feat_dim, num_layers),
+            'color': MlpSpec('color', 16 + geo_feat_dim, hidden_dim_color, 3, num_layers_color),
+            'semf': MlpSpec('semf', geo_feat_dim, hidden_dim_semantic, hidden_dim_semantic, 2),
+            'semo': MlpSpec('semo', hidden_dim_semantic + geo_feat_dim, 64, semantic_classes, 1),
+        }
+        self.offsets, o = {}, self.n_grid
+        for k, s in self.nets.items():
+            self.offsets[k] = o
+            o += s.n_params
+        self.n_total = o
+        self.Cpad = self.nets['semo'].out_pad
+
+
+class Params:
+    """Device-resident parameter / gradient / shadow buffers."""
+
+    def __init__(self, layout, device):
+        L = self.layout = layout
+        self.device = device
+        self.flat = torch.zeros(L.n_total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(L.n_total + 8, dtype=torch.float32, device=device)  # +8: side channel for DP (found_inf)
+        self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
+        self.frags, self.descs = {}, {}
+        for k, s in L.nets.items():
+            nf = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 0)
+            nb = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 1)
+            wf = torch.zeros(nf, dtype=torch.float16, device=device)
+            wb = torch.zeros(nb, dtype=torch.float16, device=device)
+            self.frags[k] = (wf, wb)
+            self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr())
+
+    def net_view(self, k, buf=None):
+        buf = self.flat if buf is None else buf
+        o = self.layout.offsets[k]
+        return buf[o:o + self.layout.nets[k].n_params]
+
+    def grid_view(self, buf=None):
+        buf = self.flat if buf is None else buf
+        return buf[:self.layout.n_grid]
+
+    def refresh_shadows(self, grid=True):
+        """fp32 master -> fp16 table + MFMA fragments (after init / checkpoint load / optimizer step)."""
+        L = self.layout
+        if grid and L.n_grid:
+            H.call('aln_cast_f16', H.ptr(self.flat), H.ptr(self.table16), L.n_grid, H.stream())
+        for k, s in L.nets.items():
+            wf, wb = self.frags[k]
+            H.call('aln_mlp_repack', C.c_void_p(self.flat.data_ptr() + 4 * L.offsets[k]), s.in_pad, s.hidden, s.out_pad,
+                   s.n_hidden, H.ptr(wf), H.ptr(wb), H.stream())
+
+
+class Workspace:
+    """Lazily allocated, shape-keyed device buffers (the caller owns all memory the kernels touch)."""
+
+    def __init__(self, device):
+        self.device, self.bufs = device, {}
+
+    def get(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(name)
+        if t is None or t[0] != key:
+            self.bufs[name] = (key, torch.empty(shape, dtype=dtype, device=self.device))
+        return self.bufs[name][1]
+
+
+f16, f32_, i32_ = torch.float16, torch.float32, torch.int32
+
+
+class HipPipeline:
+    """render forward / backward as a fixed launch sequence (renderer semantics: oracle/nerf_oracle.py run())."""
+
+    def __init__(self, layout, params, density_scale=1.0, min_near=0.2):
+        H.require_gpu()
+        self.L, self.P = layout, params
+        self.ws = Workspace(params.device)
+        self.density_scale, self.min_near = float(density_scale), float(min_near)
+        self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
+
+    # ---- point queries (models.py:175-188, 190-220, 248-256)
+    def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train):
+        e, s = self.L.enc, self.L.nets['sigma']
+        H.call('aln_encode_fwd', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows,
+               stride, H.ptr(enc), H.stream())
+        H.call('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, H.ptr(h1) if train else None,
+               H.ptr(h2) if train else None, H.ptr(out), H.stream())
+        H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sigma), H.stream())
+
+    def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
+                want_semantic=True, bg=1.0):
+        L, P, ws = self.L, self.P, self.ws
+        N = rays_o.shape[0]
+        S, M = S1 + S2, N * (S1 + S2)
+        M1 = N * S1
+        e, nets = L.enc, L.nets
+        dev = rays_o.device
+        g = lambda n, shp, dt: ws.get(n, shp, dt)
+        c = dict(N=N, S1=S1, S2=S2, M=M, train=train, want_semantic=want_semantic, bg=float(bg),
+                 rays_o=rays_o, rays_d=rays_d, norms=norms)
+        c['nears'], c['fars'] = g('nears', (N,), f32_), g('fars', (N,), f32_)
+        z = c['z'] = g('z', (M,), f32_)
+        enc = c['enc'] = g('enc', (M, e.enc_pad), f16)
+        hs = nets['sigma'].hidden
+        h1 = c['h1'] = g('h1', (M if train else 1, hs), f16)
+        h2 = c['h2'] = g('h2', (M if train else 1, hs), f16)
+        sout = c['sigma_out'] = g('sigma_out', (M, 16), f16)
+        sigma = c['sigma'] = g('sigma', (M,), f32_)
+        H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
+               H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.stream())
+        self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train)
+        if S2 > 0:
+            zf = z[M1:]
+            H.call('aln_sample_fine', H.ptr(z), H.ptr(sigma), H.ptr(c['nears']), H.ptr(c['fars']), N, S1, S2,
+                   self.density_scale, int(perturb), seed, step, H.ptr(u), H.ptr(zf), H.stream())
+            self.density_rows(N * S2, rays_o, rays_d, zf, None, S2, enc[M1:], h1[M1:] if train else h1,
+                              h2[M1:] if train else h2, sout[M1:], sigma[M1:], train)
+        perm = c['perm'] = g('perm', (N, S), torch.int16)
+        w_row, T_row, d_row = g('w_row', (M,), f32_), g('T_row', (M,), f32_), g('delta_row', (M,), f32_)
+        c.update(w_row=w_row, T_row=T_row, delta_row=d_row)
+        out = {k: torch.empty(shp, dtype=f32_, device=dev) for k, shp in
+               [('weights_sum', (N,)), ('depth', (N,)), ('depth_variance', (N,)), ('coordinates_map', (N, 3)),
+                ('image', (N, 3))]}
+        H.call('aln_composite_fwd', H.ptr(rays_o), H.ptr(rays_d), H.ptr(norms), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z),
+               H.ptr(sigma), N, S1, S2, e.bound, self.density_scale, H.ptr(perm), H.ptr(w_row), H.ptr(T_row), H.ptr(d_row),
+               H.ptr(out['weights_sum']), H.ptr(out['depth']), H.ptr(out['depth_variance']), H.ptr(out['coordinates_map']),
+               H.stream())
+        # color head on live samples only (models.py:195-203)
+        n_live, live_idx, cidx = g('n_live', (1,), i32_), g('live_idx', (M,), i32_), g('cidx_row', (M,), i32_)
+        c.update(n_live=n_live, live_idx=live_idx, cidx_row=cidx)
+        H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.stream())
+        cs = nets['color']
+        cin = c['color_in'] = g('color_in', (M, cs.in_pad), f16)
+        ch1 = c['ch1'] = g('ch1', (M if train else 1, cs.hidden), f16)
+        ch2 = c['ch2'] = g('ch2', (M if train else 1, cs.hidden), f16)
+        cout = c['color_out'] = g('color_out', (M, cs.out_pad), f16)
+        H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G,
+               cs.in_pad, H.ptr(cin), H.stream())
+        H.call('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if train else None,
+               H.ptr(ch2) if train else None, H.ptr(cout), H.stream())
+        logits = feat = None
+        if want_semantic:
+            fs, os_ = nets['semf'], nets['semo']
+            fin = c['semf_in'] = g('semf_in', (M, fs.in_pad), f16)
+            fh1 = c['fh1'] = g('fh1', (M if train else 1, fs.hidden), f16)
+            fh2 = c['fh2'] = g('fh2', (M if train else 1, fs.hidden), f16)
+            feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
+            oin = c['semo_in'] = g('semo_in', (M, os_.in_pad), f16)
+            oh1 = c['oh1'] = g('oh1', (M if train else 1, os_.hidden), f16)
+            logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
+            H.call('aln_build_sem_in', H.ptr(sout), None, M, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
+            H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if train else None,
+                   H.ptr(fh2) if train else None, H.ptr(feat), H.stream())
+            H.call('aln_build_sem_in', H.ptr(sout), H.ptr(feat), M, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
+            H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if train else None, None,
+                   H.ptr(logits), H.stream())
+            out['semantic'] = torch.empty((N, L.C), dtype=f32_, device=dev)
+            out['semantic_features'] = torch.empty((N, L.D), dtype=f32_, device=dev)
+        H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(logits), H.ptr(feat), H.ptr(out['weights_sum']),
+               N, S1, S2, L.C, L.Cpad, L.D, float(bg), H.ptr(out['image']), H.ptr(out.get('semantic')),
+               H.ptr(out.get('semantic_features')), H.stream())
+        return out, c
+
+    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None):
+        """Accumulate d(loss)/d(params) into P.grad from per-ray output gradients (fp32, already loss-scaled)."""
+        L, P, ws = self.L, self.P, self.ws
+        assert c['train'], 'backward needs a forward(train=True) context'
+        N, S1, S2, M = c['N'], c['S1'], c['S2'], c['M']
+        M1 = N * S1
+        nets, e = L.nets, L.enc
+        g = lambda n, shp, dt: ws.get(n, shp, dt)
+        sem = c['want_semantic'] and g_sem is not None
+        fi = H.ptr(self.found_inf)
+        gp = lambda k: C.c_void_p(P.grad.data_ptr() + 4 * L.offsets[k])
+        d_h0 = g('d_h0', (M,), f32_)
+        cs = nets['color']
+        d_cout = g('d_color_out', (M, cs.out_pad), f16)
+        d_logits = g('d_logits', (M, L.Cpad), f16) if sem else None
+        d_feat = g('d_feat', (M, L.D), f16) if sem else None
+        if sem and g_feat is None:
+            g_feat = torch.zeros((N, L.D), dtype=f32_, device=g_image.device)
+        H.call('aln_composite_bwd', H.ptr(c['norms']), H.ptr(c['z']), H.ptr(c['sigma']), H.ptr(c['perm']), H.ptr(c['w_row']),
+               H.ptr(c['T_row']), H.ptr(c['delta_row']), H.ptr(c['cidx_row']), H.ptr(c['color_out']),
+               H.ptr(c['logits']) if sem else None, H.ptr(c['feat']) if sem else None, H.ptr(c['sigma_out']), H.ptr(g_image),
+               H.ptr(g_depth), H.ptr(g_sem) if sem else None, H.ptr(g_feat) if sem else None, N, S1, S2, L.C, L.Cpad, L.D,
+               c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), H.ptr(d_logits), H.ptr(d_feat), fi, H.stream())
+        # color head
+        dA1, dA2 = g('dA1', (M, 128), f16), g('dA2', (M, 128), f16)
+        d_cin = g('d_color_in', (M, cs.in_pad), f16)
+        H.call('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), H.ptr(c['ch1']), H.ptr(c['ch2']), H.ptr(d_cout),
+               M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream())
+        d_fin = d_oin = None
+        if sem:
+            fs, os_ = nets['semf'], nets['semo']
+            d_oin = g('d_semo_in', (M, os_.in_pad), f16)
+            H.call('aln_mlp_bwd', C.byref(P.descs['semo']), H.ptr(c['semo_in']), H.ptr(c['oh1']), None, H.ptr(d_logits), M, None,
+                   H.ptr(dA1), None, H.ptr(d_oin), gp('semo'), fi, H.stream())
+            H.call('aln_assemble_dsemf_out', H.ptr(d_feat), H.ptr(c['feat']), H.ptr(d_oin), M, L.D, os_.in_pad, fi, H.stream())
+            d_fin = g('d_semf_in', (M, fs.in_pad), f16)
+            H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), H.ptr(c['fh1']), H.ptr(c['fh2']), H.ptr(d_feat), M,
+                   None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
+        d_sout = g('d_sigma_out', (M, 16), f16)
+        H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), nets['semo'].in_pad, L.D,
+               H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
+        d_enc = g('d_enc', (M, e.enc_pad), f16)
+        H.call('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), H.ptr(c['h1']), H.ptr(c['h2']), H.ptr(d_sout), M, None,
+               H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream())
+        ro, rd, z = c['rays_o'], c['rays_d'], c['z']
+        H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M1, S1, H.ptr(d_enc), H.ptr(P.grad), H.stream())
+        if S2 > 0:
+            H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, N * S2, S2, H.ptr(d_enc[M1:]),
+                   H.ptr(P.grad), H.stream())

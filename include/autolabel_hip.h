@@ -1,0 +1,128 @@
+/* autolabel_hip.h -- C ABI of libautolabel_hip.so (MI355X / gfx950).
+ *
+ * The reference (ethz-asl/autolabel) has NO native code of its own: on this path it
+ * calls two CUDA-only Python extensions, tinycudann and the torch-ngp fork.  Each entry
+ * point below names the reference call site whose work it replaces (file:line relative
+ * to the reference root) -- that is the interface a maintainer would bind (ctypes stub in
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain pointers and sizes; every pointer is a DEVICE pointer unless marked host.
+ *  - the caller owns all memory (PyTorch allocates it); kernels never allocate/sync.
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*), asynchronous.
+ *  - return 0 on success, negative on error; aln_last_error() gives the message
+ *    (thread-local).
+ *  - "rows" are samples in pass-major order: coarse rows ray*S1+i, then fine rows
+ *    N*S1 + ray*S2 + j.  fp16 activations are row-major [rows, width].
+ */
+#ifndef AUTOLABEL_HIP_H
+#define AUTOLABEL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALN_MAX_LEVELS 16
+#define ALN_ABI_VERSION 1
+
+/* tcnn GridEncoding config, autolabel/models.py:38-48 */
+typedef struct {
+  int32_t n_levels, n_features, log2_hashmap_size, base_resolution;
+  float per_level_scale;
+  /* derived by aln_grid_desc_init */
+  float scale[ALN_MAX_LEVELS];
+  uint32_t res[ALN_MAX_LEVELS], size[ALN_MAX_LEVELS], offset[ALN_MAX_LEVELS], dense[ALN_MAX_LEVELS];
+  uint32_t n_entries;
+} AlnGridDesc;
+
+/* input encoding: models.py:25-27 (freq), :51-59 (hg+freq), :142-143 (hg) */
+typedef struct {
+  int32_t n_freq;          /* 2 (hg+freq), 10 (freq), 0 (hg) */
+  int32_t freq_normalized; /* 1: frequency encoding sees (x+b)/2b (FreqEncoder) */
+  int32_t use_grid;
+  int32_t enc_dim, enc_pad; /* 44 -> 48 */
+  float bound;
+  AlnGridDesc grid;
+} AlnEncDesc;
+
+/* One bias-free ReLU MLP (tcnn FullyFusedMLP / CutlassMLP; models.py:84-136).
+ * Weights are fp16 in MFMA fragment order, produced by aln_mlp_repack from the fp32
+ * row-major master copy  W_l[out_l][in_l]  (y = W x). */
+typedef struct {
+  int32_t in_pad, hidden, out_pad, n_hidden; /* n_hidden in {1,2}; hidden in {64,128} */
+  const void* wf;   /* forward fragments  */
+  const void* wb;   /* backward (transposed) fragments */
+} AlnMlpDesc;
+
+const char* aln_last_error(void);
+int aln_abi_version(void);
+int aln_grid_desc_init(AlnGridDesc* g); /* host */
+
+/* ---- ray generation: autolabel/dataset.py:17-37 (_compute_direction), :182-242
+ * (_next_train), :244-266 (_get_test), on device-resident frames. */
+typedef struct {
+  const float* images;      /* [F, H*W, 3] f32 */
+  const uint16_t* depths;   /* [F, H*W] u16 millimetres */
+  const uint8_t* semantics; /* [F, H*W] u8, 0 = unlabeled */
+  const void* features;     /* [F, Hf*Wf, Cf] f16 or NULL */
+  const float* rotations;   /* [F,3,3] f32 (R_WC, ngp axes) */
+  const float* origins;     /* [F,3] */
+  const int32_t* pixel_indices; /* [n_pix] valid pixels (dataset.py:295-311) */
+  int32_t n_frames, w, h, n_pix, feat_w, feat_h, feat_c;
+  double fx, fy, cx, cy;
+} AlnFrames;
+
+typedef struct {
+  float* rays_o;  /* [B,3] */
+  float* rays_d;  /* [B,3] */
+  float* norms;   /* [B]   */
+  float* pixels;  /* [B,3] */
+  float* depth;   /* [B] metres */
+  int32_t* semantic; /* [B], -1 = unlabeled */
+  float* features;   /* [B,Cf] or NULL */
+} AlnBatch;
+
+/* chunk_frames[B/chunk] (device) picks the frame per 512-ray chunk; if NULL frames are
+ * drawn with the counter RNG.  pixel ids / jitter: counter RNG(seed, step), or explicit
+ * arrays for parity tests (ray_idx [B] i32, jitter [B,2] f32). */
+int aln_raygen_train(const AlnFrames* fr, const AlnBatch* out, int32_t B, int32_t chunk,
+                     int32_t frame_lo, int32_t frame_hi, uint32_t seed, uint32_t step,
+                     const int32_t* chunk_frames, const int32_t* ray_idx, const float* jitter,
+                     void* stream);
+int aln_raygen_frame(const AlnFrames* fr, const AlnBatch* out, int32_t frame, void* stream);
+/* bare _compute_direction on an index list (fixture F1) */
+int aln_compute_direction(const float* R_WC, const int64_t* idx, int32_t n, int32_t w, double fx, double fy,
+                          double cx, double cy, const float* jitter, float* dirs, float* norms, void* stream);
+
+/* ---- sampling: torch-ngp NeRFRenderer.run reached from autolabel/trainer.py:64-70 */
+int aln_sample_coarse(const float* rays_o, const float* rays_d, int32_t N, int32_t S1, float bound, float min_near,
+                      int32_t perturb, uint32_t seed, uint32_t step, const float* noise /*[N,S1] or NULL*/,
+                      float* nears, float* fars, float* z /*[N,S1]*/, void* stream);
+int aln_sample_fine(const float* z_coarse, const float* sigma_coarse, const float* nears, const float* fars, int32_t N,
+                    int32_t S1, int32_t S2, float density_scale, int32_t perturb, uint32_t seed, uint32_t step,
+                    const float* u /*[N,S2] or NULL*/, float* z_fine /*[N,S2] sorted*/, void* stream);
+
+/* ---- encoding: tcnn Frequency + GridEncoding, autolabel/models.py:51-59 */
+int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
+                   const float* z /*[rows]*/, const float* xyz /*[rows,3] or NULL*/, int32_t rows,
+                   int32_t rays_stride /*samples per ray for this pass*/, void* enc_out /*[rows,enc_pad] f16*/,
+                   void* stream);
+int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
+                   int32_t rows, int32_t rays_stride, const void* d_enc /*[rows,enc_pad] f16*/,
+                   float* grad_table /*[n_entries*F] f32*/, void* stream);
+
+/* ---- MLPs */
+int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
+                   void* wf, void* wb, void* stream);
+int64_t aln_mlp_frag_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden, int32_t backward);
+/* hs[l]: [rows,hidden] f16 saved post-ReLU activations (NULL at inference). */
+int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t* rows_dev, void* h1, void* h2,
+                void* out, void* stream);
+int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
+                const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW /*fp32 master layout*/,
+                int32_t* found_inf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

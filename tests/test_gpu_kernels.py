@@ -1,0 +1,335 @@
+"""Per-kernel parity: HIP (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Integer / index work is held bit-exact; floating point to the tolerance written at each check.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as O
+from oracle import raygen_oracle as R
+
+
+@pytest.fixture(scope='module')
+def H():
+    from autolabel_amd import hip
+    hip.require_gpu()
+    hip.lib()
+    return hip
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+# ------------------------------------------------------------------ ray generation (pinned to the reference)
+def test_compute_direction_vs_reference_fixture(H, golden_dir):
+    f = np.load(os.path.join(golden_dir, 'raygen_f1.npz'))
+    for name in ['toy', 'r32', 'replica', 'halfres']:
+        w, h, fx, fy, cx, cy = f[f'{name}_intr']
+        idx = f[f'{name}_idx'].astype(np.int64)
+        n = len(idx)
+        dirs, norms = torch.empty(n, 3, device='cuda'), torch.empty(n, device='cuda')
+        H.call('aln_compute_direction', H.ptr(dev(f[f'{name}_R'], torch.float32)), H.ptr(dev(idx)), n, int(w), fx, fy, cx, cy,
+               None, H.ptr(dirs), H.ptr(norms), H.stream())
+        od, on = R.compute_direction(f[f'{name}_R'], idx, int(w), fx, fy, cx, cy, False)
+        assert np.array_equal(norms.cpu().numpy(), on[:, 0]), name            # bit-exact vs oracle
+        assert np.array_equal(dirs.cpu().numpy(), od), name
+        assert np.array_equal(norms.cpu().numpy(), f[f'{name}_norm'][:, 0]), name   # bit-exact vs reference
+        assert np.max(np.abs(dirs.cpu().numpy() - f[f'{name}_dirs'])) <= 1.2e-7, name  # reference rotates via BLAS: 1 ulp
+
+
+def _frames(H, f, feats=True):
+    fr = H.AlnFrames()
+    keep = {}
+    keep['images'] = dev(f['images'], torch.float32)
+    keep['depths'] = dev(f['depths'].astype(np.int16), torch.int16)
+    keep['sem'] = dev(f['semantics'], torch.uint8)
+    keep['rot'] = dev(np.ascontiguousarray(f['poses'][:, :3, :3]), torch.float32)
+    keep['org'] = dev(np.ascontiguousarray(f['poses'][:, :3, 3]), torch.float32)
+    keep['pix'] = dev(f['pixel_indices'].astype(np.int32), torch.int32)
+    w, h, fx, fy, cx, cy = f['intr']
+    fr.images, fr.depths, fr.semantics = keep['images'].data_ptr(), keep['depths'].data_ptr(), keep['sem'].data_ptr()
+    fr.rotations, fr.origins, fr.pixel_indices = keep['rot'].data_ptr(), keep['org'].data_ptr(), keep['pix'].data_ptr()
+    fr.n_frames, fr.w, fr.h, fr.n_pix = f['images'].shape[0], int(w), int(h), len(f['pixel_indices'])
+    fr.fx, fr.fy, fr.cx, fr.cy = fx, fy, cx, cy
+    if feats and 'features' in f.files:
+        keep['feat'] = dev(f['features'], torch.float16)
+        fr.features = keep['feat'].data_ptr()
+        fr.feat_h, fr.feat_w, fr.feat_c = [int(v) for v in f['feat_shape']]
+    return fr, keep
+
+
+def _batch(H, B, Cf=0):
+    t = dict(rays_o=torch.empty(B, 3), rays_d=torch.empty(B, 3), norms=torch.empty(B), pixels=torch.empty(B, 3),
+             depth=torch.empty(B), semantic=torch.empty(B, dtype=torch.int32))
+    if Cf:
+        t['features'] = torch.empty(B, Cf)
+    t = {k: v.cuda() for k, v in t.items()}
+    b = H.AlnBatch()
+    for k, v in t.items():
+        setattr(b, k, v.data_ptr())
+    return b, t
+
+
+def test_raygen_train_replays_reference_batch(H, golden_dir):
+    """Feed the reference's own frame / pixel picks; jitter is recovered from its rays (not needed: we
+    compare the non-random outputs exactly and rays against the oracle with explicit jitter)."""
+    f = np.load(os.path.join(golden_dir, 'raygen_f2_labelled.npz'))
+    fr, keep = _frames(H, f)
+    B = 8192
+    # recover frame per chunk and pixel per ray from the reference batch (origins identify the frame)
+    org = f['poses'][:, :3, 3]
+    chunk_frames = np.array([int(np.argmin(np.abs(org - f['batch_rays_o'][c * 512]).sum(1))) for c in range(B // 512)], np.int32)
+    rng = np.random.default_rng(0)
+    ray_idx = np.concatenate([rng.choice(f['pixel_indices'], 512) for _ in range(B // 512)]).astype(np.int32)
+    jitter = rng.random((B, 2)).astype(np.float32)
+    b, t = _batch(H, B, Cf=int(f['feat_shape'][2]))
+    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, 0, 0, H.ptr(dev(chunk_frames)),
+           H.ptr(dev(ray_idx)), H.ptr(dev(jitter)), H.stream())
+    w, h, fx, fy, cx, cy = f['intr']
+    Hf, Wf, Cf = [int(v) for v in f['feat_shape']]
+    for c in range(B // 512):
+        s = slice(c * 512, (c + 1) * 512)
+        fi, idx = chunk_frames[c], ray_idx[s].astype(np.int64)
+        d, n = R.compute_direction(f['poses'][fi, :3, :3], idx, int(w), fx, fy, cx, cy, True, (jitter[s, 0], jitter[s, 1]))
+        assert np.array_equal(t['rays_d'][s].cpu().numpy(), d)
+        assert np.array_equal(t['norms'][s].cpu().numpy(), n[:, 0])
+        assert np.array_equal(t['pixels'][s].cpu().numpy(), f['images'][fi][idx])
+        assert np.array_equal(t['depth'][s].cpu().numpy(), (f['depths'][fi][idx] / 1000.0).astype(np.float32))
+        assert np.array_equal(t['semantic'][s].cpu().numpy(), f['semantics'][fi][idx].astype(int) - 1)
+        x = idx % int(w); y = (idx - x) / int(w)
+        xy = (np.stack([x, y], -1) * np.array([Wf / w, Hf / h])).astype(int)
+        assert np.array_equal(t['features'][s].cpu().numpy(), f['features'][fi][xy[:, 1] * Wf + xy[:, 0]].astype(np.float32))
+        assert np.array_equal(t['rays_o'][s].cpu().numpy(), np.broadcast_to(org[fi], (512, 3)))
+
+
+def test_raygen_train_counter_rng_matches_oracle_rng(H, golden_dir):
+    f = np.load(os.path.join(golden_dir, 'raygen_f2_plain.npz'))
+    fr, keep = _frames(H, f)
+    B, seed, step = 2048, 77, 5
+    b, t = _batch(H, B)
+    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, seed, step, None, None, None, H.stream())
+    frames = O.rand_u32(seed, O.STREAM_FRAME, step, np.arange(B // 512)) % np.uint32(fr.n_frames)
+    pix = f['pixel_indices'][O.rand_u32(seed, O.STREAM_PIXEL, step, np.arange(B)) % np.uint32(fr.n_pix)]
+    jx, jy = O.rand_uniform(seed, O.STREAM_JX, step, np.arange(B)), O.rand_uniform(seed, O.STREAM_JY, step, np.arange(B))
+    w, h, fx, fy, cx, cy = f['intr']
+    for c in range(B // 512):
+        s = slice(c * 512, (c + 1) * 512)
+        d, n = R.compute_direction(f['poses'][frames[c], :3, :3], pix[s], int(w), fx, fy, cx, cy, True, (jx[s], jy[s]))
+        assert np.array_equal(t['rays_d'][s].cpu().numpy(), d)
+        assert np.array_equal(t['pixels'][s].cpu().numpy(), f['images'][frames[c]][pix[s]])
+
+
+def test_raygen_frame_matches_reference_get_test(H, golden_dir):
+    f2 = np.load(os.path.join(golden_dir, 'raygen_f2_plain.npz'))
+    f3 = np.load(os.path.join(golden_dir, 'raygen_f3.npz'))
+    fr, keep = _frames(H, f2)
+    b, t = _batch(H, fr.w * fr.h)
+    H.call('aln_raygen_frame', C.byref(fr), C.byref(b), 0, H.stream())
+    assert np.array_equal(t['norms'].cpu().numpy(), f3['direction_norms'][:, 0])
+    assert np.max(np.abs(t['rays_d'].cpu().numpy() - f3['rays_d'].reshape(-1, 3))) <= 1.2e-7
+    assert np.array_equal(t['rays_o'].cpu().numpy(), f3['rays_o'].reshape(-1, 3))
+    assert np.array_equal(t['pixels'].cpu().numpy(), f3['pixels'].reshape(-1, 3))
+    assert np.array_equal(t['depth'].cpu().numpy(), f3['depth'].reshape(-1).astype(np.float32))
+    assert np.array_equal(t['semantic'].cpu().numpy(), f3['semantic'].reshape(-1))
+
+
+# ------------------------------------------------------------------ encoding
+def _enc_points(n, bound, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1) * bound
+    x[0] = torch.tensor([-bound, -bound, -bound]); x[1] = torch.tensor([bound, bound, bound]); x[2] = 0.0
+    x[3] = torch.tensor([bound * 1.2, 0.1, -bound * 1.5])  # leaks outside: clipped (models.py:54-57)
+    return x
+
+
+@pytest.mark.parametrize('encoding,L', [('hg+freq', 16), ('hg+freq', 4), ('freq', 0), ('hg', 16)])
+def test_encode_fwd_bit_exact_grid(H, encoding, L):
+    bound = 1.7
+    grid = H.make_grid_desc(n_levels=L) if L else None
+    e = H.make_enc_desc(encoding, bound, grid)
+    cfg = O.ModelConfig(encoding=encoding, bound=bound, grid=O.GridSpec(n_levels=L or 16))
+    n = 1000  # not a multiple of the 64-row tile (ragged tail)
+    x = _enc_points(n, bound)
+    table = (torch.rand(cfg.grid.n_entries, 2, generator=torch.Generator().manual_seed(1)) - 0.5).half()
+    model = O.OracleModel(cfg, params={'grid': table.float()}, half_sim=True)
+    want = model.encode(x).half()
+    out = torch.zeros(n, e.enc_pad, dtype=torch.float16, device='cuda')
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(table.cuda()), None, None, None, H.ptr(x.cuda()), n, 1, H.ptr(out), H.stream())
+    got = out.cpu()
+    fd = 6 * e.n_freq
+    assert torch.equal(got[:, e.enc_dim:], torch.ones(n, e.enc_pad - e.enc_dim, dtype=torch.float16))  # ones padding
+    if e.use_grid:
+        assert torch.equal(got[:, fd:e.enc_dim], want[:, fd:]), 'hash-grid features must be bit-exact'
+    # sin(): device sinf vs torch.sin differ by <= 1 fp16 ulp after rounding
+    assert (got[:, :fd].float() - want[:, :fd].float()).abs().max() <= 1e-3
+
+
+def test_encode_from_rays_and_backward(H):
+    bound, L = 1.0, 16
+    e = H.make_enc_desc('hg+freq', bound)
+    cfg = O.ModelConfig(bound=bound)
+    N, S = 37, 24
+    g = torch.Generator().manual_seed(3)
+    ro = (torch.rand(N, 3, generator=g) - 0.5)
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1)
+    z = torch.rand(N, S, generator=g) * 2
+    x = torch.clamp(ro[:, None] + rd[:, None] * z[..., None], -bound, bound).reshape(-1, 3)
+    table = ((torch.rand(cfg.grid.n_entries, 2, generator=g) - 0.5)).half()
+    model = O.OracleModel(cfg, params={'grid': table.float()}, half_sim=True)
+    enc_o = model.encode(x)
+    rows = N * S
+    out = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(table.cuda()), H.ptr(ro.cuda()), H.ptr(rd.cuda()), H.ptr(z.cuda().reshape(-1)), None,
+           rows, S, H.ptr(out), H.stream())
+    assert torch.equal(out.cpu()[:, 12:44], enc_o[:, 12:].half())
+    # backward: dL/dtable for a random upstream gradient
+    d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16)
+    d_enc[:, :44] = (torch.randn(rows, 44, generator=g) * 0.1).half()
+    (enc_o * d_enc[:, :44].float()).sum().backward()
+    want = model.params['grid'].grad
+    grad = torch.zeros(cfg.grid.n_entries * 2, device='cuda')
+    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro.cuda()), H.ptr(rd.cuda()), H.ptr(z.cuda().reshape(-1)), None, rows, S,
+           H.ptr(d_enc.cuda()), H.ptr(grad), H.stream())
+    got = grad.cpu().view(-1, 2)
+    assert torch.equal(got != 0, want != 0), 'touched-entry sets must be identical (indexing bit-exact)'
+    # fp32 atomics: order-dependent rounding only
+    assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+# ------------------------------------------------------------------ MLPs
+MLP_SHAPES = [('sigma', 48, 128, 16, 2), ('color', 32, 128, 16, 2), ('semf', 16, 64, 64, 2), ('semo', 80, 64, 16, 1),
+              ('semo_c32', 80, 64, 32, 1)]
+
+
+def _mlp_setup(H, n_in, hid, n_out, nh, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(hid, n_in)] + [(hid, hid)] * (nh - 1) + [(n_out, hid)]
+    Ws = [((torch.rand(o, i, generator=g) * 2 - 1) * (6.0 / (o + i)) ** 0.5) for o, i in shapes]
+    flat = torch.cat([w.reshape(-1) for w in Ws]).cuda()
+    nf = H.lib().aln_mlp_frag_halves(n_in, hid, n_out, nh, 0)
+    nb = H.lib().aln_mlp_frag_halves(n_in, hid, n_out, nh, 1)
+    wf = torch.zeros(nf, dtype=torch.float16, device='cuda')
+    wb = torch.zeros(nb, dtype=torch.float16, device='cuda')
+    H.call('aln_mlp_repack', H.ptr(flat), n_in, hid, n_out, nh, H.ptr(wf), H.ptr(wb), H.stream())
+    desc = H.AlnMlpDesc(n_in, hid, n_out, nh, wf.data_ptr(), wb.data_ptr())
+    return Ws, desc, (flat, wf, wb)
+
+
+@pytest.mark.parametrize('name,n_in,hid,n_out,nh', MLP_SHAPES)
+def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh):
+    rows = 1000  # ragged: not a multiple of 32
+    Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, n_in, generator=g).half()
+    xo = x.float().requires_grad_(True)
+    Wo = [w.clone().requires_grad_(True) for w in Ws]
+    want = O.mlp_forward(xo, Wo, half_sim=True)
+    h1 = torch.zeros(rows, hid, dtype=torch.float16, device='cuda')
+    h2 = torch.zeros(rows, hid, dtype=torch.float16, device='cuda') if nh == 2 else None
+    out = torch.zeros(rows, n_out, dtype=torch.float16, device='cuda')
+    xd = x.cuda()
+    H.call('aln_mlp_fwd', C.byref(desc), H.ptr(xd), rows, None, H.ptr(h1), H.ptr(h2), H.ptr(out), H.stream())
+    # fp16 outputs, fp32 accumulate in a different order than torch: 1-2 fp16 ulp
+    assert (out.cpu().float() - want).abs().max() <= 4e-3 * max(1.0, want.abs().max().item())
+    # backward
+    d_out = (torch.randn(rows, n_out, generator=g) * 0.05).half()
+    (want * d_out.float()).sum().backward()
+    dA1 = torch.zeros(rows, hid, dtype=torch.float16, device='cuda')
+    dA2 = torch.zeros(rows, hid, dtype=torch.float16, device='cuda') if nh == 2 else None
+    d_in = torch.zeros(rows, n_in, dtype=torch.float16, device='cuda')
+    dW = torch.zeros(sum(w.numel() for w in Ws), device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    H.call('aln_mlp_bwd', C.byref(desc), H.ptr(xd), H.ptr(h1), H.ptr(h2), H.ptr(d_out.cuda()), rows, None, H.ptr(dA1), H.ptr(dA2),
+           H.ptr(d_in), H.ptr(dW), H.ptr(flag), H.stream())
+    assert flag.item() == 0
+    gi = xo.grad
+    # fp16 gradient activations (reference: tcnn fp16 backward): 1e-2 relative to the tensor scale
+    assert (d_in.cpu().float() - gi).abs().max() <= 1e-2 * gi.abs().max().item() + 1e-4
+    o = 0
+    for w in Wo:
+        got = dW[o:o + w.numel()].cpu().view_as(w)
+        assert (got - w.grad).abs().max() <= 1e-2 * w.grad.abs().max().item() + 1e-4, name
+        o += w.numel()
+
+
+def test_mlp_device_row_count_and_inf_flag(H):
+    Ws, desc, keep = _mlp_setup(H, 32, 128, 16, 2)
+    rows = 512
+    x = torch.randn(rows, 32).half().cuda()
+    n_dev = torch.tensor([100], dtype=torch.int32, device='cuda')
+    out = torch.full((rows, 16), 7.0, dtype=torch.float16, device='cuda')
+    H.call('aln_mlp_fwd', C.byref(desc), H.ptr(x), rows, H.ptr(n_dev), None, None, H.ptr(out), H.stream())
+    assert (out[100:] == 7.0).all() and not (out[:100] == 7.0).all()
+    # overflow in the fp16 gradient path must raise the flag (GradScaler semantics)
+    h1 = torch.ones(rows, 128, dtype=torch.float16, device='cuda')
+    d_out = torch.full((rows, 16), 60000.0, dtype=torch.float16, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    d_in = torch.zeros(rows, 32, dtype=torch.float16, device='cuda')
+    H.call('aln_mlp_bwd', C.byref(desc), None, H.ptr(h1), H.ptr(h1), H.ptr(d_out), rows, None, None, None, H.ptr(d_in), None,
+           H.ptr(flag), H.stream())
+    assert flag.item() == 1
+
+
+# ------------------------------------------------------------------ sampling
+def _rays(n, seed=0, bound=1.0):
+    g = torch.Generator().manual_seed(seed)
+    o = (torch.rand(n, 3, generator=g) - 0.5) * bound
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    o[0] = torch.tensor([5.0, 5.0, 5.0]); d[0] = torch.tensor([1.0, 0.0, 0.0])   # miss
+    d[1] = torch.tensor([0.0, 0.0, 1.0])                                          # axis-aligned (1/0)
+    return o, d
+
+
+def test_sample_coarse_bit_exact(H):
+    N, S1, bound = 50, 128, 1.3
+    o, d = _rays(N, bound=bound)
+    noise = torch.rand(N, S1, generator=torch.Generator().manual_seed(1))
+    m = O.OracleModel(O.ModelConfig(bound=bound, grid=O.GridSpec(n_levels=2)))
+    near, far = m.near_far(o, d)
+    lin = torch.arange(S1, dtype=torch.float32) / np.float32(S1 - 1)
+    z = near[:, None] + (far - near)[:, None] * lin[None]
+    zp = z + (noise - 0.5) * ((far - near)[:, None] / np.float32(S1))
+    for perturb, want in [(0, z), (1, zp)]:
+        nears, fars, zz = torch.empty(N, device='cuda'), torch.empty(N, device='cuda'), torch.empty(N, S1, device='cuda')
+        H.call('aln_sample_coarse', H.ptr(o.cuda()), H.ptr(d.cuda()), N, S1, bound, 0.2, perturb, 0, 0, H.ptr(noise.cuda()),
+               H.ptr(nears), H.ptr(fars), H.ptr(zz), H.stream())
+        assert torch.equal(nears.cpu(), near) and torch.equal(fars.cpu(), far)
+        assert torch.equal(zz.cpu(), want)
+    # internal counter RNG == oracle RNG
+    H.call('aln_sample_coarse', H.ptr(o.cuda()), H.ptr(d.cuda()), N, S1, bound, 0.2, 1, 9, 4, None, H.ptr(nears), H.ptr(fars),
+           H.ptr(zz), H.stream())
+    u = torch.from_numpy(O.rand_uniform(9, O.STREAM_PERTURB, 4, np.arange(N * S1))).view(N, S1)
+    assert torch.equal(zz.cpu(), z + (u - 0.5) * ((far - near)[:, None] / np.float32(S1)))
+
+
+@pytest.mark.parametrize('perturb', [0, 1])
+def test_sample_fine_matches_sample_pdf(H, perturb):
+    N, S1, S2 = 40, 128, 128
+    g = torch.Generator().manual_seed(2)
+    near, far = torch.full((N,), 0.2), torch.rand(N, generator=g) * 3 + 1
+    z = near[:, None] + (far - near)[:, None] * (torch.arange(S1) / (S1 - 1))[None]
+    sigma = torch.exp(torch.randn(N, S1, generator=g) * 2)
+    sigma[0] = 0.0  # empty ray: uniform pdf from the +1e-5 floor
+    m = O.OracleModel(O.ModelConfig(grid=O.GridSpec(n_levels=2)))
+    sd = ((far - near) / np.float32(S1))[:, None]
+    w, _, _, deltas = m._weights(z, sigma, sd)
+    zmid = z[:, :-1] + 0.5 * deltas[:, :-1]
+    u = torch.rand(N, S2, generator=g) if perturb else ((torch.arange(S2, dtype=torch.float32) + 0.5) / S2)[None].expand(N, S2)
+    want = torch.sort(O.sample_pdf(zmid, w[:, 1:-1], u.contiguous()), dim=1)[0]
+    zf = torch.empty(N, S2, device='cuda')
+    H.call('aln_sample_fine', H.ptr(z.cuda()), H.ptr(sigma.cuda()), H.ptr(near.cuda()), H.ptr(far.cuda()), N, S1, S2, 1.0, perturb,
+           0, 0, H.ptr(u.contiguous().cuda()) if perturb else None, H.ptr(zf), H.stream())
+    got = zf.cpu()
+    assert (got[:, 1:] >= got[:, :-1]).all()
+    # parallel scans re-associate the cumprod / cumsum: 1e-4 of the ray span (cdf steps can be steep)
+    assert (got - want).abs().max() <= 2e-4 * far.max().item()

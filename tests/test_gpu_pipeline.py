@@ -1,0 +1,192 @@
+"""End-to-end parity of the HIP render / loss / backward / Adam path against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as O
+
+
+def build_pair(encoding='hg+freq', L=16, D=64, C_=3, bound=1.0, seed=0, grid_scale=1e4):
+    """Same parameters in the oracle (named tensors) and in the HIP flat buffer."""
+    from autolabel_amd import hip as H
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    cfg = O.ModelConfig(encoding=encoding, feature_dim=D, n_classes=C_, bound=bound, grid=O.GridSpec(n_levels=L))
+    p = O.init_params(cfg, seed)
+    if 'grid' in p:
+        p['grid'] = (p['grid'] * grid_scale).half().float()  # non-trivial density; exactly representable in the fp16 table
+    oracle = O.OracleModel(cfg, params=p, half_sim=True)
+    layout = ModelLayout(encoding, 15, 128, 128, D, C_, bound=bound, grid=H.make_grid_desc(n_levels=L))
+    P = Params(layout, 'cuda')
+    parts = [p['grid'].reshape(-1)] if 'grid' in p else []
+    for name in ['sigma', 'color', 'semf', 'semo']:
+        parts += [p[f'{name}.{i}'].reshape(-1) for i in range(len(O.mlp_shapes(cfg)[name]))]
+    flat = torch.cat([t.detach() for t in parts])
+    assert flat.numel() == layout.n_total
+    P.flat.copy_(flat.cuda())
+    P.refresh_shadows()
+    return oracle, HipPipeline(layout, P), cfg
+
+
+def make_rays(n, seed=0, bound=1.0):
+    g = torch.Generator().manual_seed(seed)
+    o = (torch.rand(n, 3, generator=g) - 0.5) * bound
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    norms = 1.0 + torch.rand(n, 1, generator=g) * 0.3
+    return o, d, norms
+
+
+def flat_grads(oracle, cfg):
+    parts = [oracle.params['grid'].grad.reshape(-1)] if 'grid' in oracle.params else []
+    for name in ['sigma', 'color', 'semf', 'semo']:
+        parts += [oracle.params[f'{name}.{i}'].grad.reshape(-1) for i in range(len(O.mlp_shapes(cfg)[name]))]
+    return torch.cat(parts)
+
+
+def rel(a, b):
+    return (a - b).norm().item() / max(b.norm().item(), 1e-20)
+
+
+@pytest.mark.parametrize('S1,S2,perturb', [(128, 128, True), (64, 0, False), (96, 32, False)])
+def test_render_forward_matches_oracle(S1, S2, perturb):
+    oracle, pipe, cfg = build_pair()
+    N = 96
+    o, d, norms = make_rays(N, seed=1)
+    g = torch.Generator().manual_seed(7)
+    noise, u = torch.rand(N, S1, generator=g), torch.rand(N, max(S2, 1), generator=g)
+    with torch.no_grad():
+        want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=perturb, noise_coarse=noise, u_fine=u)
+    out, ctx = pipe.forward(o.cuda(), d.cuda(), norms.cuda().reshape(-1), S1, S2, perturb, train=False,
+                            noise=noise.cuda(), u=u.cuda() if S2 else None)
+    torch.cuda.synchronize()
+    # fp16 MLP chain with re-associated fp32 sums + w>1e-4 mask flips: 5e-3 absolute on O(1) outputs
+    assert (out['weights_sum'].cpu() - want['weights_sum']).abs().max() < 5e-3
+    assert (out['image'].cpu() - want['image']).abs().max() < 5e-3
+    assert (out['depth'].cpu() - want['depth']).abs().max() < 5e-3 * max(1.0, want['depth'].max().item())
+    assert (out['depth_variance'].cpu() - want['depth_variance']).abs().max() < 1e-2
+    assert (out['coordinates_map'].cpu() - want['coordinates_map']).abs().max() < 5e-3
+    assert (out['semantic'].cpu() - want['semantic']).abs().max() < 1e-2 * max(1.0, want['semantic'].abs().max().item())
+    assert (out['semantic_features'].cpu() - want['semantic_features']).abs().max() < 1e-2 * max(
+        1.0, want['semantic_features'].abs().max().item())
+    # merged sample order identical to the stable sort of the oracle (index work: exact up to z ties)
+    S = S1 + S2
+    z_sorted = torch.gather(ctx['z'].cpu().view(-1)[None].expand(N, -1), 1, torch.stack(
+        [torch.tensor([r * S1 + i if i < S1 else N * S1 + r * S2 + i - S1 for i in ctx['perm'].cpu()[r].long().tolist()])
+         for r in range(N)]))
+    assert (z_sorted[:, 1:] >= z_sorted[:, :-1]).all()
+    assert (z_sorted - want['_z']).abs().max() < 2e-3
+
+
+def _batch(N, C_, Cf, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    b = {'pixels': torch.rand(N, 3, generator=g), 'depth': torch.rand(N, generator=g) * 1.5 + 0.2,
+         'semantic': torch.randint(-1, C_, (N,), generator=g), 'features': torch.randn(N, Cf, generator=g)}
+    b['depth'][::6] = 0.0
+    return b
+
+
+def hip_loss(pipe, out, batch, N, C_, D, Cf, scale=1.0, weights=(1.0, 0.1, 1.0, 0.5)):
+    from autolabel_amd import hip as H
+    dv = 'cuda'
+    g_image, g_depth = torch.empty(N, 3, device=dv), torch.empty(N, device=dv)
+    g_sem, g_feat = torch.empty(N, C_, device=dv), torch.empty(N, D, device=dv)
+    counts, terms = torch.zeros(2, dtype=torch.int32, device=dv), torch.zeros(5, device=dv)
+    ls = torch.tensor([scale], device=dv)
+    gt = {k: v.cuda() for k, v in batch.items()}
+    gt['semantic'] = gt['semantic'].int()
+    H.call('aln_loss_fwd_bwd', H.ptr(out['image']), H.ptr(out['depth']), H.ptr(out['semantic']), H.ptr(out['semantic_features']),
+           H.ptr(gt['pixels']), H.ptr(gt['depth']), H.ptr(gt['semantic']), H.ptr(gt['features'].contiguous()) if Cf else None, N, C_, D, Cf,
+           weights[0], weights[1], weights[2], weights[3], H.ptr(ls), H.ptr(counts), H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem),
+           H.ptr(g_feat), H.ptr(terms), H.stream())
+    return g_image, g_depth, g_sem, g_feat, terms
+
+
+def test_loss_kernel_matches_trainer_formula():
+    oracle, pipe, cfg = build_pair(L=2)
+    N, C_, D, Cf = 200, 3, 64, 40
+    g = torch.Generator().manual_seed(3)
+    out = {'image': torch.rand(N, 3, generator=g), 'depth': torch.rand(N, generator=g) * 2,
+           'semantic': torch.randn(N, C_, generator=g) * 2, 'semantic_features': torch.randn(N, D, generator=g)}
+    batch = _batch(N, C_, Cf)
+    o_req = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+    loss, terms = O.loss_fn(o_req, batch, feature_loss=True)
+    loss.backward()
+    gi, gd, gs, gf, t = hip_loss(pipe, {k: v.cuda() for k, v in out.items()}, batch, N, C_, D, Cf, scale=128.0)
+    assert abs(t[4].item() - loss.item()) < 1e-5 * max(1, abs(loss.item()))
+    assert torch.allclose(gi.cpu() / 128, o_req['image'].grad, atol=1e-7)
+    assert torch.allclose(gd.cpu() / 128, o_req['depth'].grad, atol=1e-7)
+    assert torch.allclose(gs.cpu() / 128, o_req['semantic'].grad, atol=1e-6)
+    assert torch.allclose(gf.cpu() / 128, o_req['semantic_features'].grad, atol=1e-7)
+    # no labels / no valid depth: terms vanish instead of NaN (SPEC)
+    batch2 = dict(batch, semantic=torch.full((N,), -1), depth=torch.zeros(N))
+    gi, gd, gs, gf, t = hip_loss(pipe, {k: v.cuda() for k, v in out.items()}, batch2, N, C_, D, Cf)
+    assert gs.abs().max().item() == 0 and gd.abs().max().item() == 0 and torch.isfinite(t).all()
+
+
+def test_train_step_gradients_match_oracle_autograd():
+    oracle, pipe, cfg = build_pair(L=16, D=64, C_=3)
+    N, S1, S2, C_, D, Cf = 64, 64, 64, 3, 64, 48
+    o, d, norms = make_rays(N, seed=2)
+    g = torch.Generator().manual_seed(11)
+    noise, u = torch.rand(N, S1, generator=g), torch.rand(N, S2, generator=g)
+    batch = _batch(N, C_, Cf, seed=4)
+    want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=True, noise_coarse=noise, u_fine=u)
+    loss, _ = O.loss_fn(want, batch, feature_loss=True)
+    loss.backward()
+    gw = flat_grads(oracle, cfg)
+    out, ctx = pipe.forward(o.cuda(), d.cuda(), norms.cuda().reshape(-1), S1, S2, True, train=True, noise=noise.cuda(), u=u.cuda())
+    scale = 1024.0
+    gi, gd, gs, gf, t = hip_loss(pipe, out, batch, N, C_, D, Cf, scale=scale)
+    assert abs(t[4].item() - loss.item()) < 5e-3 * max(1.0, loss.item())
+    pipe.P.grad.zero_()
+    pipe.backward(ctx, gi, gd, gs, gf)
+    torch.cuda.synchronize()
+    assert pipe.found_inf.item() == 0
+    got = pipe.P.grad[:pipe.L.n_total].cpu() / scale
+    L = pipe.L
+    # fp16 gradient activations (loss-scaled) vs fp32 autograd: <= 3% of each tensor's norm
+    assert rel(got[:L.n_grid], gw[:L.n_grid]) < 3e-2, 'hash-grid gradient'
+    for k in ['sigma', 'color', 'semf', 'semo']:
+        a = L.offsets[k]
+        b = a + L.nets[k].n_params
+        assert rel(got[a:b], gw[a:b]) < 3e-2, k
+    touched_h, touched_o = got[:L.n_grid] != 0, gw[:L.n_grid] != 0
+    # same table entries receive gradient (ties at the w>1e-4 / ReLU boundaries may drop a few)
+    assert (touched_h != touched_o).float().mean().item() < 1e-3
+
+
+def test_adam_step_matches_torch_adam_and_skips_on_inf():
+    from autolabel_amd import hip as H
+    n_grid, n = 1000, 1600
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{'params': [p_ref]}], lr=5e-3, betas=(0.9, 0.99), eps=1e-15)
+    p, gr, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    t16 = torch.zeros(n_grid, dtype=torch.float16, device='cuda')
+    si, sf, cst = torch.zeros(4, dtype=torch.int32, device='cuda'), torch.tensor([128.0, 0, 0, 0], device='cuda'), torch.zeros(4, device='cuda')
+
+    def step():
+        H.call('aln_adam_step', H.ptr(p), H.ptr(gr), H.ptr(m), H.ptr(v), H.ptr(t16), n_grid, n, H.ptr(si), H.ptr(sf), H.ptr(cst),
+               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, H.stream())
+    for it in range(4):
+        gt = torch.randn(n, generator=g)
+        pr = p_ref.detach().clone()
+        p_ref.grad = gt.clone()
+        p_ref.grad[n_grid:] += 1e-6 * pr[n_grid:]   # weight decay on the MLP group only (scripts/train.py:55-58)
+        opt.step()
+        scale = sf[0].item()
+        gr.copy_((gt * scale).cuda())
+        step()
+        assert gr.abs().max().item() == 0  # gradients are zeroed by the fused step
+    assert torch.allclose(p.cpu(), p_ref.detach(), atol=2e-6)
+    assert torch.equal(t16.cpu(), p[:n_grid].cpu().half())
+    assert si[0].item() == 4 and sf[0].item() == 256.0  # grew once after 3 clean steps
+    # an overflow step is skipped, scale backs off, step counter is unchanged
+    before = p.clone()
+    gr.fill_(1.0); si[2] = 1
+    step()
+    assert torch.equal(p, before) and sf[0].item() == 128.0 and si[0].item() == 4 and si[2].item() == 0
