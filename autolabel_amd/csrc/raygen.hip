@@ -14,7 +14,8 @@ __device__ inline void pixel_direction(const float* __restrict__ R, int64_t idx,
   if (randomize) { xs = __fadd_rn(xs, jx); ys = __fadd_rn(ys, jy); }
   else { xs = __fadd_rn(xs, 0.5f); ys = __fadd_rn(ys, 0.5f); }
   float d0 = (float)(((double)xs - cx) / fx), d1 = (float)(((double)ys - cy) / fy), d2 = 1.0f;
-  float n = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+  // v_sqrt_f32 is 1-ulp; the f64 root rounded once to f32 is the correctly rounded f32 root (numpy parity)
+  float n = (float)sqrt((double)__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
   d0 = __fdiv_rn(d0, n); d1 = __fdiv_rn(d1, n); d2 = __fdiv_rn(d2, n);
 #pragma unroll
   for (int r = 0; r < 3; ++r)

@@ -382,12 +382,14 @@ class OracleModel:
         return alphas * T, alphas, T, deltas
 
     def run(self, rays_o, rays_d, direction_norms, num_steps=128, upsample_steps=128, bg_color=None,
-            perturb=False, noise_coarse=None, u_fine=None, want_semantic=True):
+            perturb=False, noise_coarse=None, u_fine=None, want_semantic=True, z_fine_override=None):
         """torch-ngp NeRFRenderer.run (non-cuda-ray) + fork outputs.
 
         noise_coarse [N,num_steps] / u_fine [N,upsample_steps]: explicit uniform
         randoms (used when perturb=True); the HIP kernels consume the same
-        numbers so parity tests are deterministic.
+        numbers so parity tests are deterministic.  z_fine_override [N,upsample_steps]
+        replaces the importance samples (finest grid cells are ~4e-6 wide, so gradient parity per
+        table entry needs bit-identical sample positions; the sampler itself is tested separately).
         """
         cfg = self.cfg
         N = rays_o.shape[0]
@@ -418,6 +420,8 @@ class OracleModel:
                     u = (torch.arange(upsample_steps, dtype=torch.float32) + 0.5) / np.float32(upsample_steps)
                     u = u[None].expand(N, upsample_steps)
                 new_z = sample_pdf(z_mid, w[:, 1:-1], u.contiguous())
+                if z_fine_override is not None:
+                    new_z = z_fine_override
                 new_xyz = pts(new_z)
             nd = self.density(new_xyz.reshape(-1, 3))
             z = torch.cat([z, new_z], 1)

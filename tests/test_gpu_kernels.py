@@ -38,8 +38,9 @@ def test_compute_direction_vs_reference_fixture(H, golden_dir):
         idx = f[f'{name}_idx'].astype(np.int64)
         n = len(idx)
         dirs, norms = torch.empty(n, 3, device='cuda'), torch.empty(n, device='cuda')
-        H.call('aln_compute_direction', H.ptr(dev(f[f'{name}_R'], torch.float32)), H.ptr(dev(idx)), n, int(w), fx, fy, cx, cy,
-               None, H.ptr(dirs), H.ptr(norms), H.stream())
+        Rd, idxd = dev(f[f'{name}_R'], torch.float32), dev(idx)  # keep device inputs alive across the async launch
+        H.call('aln_compute_direction', H.ptr(Rd), H.ptr(idxd), n, int(w), fx, fy, cx, cy, None, H.ptr(dirs), H.ptr(norms),
+               H.stream())
         od, on = R.compute_direction(f[f'{name}_R'], idx, int(w), fx, fy, cx, cy, False)
         assert np.array_equal(norms.cpu().numpy(), on[:, 0]), name            # bit-exact vs oracle
         assert np.array_equal(dirs.cpu().numpy(), od), name
@@ -93,8 +94,8 @@ def test_raygen_train_replays_reference_batch(H, golden_dir):
     ray_idx = np.concatenate([rng.choice(f['pixel_indices'], 512) for _ in range(B // 512)]).astype(np.int32)
     jitter = rng.random((B, 2)).astype(np.float32)
     b, t = _batch(H, B, Cf=int(f['feat_shape'][2]))
-    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, 0, 0, H.ptr(dev(chunk_frames)),
-           H.ptr(dev(ray_idx)), H.ptr(dev(jitter)), H.stream())
+    cfd, rid, jd = dev(chunk_frames), dev(ray_idx), dev(jitter)
+    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, 0, 0, H.ptr(cfd), H.ptr(rid), H.ptr(jd), H.stream())
     w, h, fx, fy, cx, cy = f['intr']
     Hf, Wf, Cf = [int(v) for v in f['feat_shape']]
     for c in range(B // 512):
@@ -164,14 +165,16 @@ def test_encode_fwd_bit_exact_grid(H, encoding, L):
     model = O.OracleModel(cfg, params={'grid': table.float()}, half_sim=True)
     want = model.encode(x).half()
     out = torch.zeros(n, e.enc_pad, dtype=torch.float16, device='cuda')
-    H.call('aln_encode_fwd', C.byref(e), H.ptr(table.cuda()), None, None, None, H.ptr(x.cuda()), n, 1, H.ptr(out), H.stream())
+    td, xd = table.cuda(), x.cuda()
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(td), None, None, None, H.ptr(xd), n, 1, H.ptr(out), H.stream())
     got = out.cpu()
     fd = 6 * e.n_freq
     assert torch.equal(got[:, e.enc_dim:], torch.ones(n, e.enc_pad - e.enc_dim, dtype=torch.float16))  # ones padding
     if e.use_grid:
         assert torch.equal(got[:, fd:e.enc_dim], want[:, fd:]), 'hash-grid features must be bit-exact'
     # sin(): device sinf vs torch.sin differ by <= 1 fp16 ulp after rounding
-    assert (got[:, :fd].float() - want[:, :fd].float()).abs().max() <= 1e-3
+    if fd:
+        assert (got[:, :fd].float() - want[:, :fd].float()).abs().max() <= 1e-3
 
 
 def test_encode_from_rays_and_backward(H):
@@ -189,8 +192,8 @@ def test_encode_from_rays_and_backward(H):
     enc_o = model.encode(x)
     rows = N * S
     out = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
-    H.call('aln_encode_fwd', C.byref(e), H.ptr(table.cuda()), H.ptr(ro.cuda()), H.ptr(rd.cuda()), H.ptr(z.cuda().reshape(-1)), None,
-           rows, S, H.ptr(out), H.stream())
+    td, rod, rdd, zd = table.cuda(), ro.cuda(), rd.cuda(), z.cuda().reshape(-1)
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(td), H.ptr(rod), H.ptr(rdd), H.ptr(zd), None, rows, S, H.ptr(out), H.stream())
     assert torch.equal(out.cpu()[:, 12:44], enc_o[:, 12:].half())
     # backward: dL/dtable for a random upstream gradient
     d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16)
@@ -198,8 +201,8 @@ def test_encode_from_rays_and_backward(H):
     (enc_o * d_enc[:, :44].float()).sum().backward()
     want = model.params['grid'].grad
     grad = torch.zeros(cfg.grid.n_entries * 2, device='cuda')
-    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro.cuda()), H.ptr(rd.cuda()), H.ptr(z.cuda().reshape(-1)), None, rows, S,
-           H.ptr(d_enc.cuda()), H.ptr(grad), H.stream())
+    ded = d_enc.cuda()
+    H.call('aln_encode_bwd', C.byref(e), H.ptr(rod), H.ptr(rdd), H.ptr(zd), None, rows, S, H.ptr(ded), H.ptr(grad), H.stream())
     got = grad.cpu().view(-1, 2)
     assert torch.equal(got != 0, want != 0), 'touched-entry sets must be identical (indexing bit-exact)'
     # fp32 atomics: order-dependent rounding only
@@ -249,7 +252,8 @@ def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh):
     d_in = torch.zeros(rows, n_in, dtype=torch.float16, device='cuda')
     dW = torch.zeros(sum(w.numel() for w in Ws), device='cuda')
     flag = torch.zeros(1, dtype=torch.int32, device='cuda')
-    H.call('aln_mlp_bwd', C.byref(desc), H.ptr(xd), H.ptr(h1), H.ptr(h2), H.ptr(d_out.cuda()), rows, None, H.ptr(dA1), H.ptr(dA2),
+    dod = d_out.cuda()
+    H.call('aln_mlp_bwd', C.byref(desc), H.ptr(xd), H.ptr(h1), H.ptr(h2), H.ptr(dod), rows, None, H.ptr(dA1), H.ptr(dA2),
            H.ptr(d_in), H.ptr(dW), H.ptr(flag), H.stream())
     assert flag.item() == 0
     gi = xo.grad
@@ -299,14 +303,15 @@ def test_sample_coarse_bit_exact(H):
     lin = torch.arange(S1, dtype=torch.float32) / np.float32(S1 - 1)
     z = near[:, None] + (far - near)[:, None] * lin[None]
     zp = z + (noise - 0.5) * ((far - near)[:, None] / np.float32(S1))
+    od_, dd_, nd_ = o.cuda(), d.cuda(), noise.cuda()
     for perturb, want in [(0, z), (1, zp)]:
         nears, fars, zz = torch.empty(N, device='cuda'), torch.empty(N, device='cuda'), torch.empty(N, S1, device='cuda')
-        H.call('aln_sample_coarse', H.ptr(o.cuda()), H.ptr(d.cuda()), N, S1, bound, 0.2, perturb, 0, 0, H.ptr(noise.cuda()),
+        H.call('aln_sample_coarse', H.ptr(od_), H.ptr(dd_), N, S1, bound, 0.2, perturb, 0, 0, H.ptr(nd_),
                H.ptr(nears), H.ptr(fars), H.ptr(zz), H.stream())
         assert torch.equal(nears.cpu(), near) and torch.equal(fars.cpu(), far)
         assert torch.equal(zz.cpu(), want)
     # internal counter RNG == oracle RNG
-    H.call('aln_sample_coarse', H.ptr(o.cuda()), H.ptr(d.cuda()), N, S1, bound, 0.2, 1, 9, 4, None, H.ptr(nears), H.ptr(fars),
+    H.call('aln_sample_coarse', H.ptr(od_), H.ptr(dd_), N, S1, bound, 0.2, 1, 9, 4, None, H.ptr(nears), H.ptr(fars),
            H.ptr(zz), H.stream())
     u = torch.from_numpy(O.rand_uniform(9, O.STREAM_PERTURB, 4, np.arange(N * S1))).view(N, S1)
     assert torch.equal(zz.cpu(), z + (u - 0.5) * ((far - near)[:, None] / np.float32(S1)))
@@ -327,8 +332,9 @@ def test_sample_fine_matches_sample_pdf(H, perturb):
     u = torch.rand(N, S2, generator=g) if perturb else ((torch.arange(S2, dtype=torch.float32) + 0.5) / S2)[None].expand(N, S2)
     want = torch.sort(O.sample_pdf(zmid, w[:, 1:-1], u.contiguous()), dim=1)[0]
     zf = torch.empty(N, S2, device='cuda')
-    H.call('aln_sample_fine', H.ptr(z.cuda()), H.ptr(sigma.cuda()), H.ptr(near.cuda()), H.ptr(far.cuda()), N, S1, S2, 1.0, perturb,
-           0, 0, H.ptr(u.contiguous().cuda()) if perturb else None, H.ptr(zf), H.stream())
+    zd, sd_, nd_, fd_, ud = z.cuda(), sigma.cuda(), near.cuda(), far.cuda(), u.contiguous().cuda()
+    H.call('aln_sample_fine', H.ptr(zd), H.ptr(sd_), H.ptr(nd_), H.ptr(fd_), N, S1, S2, 1.0, perturb,
+           0, 0, H.ptr(ud) if perturb else None, H.ptr(zf), H.stream())
     got = zf.cpu()
     assert (got[:, 1:] >= got[:, :-1]).all()
     # parallel scans re-associate the cumprod / cumsum: 1e-4 of the ray span (cdf steps can be steep)

@@ -59,8 +59,8 @@ def test_render_forward_matches_oracle(S1, S2, perturb):
     noise, u = torch.rand(N, S1, generator=g), torch.rand(N, max(S2, 1), generator=g)
     with torch.no_grad():
         want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=perturb, noise_coarse=noise, u_fine=u)
-    out, ctx = pipe.forward(o.cuda(), d.cuda(), norms.cuda().reshape(-1), S1, S2, perturb, train=False,
-                            noise=noise.cuda(), u=u.cuda() if S2 else None)
+    od, dd, nd, nz, ud = o.cuda(), d.cuda(), norms.cuda().reshape(-1), noise.cuda(), u.cuda()
+    out, ctx = pipe.forward(od, dd, nd, S1, S2, perturb, train=False, noise=nz, u=ud if S2 else None)
     torch.cuda.synchronize()
     # fp16 MLP chain with re-associated fp32 sums + w>1e-4 mask flips: 5e-3 absolute on O(1) outputs
     assert (out['weights_sum'].cpu() - want['weights_sum']).abs().max() < 5e-3
@@ -95,12 +95,13 @@ def hip_loss(pipe, out, batch, N, C_, D, Cf, scale=1.0, weights=(1.0, 0.1, 1.0, 
     g_sem, g_feat = torch.empty(N, C_, device=dv), torch.empty(N, D, device=dv)
     counts, terms = torch.zeros(2, dtype=torch.int32, device=dv), torch.zeros(5, device=dv)
     ls = torch.tensor([scale], device=dv)
-    gt = {k: v.cuda() for k, v in batch.items()}
+    gt = {k: v.cuda().contiguous() for k, v in batch.items()}
     gt['semantic'] = gt['semantic'].int()
     H.call('aln_loss_fwd_bwd', H.ptr(out['image']), H.ptr(out['depth']), H.ptr(out['semantic']), H.ptr(out['semantic_features']),
-           H.ptr(gt['pixels']), H.ptr(gt['depth']), H.ptr(gt['semantic']), H.ptr(gt['features'].contiguous()) if Cf else None, N, C_, D, Cf,
+           H.ptr(gt['pixels']), H.ptr(gt['depth']), H.ptr(gt['semantic']), H.ptr(gt['features']) if Cf else None, N, C_, D, Cf,
            weights[0], weights[1], weights[2], weights[3], H.ptr(ls), H.ptr(counts), H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem),
            H.ptr(g_feat), H.ptr(terms), H.stream())
+    torch.cuda.synchronize()  # gt / ls temporaries must outlive the launch
     return g_image, g_depth, g_sem, g_feat, terms
 
 
@@ -114,7 +115,8 @@ def test_loss_kernel_matches_trainer_formula():
     o_req = {k: v.clone().requires_grad_(True) for k, v in out.items()}
     loss, terms = O.loss_fn(o_req, batch, feature_loss=True)
     loss.backward()
-    gi, gd, gs, gf, t = hip_loss(pipe, {k: v.cuda() for k, v in out.items()}, batch, N, C_, D, Cf, scale=128.0)
+    out_d = {k: v.cuda() for k, v in out.items()}
+    gi, gd, gs, gf, t = hip_loss(pipe, out_d, batch, N, C_, D, Cf, scale=128.0)
     assert abs(t[4].item() - loss.item()) < 1e-5 * max(1, abs(loss.item()))
     assert torch.allclose(gi.cpu() / 128, o_req['image'].grad, atol=1e-7)
     assert torch.allclose(gd.cpu() / 128, o_req['depth'].grad, atol=1e-7)
@@ -122,22 +124,29 @@ def test_loss_kernel_matches_trainer_formula():
     assert torch.allclose(gf.cpu() / 128, o_req['semantic_features'].grad, atol=1e-7)
     # no labels / no valid depth: terms vanish instead of NaN (SPEC)
     batch2 = dict(batch, semantic=torch.full((N,), -1), depth=torch.zeros(N))
-    gi, gd, gs, gf, t = hip_loss(pipe, {k: v.cuda() for k, v in out.items()}, batch2, N, C_, D, Cf)
+    gi, gd, gs, gf, t = hip_loss(pipe, out_d, batch2, N, C_, D, Cf)
     assert gs.abs().max().item() == 0 and gd.abs().max().item() == 0 and torch.isfinite(t).all()
 
 
 def test_train_step_gradients_match_oracle_autograd():
+    """Backward parity.  The oracle is evaluated at the HIP path's own importance samples (z_fine_override):
+    the finest hash-grid cells are 4e-6 wide, so a 1e-6 difference in z (re-associated cumsum in the sampler,
+    tested on its own above) moves a sample's gradient to other table entries."""
     oracle, pipe, cfg = build_pair(L=16, D=64, C_=3)
     N, S1, S2, C_, D, Cf = 64, 64, 64, 3, 64, 48
     o, d, norms = make_rays(N, seed=2)
     g = torch.Generator().manual_seed(11)
     noise, u = torch.rand(N, S1, generator=g), torch.rand(N, S2, generator=g)
     batch = _batch(N, C_, Cf, seed=4)
-    want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=True, noise_coarse=noise, u_fine=u)
+    od, dd, nd, nz, ud = o.cuda(), d.cuda(), norms.cuda().reshape(-1), noise.cuda(), u.cuda()
+    out, ctx = pipe.forward(od, dd, nd, S1, S2, True, train=True, noise=nz, u=ud)
+    z_fine = ctx['z'][N * S1:].view(N, S2).cpu()
+    want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=True, noise_coarse=noise, u_fine=u,
+                      z_fine_override=z_fine)
     loss, _ = O.loss_fn(want, batch, feature_loss=True)
     loss.backward()
     gw = flat_grads(oracle, cfg)
-    out, ctx = pipe.forward(o.cuda(), d.cuda(), norms.cuda().reshape(-1), S1, S2, True, train=True, noise=noise.cuda(), u=u.cuda())
+    assert (out['image'].cpu() - want['image']).abs().max() < 3e-3
     scale = 1024.0
     gi, gd, gs, gf, t = hip_loss(pipe, out, batch, N, C_, D, Cf, scale=scale)
     assert abs(t[4].item() - loss.item()) < 5e-3 * max(1.0, loss.item())
@@ -147,14 +156,14 @@ def test_train_step_gradients_match_oracle_autograd():
     assert pipe.found_inf.item() == 0
     got = pipe.P.grad[:pipe.L.n_total].cpu() / scale
     L = pipe.L
-    # fp16 gradient activations (loss-scaled) vs fp32 autograd: <= 3% of each tensor's norm
-    assert rel(got[:L.n_grid], gw[:L.n_grid]) < 3e-2, 'hash-grid gradient'
+    # fp16 gradient activations (loss-scaled) vs fp32 autograd: <= 1% of each tensor's norm
+    assert rel(got[:L.n_grid], gw[:L.n_grid]) < 1e-2, 'hash-grid gradient'
     for k in ['sigma', 'color', 'semf', 'semo']:
         a = L.offsets[k]
         b = a + L.nets[k].n_params
-        assert rel(got[a:b], gw[a:b]) < 3e-2, k
+        assert rel(got[a:b], gw[a:b]) < 1e-2, k
     touched_h, touched_o = got[:L.n_grid] != 0, gw[:L.n_grid] != 0
-    # same table entries receive gradient (ties at the w>1e-4 / ReLU boundaries may drop a few)
+    # same table entries receive gradient (fp16 underflow of tiny contributions may drop a few)
     assert (touched_h != touched_o).float().mean().item() < 1e-3
 
 
