@@ -41,7 +41,7 @@ __device__ inline void normalize_pos(const float* x, float bound, bool clip, flo
 }
 
 // level-local corner indices + trilinear weights (oracle: grid_corner_indices)
-__device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn, uint32_t* idx, float* w) {
+__device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn, uint32_t* idx, float* w, uint32_t* base = nullptr) {
   float scale = g.scale[l];
   uint32_t res = g.res[l], size = g.size[l];
   bool dense = g.dense[l] != 0;
@@ -53,6 +53,7 @@ __device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn
     gi[k] = (uint32_t)(int)fl;
     fr[k] = __fsub_rn(pos, fl);
   }
+  if (base) { base[0] = gi[0]; base[1] = gi[1]; base[2] = gi[2]; }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     float ww = 1.0f; uint32_t cg[3];
@@ -125,12 +126,25 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
   }
 }
 
+// Backward: scatter-add of w_c * dL/dfeat into the fp32 gradient table.
+//
+// Measured on MI355X (scripts/dev/probe_atomics*.hip): a global float atomic costs one request per distinct
+// 32-byte sector per wave-instruction (~21 G requests/s chip-wide, independent of scope, XCD locality or table size);
+// lanes hitting the SAME address serialize (14 G lane-ops/s), lanes sharing a sector coalesce (8 lanes/sector: 166 G
+// lane-ops/s).  Hence:
+//  1. run-dedupe: consecutive samples of a ray fall into the same cell at coarse levels (and, for the importance
+//     samples, far into the fine levels); a wave-level segmented reduction sums them before anything is issued;
+//  2. sector-aware issue: the 16 (corner, feature) adds of one cell are issued by 16 ADJACENT lanes ordered
+//     [corner bit0 = x][feature], so the 2 features (8 B) and, when x is even, the x-pair (idx ^ 1: the x prime is 1)
+//     share one 16-byte span -- 4..8 requests per cell instead of 16.
 __global__ __launch_bounds__(256) void k_encode_bwd(EncParams p, const h16* __restrict__ d_enc, float* __restrict__ grad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  h16* tile = (h16*)smem;
   const int pad = p.e.enc_pad;
   const int fdim = 3 * 2 * p.e.n_freq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  h16* tile = (h16*)smem;                                              // [ENC_TILE][pad]
+  float* sval = (float*)(smem + ((ENC_TILE * pad * 2 + 15) & ~15)) + wave * (64 * 16);   // per wave [64 runs][16]
+  uint32_t* sidx = (uint32_t*)((float*)(smem + ((ENC_TILE * pad * 2 + 15) & ~15)) + 4 * 64 * 16) + wave * (64 * 8);
   const int ntiles = (p.rows + ENC_TILE - 1) / ENC_TILE;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     int rows_here = min(ENC_TILE, p.rows - t * ENC_TILE);
@@ -139,24 +153,52 @@ __global__ __launch_bounds__(256) void k_encode_bwd(EncParams p, const h16* __re
     uint4* dst = (uint4*)tile;
     for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
     __syncthreads();
-    int row = t * ENC_TILE + lane;
-    if (row < p.rows) {
-      float x[3], xn[3];
-      row_position(p, row, x);
-      normalize_pos(x, p.e.bound, true, xn);
-      for (int l = wave; l < p.e.grid.n_levels; l += 4) {
-        h16x2 g = *(h16x2*)&tile[lane * pad + fdim + 2 * l];
-        float g0 = (float)g[0], g1 = (float)g[1];
-        if (g0 == 0.f && g1 == 0.f) continue;
-        uint32_t idx[8]; float w[8];
-        grid_corners(p.e.grid, l, xn, idx, w);
-        float* gt = grad + 2 * (size_t)p.e.grid.offset[l];
+    const int row = t * ENC_TILE + lane;
+    const bool valid = row < p.rows;
+    float x[3] = {0, 0, 0}, xn[3];
+    if (valid) row_position(p, row, x);
+    normalize_pos(x, p.e.bound, true, xn);
+    for (int l = wave; l < p.e.grid.n_levels; l += 4) {
+      float g0 = 0.f, g1 = 0.f;
+      if (valid) { h16x2 g = *(h16x2*)&tile[lane * pad + fdim + 2 * l]; g0 = (float)g[0]; g1 = (float)g[1]; }
+      uint32_t idx[8]; float w[8];
+      uint32_t cell[3];
+      grid_corners(p.e.grid, l, xn, idx, w, cell);
+      // a run = adjacent lanes in the same cell (same base corner => same 8 indices)
+      // (shuffles are evaluated unconditionally: no short-circuit around cross-lane ops)
+      uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
+      bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
+      unsigned long long hm = __ballot(head);
+      int rid = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
+      float v[16];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          unsafeAtomicAdd(gt + 2 * (size_t)idx[c], w[c] * g0);
-          unsafeAtomicAdd(gt + 2 * (size_t)idx[c] + 1, w[c] * g1);
+      for (int c = 0; c < 8; ++c) { v[2 * c] = w[c] * g0; v[2 * c + 1] = w[c] * g1; }
+      const int nruns = __popcll(hm);
+      if (nruns < 64) {  // segmented sum towards the run head
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          int r2 = __shfl_down(rid, off);
+          bool take = (lane + off < 64) && (r2 == rid);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) { float o = __shfl_down(v[k], off); v[k] += take ? o : 0.f; }
         }
       }
+      if (head) {
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) *(float4*)&sval[rid * 16 + k] = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+#pragma unroll
+        for (int c = 0; c < 8; c += 4) *(uint4*)&sidx[rid * 8 + c] = make_uint4(idx[c], idx[c + 1], idx[c + 2], idx[c + 3]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float* gt = grad + 2 * (size_t)p.e.grid.offset[l];
+      const int nops = nruns * 16;
+      for (int op = lane; op < nops; op += 64) {
+        int r = op >> 4, k = op & 15;
+        float val = sval[r * 16 + k];
+        if (val != 0.f) unsafeAtomicAdd(gt + 2 * (size_t)sidx[r * 8 + (k >> 1)] + (k & 1), val);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
   }
@@ -197,7 +239,7 @@ extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const fl
   if (rows == 0 || !e->use_grid) return 0;
   int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
-  size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);
+  size_t lds = (((size_t)ENC_TILE * e->enc_pad * sizeof(h16) + 15) & ~(size_t)15) + 4 * 64 * (16 * sizeof(float) + 8 * sizeof(uint32_t));
   hipLaunchKernelGGL(k_encode_bwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (const h16*)d_enc, grad_table);
   ALN_CHECK_LAUNCH("encode_bwd");
   return 0;

@@ -1,0 +1,94 @@
+"""Fused training step: render forward -> on-device loss -> backward -> (RCCL grad all-reduce) -> fused Adam.
+
+This is the MI355X-native replacement of the reference's hot loop (autolabel/trainer.py:39-49: zero_grad, autocast
+forward, GradScaler-scaled backward, per-optimizer step, scaler.update) with no host synchronisation: the loss
+scale, the overflow flag, the optimizer step counter and the loss terms all live on the device.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip as H
+
+ADAM_DEFAULTS = dict(lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6)  # scripts/train.py:50-63
+SCALER_DEFAULTS = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)  # torch GradScaler
+
+
+class TrainEngine:
+    def __init__(self, pipe, lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6, rgb_weight=1.0, depth_weight=0.1,
+                 semantic_weight=1.0, feature_weight=0.5, feature_loss=False, num_steps=128, upsample_steps=128,
+                 scaler=None, process_group=None):
+        self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
+        dv = self.P.device
+        self.lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(weight_decay_net)
+        self.weights = (float(rgb_weight), float(depth_weight), float(semantic_weight), float(feature_weight))
+        self.feature_loss = feature_loss
+        self.S1, self.S2 = int(num_steps), int(upsample_steps)
+        sc = dict(SCALER_DEFAULTS, **(scaler or {}))
+        self.scaler_cfg = sc
+        n = self.L.n_total
+        self.m = torch.zeros(n, device=dv)
+        self.v = torch.zeros(n, device=dv)
+        self.state_i = torch.zeros(4, dtype=torch.int32, device=dv)  # [adam step, growth tracker, found_inf, -]
+        self.state_f = torch.tensor([sc['init_scale'], 0, 0, 0], dtype=torch.float32, device=dv)  # [loss scale]
+        self.consts = torch.zeros(4, device=dv)
+        self.counts = torch.zeros(2, dtype=torch.int32, device=dv)
+        self.terms = torch.zeros(5, device=dv)  # rgb, depth, feature, semantic, total (last step)
+        pipe.found_inf = self.state_i[2:3]
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self._g = {}
+
+    def _gbuf(self, name, shape):
+        t = self._g.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._g[name] = torch.empty(shape, dtype=torch.float32, device=self.P.device)
+        return t
+
+    def forward_backward(self, batch, seed, step, noise=None, u=None):
+        L, pipe = self.L, self.pipe
+        N = batch['rays_o'].shape[0]
+        out, ctx = pipe.forward(batch['rays_o'], batch['rays_d'], batch['direction_norms'].reshape(-1), self.S1, self.S2, True,
+                                train=True, seed=seed, step=step, noise=noise, u=u)
+        gt_feat = batch.get('features') if self.feature_loss else None
+        Cf = gt_feat.shape[1] if gt_feat is not None else 0
+        g_image, g_depth = self._gbuf('g_image', (N, 3)), self._gbuf('g_depth', (N,))
+        g_sem, g_feat = self._gbuf('g_sem', (N, L.C)), self._gbuf('g_feat', (N, L.D))
+        w = self.weights
+        H.call('aln_loss_fwd_bwd', H.ptr(out['image']), H.ptr(out['depth']), H.ptr(out['semantic']),
+               H.ptr(out['semantic_features']), H.ptr(batch['pixels']), H.ptr(batch['depth']), H.ptr(batch['semantic']),
+               H.ptr(gt_feat), N, L.C, L.D, Cf, w[0], w[1], w[2], w[3] if gt_feat is not None else 0.0, H.ptr(self.state_f),
+               H.ptr(self.counts), H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem), H.ptr(g_feat), H.ptr(self.terms), H.stream())
+        pipe.backward(ctx, g_image, g_depth, g_sem, g_feat)
+        return out
+
+    def all_reduce_grads(self):
+        """One collective for every gradient (flat buffer) + the overflow flag riding in its tail."""
+        if self.world == 1:
+            return
+        n = self.L.n_total
+        self.P.grad[n] = self.state_i[2].float()
+        torch.distributed.all_reduce(self.P.grad, op=torch.distributed.ReduceOp.AVG, group=self.pg)
+        self.state_i[2] = (self.P.grad[n] > 0).int()
+        self.P.grad[n] = 0
+
+    def optimizer_step(self):
+        P, L, sc = self.P, self.L, self.scaler_cfg
+        H.call('aln_adam_step', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
+               H.ptr(self.state_i), H.ptr(self.state_f), H.ptr(self.consts), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+               sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), H.stream())
+        P.refresh_shadows(grid=False)
+
+    def step(self, batch, seed, step, noise=None, u=None):
+        out = self.forward_backward(batch, seed, step, noise, u)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        return out
+
+    # checkpoint payload mirrors torch's {'optimizer', 'scaler'} entries (autolabel/backend.py:157-164)
+    def state_dict(self):
+        return {'m': self.m, 'v': self.v, 'state_i': self.state_i, 'state_f': self.state_f, 'lr': self.lr}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.state_i.copy_(sd['state_i']); self.state_f.copy_(sd['state_f'])
+        self.lr = float(sd.get('lr', self.lr))

@@ -75,6 +75,20 @@ class Params:
             self.frags[k] = (wf, wb)
             self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr())
 
+    def init_(self, seed=0):
+        """tcnn default initialisation: grid U(-1e-4,1e-4), MLP weights xavier-uniform per padded [out,in] matrix."""
+        L = self.layout
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        if L.n_grid:
+            self.flat[:L.n_grid] = (torch.rand(L.n_grid, generator=g, device=self.device) * 2 - 1) * 1e-4
+        for k, s in L.nets.items():
+            o = L.offsets[k]
+            for (no, ni) in s.shapes:
+                lim = math.sqrt(6.0 / (no + ni))
+                self.flat[o:o + no * ni] = (torch.rand(no * ni, generator=g, device=self.device) * 2 - 1) * lim
+                o += no * ni
+        self.refresh_shadows()
+
     def net_view(self, k, buf=None):
         buf = self.flat if buf is None else buf
         o = self.layout.offsets[k]

@@ -1,0 +1,167 @@
+"""Headline benchmark: NeRF training throughput (rays/s) on a synthetic 640x480 RGB-D scene.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); weak scaling: every rank trains on its own
+4096-ray batches drawn from its shard of the frames, gradients are averaged with one RCCL all-reduce per step.
+A "step" = device ray generation + render forward + loss + backward + Adam for one batch, inputs resident in HBM.
+Prints ONE JSON line on rank 0 (contract in the task description; `roofline` and `cpu_baseline` objects added).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=100)
+    p.add_argument('--warmup', type=int, default=20)
+    p.add_argument('--batch', type=int, default=4096)
+    p.add_argument('--frames', type=int, default=200)
+    p.add_argument('--feature-dim', type=int, default=64)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--render-frames', type=int, default=2)
+    return p.parse_args()
+
+
+def build(args, device, rank, world):
+    from autolabel_amd import hip as H
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    # S1 scene: 640x480, trained at factor 2 like scripts/train.py:15
+    scene = synthetic.make_room_scene(n_frames=args.frames, seed=0, device=device, feat_dim=64, feat_hw=(60, 80))
+    full = DeviceFrames.from_scene(scene, device)
+    train = DeviceFrames.from_scene(synthetic.subsample(scene, 2), device)
+    lo, hi = scene['min_bounds'], scene['max_bounds']
+    bound = float(((hi - lo) - (lo + hi) * 0.5).max())  # autolabel/model_utils.py:62-63
+    layout = ModelLayout('hg+freq', 15, 128, 128, args.feature_dim, scene['n_classes'], bound=bound)
+    P = Params(layout, device)
+    P.init_(seed=0)
+    pipe = HipPipeline(layout, P)
+    pg = torch.distributed.group.WORLD if world > 1 else None
+    eng = TrainEngine(pipe, feature_loss=True, process_group=pg)
+    per = args.frames // world
+    return scene, full, train, eng, (rank * per, (rank + 1) * per if rank < world - 1 else args.frames)
+
+
+def cpu_baseline(scene_small, feature_dim, n_classes, bound, B=256, steps=2):
+    """The CPU oracle (pure PyTorch fp32, all host threads) on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import nerf_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    cfg = O.ModelConfig(feature_dim=feature_dim, n_classes=n_classes, bound=bound)
+    m = O.OracleModel(cfg, seed=0)
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in m.params.items()}
+    g = torch.Generator().manual_seed(0)
+    times = []
+    for it in range(steps + 1):
+        o = (torch.rand(B, 3, generator=g) - 0.5) * 2
+        d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1)
+        batch = {'pixels': torch.rand(B, 3, generator=g), 'depth': torch.rand(B, generator=g) * 3,
+                 'semantic': torch.randint(-1, n_classes, (B,), generator=g), 'features': torch.randn(B, 64, generator=g)}
+        t0 = time.time()
+        out = m.run(o, d, torch.ones(B, 1), 128, 128, perturb=True, noise_coarse=torch.rand(B, 128, generator=g),
+                    u_fine=torch.rand(B, 128, generator=g))
+        loss, _ = O.loss_fn(out, batch, feature_loss=True)
+        for p in m.params.values():
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for k, p in m.params.items():
+                O.adam_update(p, p.grad, st[k][0], st[k][1], it + 1, 5e-3, weight_decay=0.0 if k == 'grid' else 1e-6)
+        if it > 0:
+            times.append(time.time() - t0)
+    return B / (sum(times) / len(times)), f'{steps} oracle train steps of {B} rays x 256 samples (same model config)'
+
+
+def main():
+    args = parse()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    scene, full, train, eng, frange = build(args, device, rank, world)
+    B = args.batch
+    batch = train.alloc_batch(B)
+    batch['direction_norms'] = batch['direction_norms']
+
+    def step(i):
+        train.next_train(batch, seed=1234 + rank, step=i, frame_range=frange)
+        eng.step(batch, seed=99 + rank, step=i)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.time()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    rays_per_s = B * world * args.steps / dt
+    terms = eng.terms.tolist()
+
+    # render throughput: full 640x480 frames, 512 coarse steps, no upsampling (scripts/render.py:96-102)
+    render_mrays = None
+    if rank == 0 and args.render_frames > 0:
+        fb = full.alloc_batch(full.w * full.h)
+        full.get_test(0, fb)
+        chunk = 16384
+        def render_frame(f):
+            full.get_test(f, fb)
+            for a in range(0, full.w * full.h, chunk):
+                eng.pipe.forward(fb['rays_o'][a:a + chunk], fb['rays_d'][a:a + chunk], fb['direction_norms'][a:a + chunk].reshape(-1),
+                                 512, 0, False, train=False)
+        render_frame(0)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for f in range(args.render_frames):
+            render_frame(f)
+        torch.cuda.synchronize()
+        render_mrays = full.w * full.h * args.render_frames / (time.time() - t1) / 1e6
+
+    if rank == 0:
+        res = {
+            'metric': 'train rays/sec (640x480 synthetic RGB-D scene, hg+freq, DINO-like features)', 'value': rays_per_s,
+            'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1000 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': "S1 synthetic room standing in for the 'bench' scene: 200 frames 640x480 trained at factor 2, "
+                                   'DINO-like 64-d features, hg+freq L=16 T=2^19, 128+128 samples/ray',
+                       'rays_per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}'},
+            'render_Mrays_per_s': render_mrays,
+            'loss_terms_last_step': {'rgb': terms[0], 'depth': terms[1], 'feature': terms[2], 'semantic': terms[3], 'total': terms[4]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            lo, hi = scene['min_bounds'], scene['max_bounds']
+            v, sample = cpu_baseline(None, args.feature_dim, scene['n_classes'], float(((hi - lo) - (lo + hi) * 0.5).max()))
+            res['cpu_baseline'] = {'value': v, 'unit': 'rays/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': sample}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
