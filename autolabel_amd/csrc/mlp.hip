@@ -12,6 +12,7 @@
 // Activations therefore never leave registers between layers; weights live in LDS in fragment order
 // (one conflict-free ds_read_b128 per lane per MFMA).
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------- fragment bookkeeping
 struct MlpLayers {
@@ -335,6 +336,205 @@ __global__ __launch_bounds__(256) void k_dw_gemm(const h16* __restrict__ dA, int
   }
 }
 
+// ---------------------------------------------------------------- fused backward (data path + weight gradients)
+// One kernel per head: the backward chain stays in registers as above; for the weight gradients
+//   dW_l[o][i] = sum_samples dA_l[s][o] * X_l[s][i]
+// the contraction index is the SAMPLE, i.e. both MFMA operands need 8 consecutive samples per lane.  The block stages
+// dA_l and X_l (saved activations / layer input) of its 128 samples in LDS as plain row-major [sample][feature] tiles and
+// reads operand fragments with the gfx950 hardware transpose read ds_read_b64_tr_b16 (16 lanes fetch a 4-sample x 16-feature
+// block; lane i receives feature i of 4 consecutive samples -- semantics verified by scripts/dev/probe_trread.hip).
+// dW accumulators live in registers for the whole kernel (each wave owns a fixed subset of 32x32 C-blocks) and are flushed
+// once at the end: no per-layer dA round trip through HBM and no separate dW GEMM launches.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ inline h16x8 tr_frag(const h16* tile, int pitch, int col0, int ks, int lane) {
+  // operand fragment for mfma 32x32x16: lane (i = lane&31, hf = lane>>5) gets tile[16ks + 8hf + 0..7][col0 + i]
+  const int hf = lane >> 5;
+  const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  uint32_t a0 = (uint32_t)(uintptr_t)(tile + (size_t)row * pitch + col);
+  uint32_t a1 = (uint32_t)(uintptr_t)(tile + (size_t)(row + 4) * pitch + col);
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+  union { struct { s16x4 l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+// cooperative global -> LDS tile load: nrows x ncols halves (ncols % 8 == 0), rows >= limit are zero-filled
+__device__ inline void load_tile(h16* tile, int pitch, const h16* g, int ncols, int r0, int nrows, int limit) {
+  const int per_row = ncols / 8;
+  for (int i = threadIdx.x; i < nrows * per_row; i += 256) {
+    int r = i / per_row, k = i % per_row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < limit) v = *(const uint4*)(g + (size_t)(r0 + r) * ncols + 8 * k);
+    *(uint4*)(tile + (size_t)r * pitch + 8 * k) = v;
+  }
+}
+
+// dW accumulate over the block tile: wave owns C-blocks blk = wave + 4b (blk -> (ob, ib) = (blk / NIB, blk % NIB)).
+// When 4 % NIB == 0 the input block ib is the same for all owned blocks, so its fragment is fetched once per k-step.
+template <int NBLK, int NOB, int NIB>
+__device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], const h16* tA, int pA, const h16* tB, int pB, int wave, int lane) {
+  constexpr bool IB_CONST = (4 % NIB) == 0;
+#pragma unroll 1
+  for (int ks = 0; ks < 128 / 16; ++ks) {
+    h16x8 bc;
+    if (IB_CONST) bc = tr_frag(tB, pB, 32 * (wave % NIB), ks, lane);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      const int blk = wave + 4 * b;
+      if (blk < NOB * NIB) {
+        h16x8 a = tr_frag(tA, pA, 32 * (blk / NIB), ks, lane);
+        h16x8 bb = IB_CONST ? bc : tr_frag(tB, pB, 32 * (blk % NIB), ks, lane);
+        dw[b] = mfma16(a, bb, dw[b]);
+      }
+    }
+  }
+}
+
+template <int IN, int HID, int OUT, int NHID>
+__global__ __launch_bounds__(256) void k_mlp_bwd_fused(const h16* __restrict__ wb_g, size_t wb_halves,
+                                                      const h16* __restrict__ x, const h16* __restrict__ h1,
+                                                      const h16* __restrict__ h2, const h16* __restrict__ d_out, int rows,
+                                                      const int* __restrict__ rows_dev, h16* __restrict__ d_in,
+                                                      float* __restrict__ dW, int* __restrict__ found_inf) {
+  constexpr int NB = HID / 32, KS = HID / 16, KSO = OUT / 16, IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
+  constexpr int PD = HID + 8, PX = (HID > IN ? HID : IN) + 8, PO = OUT + 8;   // LDS row pitches (halves)
+  constexpr int TR = 128;                                                        // rows per block tile
+  // C-blocks owned per wave (round-robin over the 4 waves)
+  constexpr int NBLK_LAST = (OB * NB + 3) / 4, NBLK_MID = (NB * NB + 3) / 4, NBLK_FIRST = (NB * IB + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* wl = (h16*)smem;
+  h16* tD = wl + wb_halves;
+  h16* tX = tD + TR * PD;
+  h16* tO = tX + TR * PX;
+  copy_to_lds(wl, wb_g, wb_halves);
+  const h16x8* frag = (const h16x8*)wl;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
+  if (rows_dev) rows = min(rows, *rows_dev);
+  const size_t f1 = (size_t)NB * KSO;
+  const size_t fl = f1 + (NHID == 2 ? (size_t)NB * KS : 0);
+  MlpLayers L = mlp_layers(IN, HID, OUT, NHID);
+  f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
+  zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
+  bool bad = false;
+  const int ntiles = (rows + TR - 1) / TR;
+  const h16* hl = (NHID == 2) ? h2 : h1;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * TR;
+    const int srow = wave * 32 + c;           // this lane's sample row inside the tile
+    __syncthreads();                          // previous tile's readers are done with tO / tX / tD
+    load_tile(tO, PO, d_out, OUT, r0, TR, rows);
+    load_tile(tX, PX, hl, HID, r0, TR, rows);
+    __syncthreads();
+    // ---- dW_last[o][i] += dOut^T . h_last
+    dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, tX, PX, wave, lane);
+    // ---- chain: dA_last = relu'(h_last) * (W_last^T dOut)
+    f32x16 acc[NB];
+    zero_acc(acc);
+#pragma unroll
+    for (int ks = 0; ks < KSO; ++ks) {
+      h16x8 bfr = *(const h16x8*)(tO + (size_t)srow * PO + 16 * ks + 8 * hf);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KSO + ks) * 64 + lane], bfr, acc[m]);
+    }
+    h16x8 p[KS];
+    bad |= mask_pack_store<NB>(acc, p, tX + (size_t)srow * PX, nullptr, hf, true);
+    if (NHID == 2) {
+      __syncthreads();                        // everyone is done reading tX (= h2) and tO
+#pragma unroll
+      for (int m = 0; m < NB; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
+          v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
+          *(h16x4*)(tD + (size_t)srow * PD + 32 * m + 8 * q + 4 * hf) = v;
+        }
+      load_tile(tX, PX, h1, HID, r0, TR, rows);
+      __syncthreads();
+      dw_accumulate<NBLK_MID, NB, NB>(dw_mid, tD, PD, tX, PX, wave, lane);
+      zero_acc(acc);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[(f1 + (size_t)m * KS + ks) * 64 + lane], p[ks], acc[m]);
+      bad |= mask_pack_store<NB>(acc, p, tX + (size_t)srow * PX, nullptr, hf, true);
+    }
+    __syncthreads();                          // done reading tX (= h1) / tD
+#pragma unroll
+    for (int m = 0; m < NB; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
+        v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
+        *(h16x4*)(tD + (size_t)srow * PD + 32 * m + 8 * q + 4 * hf) = v;
+      }
+    load_tile(tX, PX, x, IN, r0, TR, rows);
+    // columns IN..32*IB-1 of the last C-block read whatever follows in LDS: they only reach dW columns >= IN, which are never flushed
+    __syncthreads();
+    dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, tD, PD, tX, PX, wave, lane);
+    if (d_in) {
+      const int row = r0 + srow;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) o = mfma16(frag[(fl + (size_t)ib * KS + ks) * 64 + lane], p[ks], o);
+        if (row < rows) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int f = 32 * ib + 8 * q + 4 * hf;
+            if (f < IN) {
+              h16x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] = (h16)o[4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
+              *(h16x4*)(d_in + (size_t)row * IN + f) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- flush weight gradients (C layout: lane = input column, 32 consecutive floats per row)
+  auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, float* base) {
+    const int i = 32 * ib + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      if (o < OUTL && i < INL && a[r] != 0.f) unsafeAtomicAdd(base + (size_t)o * INL + i, a[r]);
+    }
+  };
+  if (dW) {
+#pragma unroll
+    for (int b = 0; b < NBLK_LAST; ++b) { int blk = wave + 4 * b; if (blk < OB * NB) flush(dw_last[b], blk / NB, blk % NB, OUT, HID, dW + L.w_off[L.n - 1]); }
+    if (NHID == 2) {
+#pragma unroll
+      for (int b = 0; b < NBLK_MID; ++b) { int blk = wave + 4 * b; if (blk < NB * NB) flush(dw_mid[b], blk / NB, blk % NB, HID, HID, dW + L.w_off[1]); }
+    }
+#pragma unroll
+    for (int b = 0; b < NBLK_FIRST; ++b) { int blk = wave + 4 * b; if (blk < NB * IB) flush(dw_first[b], blk / IB, blk % IB, HID, IN, dW + L.w_off[0]); }
+  }
+  if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
+}
+
+template <int IN, int HID, int OUT, int NHID>
+static int launch_bwd_fused(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int rows,
+                            const int* rows_dev, void* d_in, float* dW, int* found_inf, hipStream_t s) {
+  constexpr int PD = HID + 8, PX = (HID > IN ? HID : IN) + 8, PO = OUT + 8;
+  size_t halves = (size_t)aln_mlp_frag_halves(IN, HID, OUT, NHID, 1);
+  size_t lds = (halves + 128 * (size_t)(PD + PX + PO)) * 2;
+  ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_fused: LDS %zu B exceeds 160 KiB", lds);
+  int tiles = (rows + 127) / 128;
+  int g = tiles < 256 ? tiles : 256;
+  hipFuncSetAttribute((const void*)k_mlp_bwd_fused<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_mlp_bwd_fused<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wb, halves, (const h16*)x,
+                     (const h16*)h1, (const h16*)h2, (const h16*)d_out, rows, rows_dev, (h16*)d_in, dW, found_inf);
+  ALN_CHECK_LAUNCH("mlp_bwd_fused");
+  return 0;
+}
+
 // ---------------------------------------------------------------- launchers
 static int mlp_grid(int rows) {
   int tiles = (rows + 127) / 128;
@@ -386,11 +586,18 @@ extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, c
   ALN_REQUIRE(m->n_hidden == 1 || h2, "mlp_bwd: h2 required for 2 hidden layers");
   ALN_REQUIRE(!dW || (x && dA1 && (m->n_hidden == 1 || dA2)), "mlp_bwd: dW needs x, dA1, dA2 buffers");
   if (rows <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dW && !getenv("ALN_MLP_BWD_UNFUSED")) {
+#define TRY(I, H, O, N)                                                                                   \
+    if (m->in_pad == I && m->hidden == H && m->out_pad == O && m->n_hidden == N)                          \
+      return launch_bwd_fused<I, H, O, N>(m, x, h1, h2, d_out, rows, rows_dev, d_in, dW, found_inf, s);
+    TRY(48, 128, 16, 2) TRY(32, 128, 16, 2) TRY(64, 128, 16, 2) TRY(16, 64, 64, 2) TRY(80, 64, 16, 1) TRY(80, 64, 32, 1)
+#undef TRY
+  }
   size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 1);
   size_t lds = halves * 2;
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd: weights (%zu B) exceed LDS", lds);
   dim3 g(mlp_grid(rows)), b(256);
-  hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(H, N)                                                                                                   \
   do {                                                                                                                 \
     hipFuncSetAttribute((const void*)k_mlp_bwd<H, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
