@@ -1,0 +1,116 @@
+"""``NeRFRenderer`` -- base class of ``ALNetwork``.
+
+In the reference this class comes from the ETH-ASL fork of torch-ngp (``torch_ngp.nerf.renderer.NeRFRenderer``, not in the
+reference tree; call sites autolabel/trainer.py:64-70,102-107,127-133, scripts/render.py:96-102, scripts/export.py:83-89,
+autolabel/evaluation.py:62-66,302-306, scripts/ros/node.py:256-262, scripts/language/pointcloud.py:58-68).  Here its
+``render``/``run`` are one fixed sequence of HIP launches (``pipeline.HipPipeline``) wrapped in a single autograd node.
+
+Interface kept: ``render(rays_o, rays_d, direction_norms, staged=False, bg_color=None, perturb=False, num_steps=...,
+upsample_steps=..., max_ray_batch=..., **ignored_opt)`` -> dict with ``image, depth, semantic, semantic_features,
+depth_variance, coordinates_map, weights_sum``; attributes ``bound, cuda_ray, density_scale, min_near, bg_radius``;
+``mark_untrained_grid`` / ``update_extra_state`` (no-ops when ``cuda_ray`` is False, autolabel/model_utils.py:72).
+"""
+import torch
+import torch.nn as nn
+
+from .pipeline import HipPipeline, ModelLayout, Params
+
+
+class _RenderFn(torch.autograd.Function):
+    """forward = HipPipeline.forward, backward = HipPipeline.backward; parameter gradients are returned as views of the
+    flat gradient buffer (one tensor per parameter block)."""
+
+    @staticmethod
+    def forward(ctx, model, rays_o, rays_d, norms, cfg, *params):
+        pipe = model._pipe
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        out, c = pipe.forward(rays_o, rays_d, norms, cfg['num_steps'], cfg['upsample_steps'], cfg['perturb'], train=train,
+                              seed=cfg['seed'], step=cfg['step'], noise=cfg.get('noise'), u=cfg.get('u'), bg=cfg['bg'])
+        ctx.model, ctx.c = model, (c if train else None)
+        keys = ['image', 'depth', 'semantic', 'semantic_features', 'depth_variance', 'coordinates_map', 'weights_sum']
+        ctx.mark_non_differentiable(out['depth_variance'], out['coordinates_map'], out['weights_sum'])
+        return tuple(out[k] for k in keys)
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth, g_sem, g_feat, *_):
+        model, c = ctx.model, ctx.c
+        if c is None:
+            raise RuntimeError('render() was run without gradient tracking')
+        pipe, L = model._pipe, model._layout
+        N = c['N']
+        z = lambda g, shape: (torch.zeros(shape, device=pipe.P.device) if g is None else g.float().contiguous())
+        pipe.P.grad.zero_()
+        pipe.backward(c, z(g_image, (N, 3)), z(g_depth, (N,)), z(g_sem, (N, L.C)), z(g_feat, (N, L.D)))
+        grads = []
+        for name, p in model._param_blocks():
+            a, b = model._block_range(name)
+            grads.append(pipe.P.grad[a:b].view_as(p).clone() if p.requires_grad else None)
+        return (None, None, None, None, None, *grads)
+
+
+class NeRFRenderer(nn.Module):
+
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1, **kwargs):
+        super().__init__()
+        self.bound = bound
+        self.cuda_ray = cuda_ray
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+        if cuda_ray:
+            raise NotImplementedError('cuda_ray (occupancy-grid marching) is not part of this hot path '
+                                      '(the reference always passes cuda_ray=False, autolabel/model_utils.py:72)')
+        aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+        self.register_buffer('aabb_train', aabb)
+        self.register_buffer('aabb_infer', aabb.clone())
+        self._render_calls = 0
+        self.num_steps_default, self.upsample_steps_default, self.max_ray_batch_default = 128, 128, 4096
+
+    # --- hooks of the cuda_ray path (dead in the reference configuration)
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        return
+
+    def update_extra_state(self, decay=0.95, S=128):
+        return
+
+    def reset_extra_state(self):
+        return
+
+    def run(self, rays_o, rays_d, direction_norms, num_steps=None, upsample_steps=None, bg_color=None, perturb=False,
+            seed=None, noise=None, u=None, **kwargs):
+        """One chunk of rays [N,3] -> per-ray outputs.  bg_color None -> white (upstream torch-ngp)."""
+        self._ensure_device()
+        N = rays_o.shape[0]
+        cfg = dict(num_steps=int(num_steps if num_steps is not None else self.num_steps_default),
+                   upsample_steps=int(upsample_steps if upsample_steps is not None else self.upsample_steps_default),
+                   perturb=bool(perturb), seed=int(self._seed if seed is None else seed), step=self._render_calls,
+                   bg=1.0 if bg_color is None else float(bg_color), noise=noise, u=u)
+        self._render_calls += 1
+        f = lambda t: t.reshape(-1, t.shape[-1]).float().contiguous()
+        names = ['image', 'depth', 'semantic', 'semantic_features', 'depth_variance', 'coordinates_map', 'weights_sum']
+        outs = _RenderFn.apply(self, f(rays_o), f(rays_d), direction_norms.reshape(-1).float().contiguous(), cfg,
+                               *[p for _, p in self._param_blocks()])
+        return dict(zip(names, outs))
+
+    def render(self, rays_o, rays_d, direction_norms, staged=False, max_ray_batch=None, **kwargs):
+        """rays_*: [..., 3]; direction_norms: [..., 1] (or flat).  staged=True chunks rays by max_ray_batch and returns
+        outputs reshaped to the ray prefix (H, W for a frame: autolabel/trainer.py:109-114)."""
+        prefix = rays_o.shape[:-1]
+        ro, rd = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        dn = direction_norms.reshape(-1)
+        kwargs = {k: v for k, v in kwargs.items() if k in ('num_steps', 'upsample_steps', 'bg_color', 'perturb', 'seed', 'noise', 'u')}
+        if not staged:
+            out = self.run(ro, rd, dn, **kwargs)
+        else:
+            mb = int(max_ray_batch or self.max_ray_batch_default)
+            parts = [self.run(ro[a:a + mb], rd[a:a + mb], dn[a:a + mb], **kwargs) for a in range(0, ro.shape[0], mb)]
+            out = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+        res = {}
+        for k, v in out.items():
+            res[k] = v.reshape(*prefix, *v.shape[1:]) if v.dim() > 1 else v.reshape(*prefix)
+        return res
+
+    # --- device binding of the flat parameter buffer (see models.ALNetwork)
+    def _ensure_device(self):
+        raise NotImplementedError

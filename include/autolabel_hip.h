@@ -111,16 +111,66 @@ int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d
                    int32_t rows, int32_t rays_stride, const void* d_enc /*[rows,enc_pad] f16*/,
                    float* grad_table /*[n_entries*F] f32*/, void* stream);
 
-/* ---- MLPs */
+/* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
                    void* wf, void* wb, void* stream);
 int64_t aln_mlp_frag_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden, int32_t backward);
-/* hs[l]: [rows,hidden] f16 saved post-ReLU activations (NULL at inference). */
+/* h1/h2: [rows,hidden] f16 saved post-ReLU activations (NULL at inference).  rows_dev (optional, device int32)
+ * clamps the row count on the device (compacted live samples). */
 int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t* rows_dev, void* h1, void* h2,
                 void* out, void* stream);
+/* d_in (optional) [rows,in_pad] f16; dW (optional) += weight gradients in the fp32 master layout; dA1/dA2 are scratch
+ * [rows,hidden] f16 (only touched by the unfused fallback); found_inf is OR-ed when an fp16 gradient overflows. */
 int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
-                const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW /*fp32 master layout*/,
-                int32_t* found_inf, void* stream);
+                const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW, int32_t* found_inf, void* stream);
+
+/* ---- head plumbing: autolabel/models.py:175-188 (sigma = trunc_exp(h0), geo_feat = h[1:]), :190-220 (boolean-mask
+ * gather + SH(dir) ++ geo_feat), :248-256 (cat[relu(f), geo_feat]) and the matching gradient assembly */
+int aln_sigma_act(const void* sigma_out /*[rows,16] f16*/, int32_t rows, float* sigma, void* stream);
+int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx, int32_t* cidx_row,
+                     void* stream);
+int aln_build_color_in(const int32_t* live_idx, const int32_t* n_live, int32_t max_rows, const float* rays_d,
+                       const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out, int32_t G, int32_t in_pad,
+                       void* color_in, void* stream);
+int aln_build_sem_in(const void* sigma_out, const void* f, int32_t rows, int32_t D, int32_t G, int32_t semf_in_pad,
+                     int32_t semo_in_pad, void* semf_in, void* semo_in, void* stream);
+int aln_assemble_grads(const float* d_h0, const void* d_semf_in, int32_t semf_in_pad, const void* d_semo_in,
+                       int32_t semo_in_pad, int32_t D, const void* d_color_in, int32_t color_in_pad, const int32_t* cidx_row,
+                       int32_t rows, int32_t G, void* d_sigma_out, int32_t* found_inf, void* stream);
+int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d_semo_in, int32_t rows, int32_t D, int32_t semo_in_pad,
+                           int32_t* found_inf, void* stream);
+
+/* ---- compositing: alpha / cumprod weights and weighted sums of NeRFRenderer.run (fork), outputs image, depth
+ * (metric z-depth = sum w t / direction_norm), semantic, semantic_features, depth_variance, coordinates_map;
+ * call sites autolabel/trainer.py:64-70, scripts/export.py:83-89, scripts/language/pointcloud.py:58-68 */
+int aln_composite_fwd(const float* rays_o, const float* rays_d, const float* norms, const float* nears, const float* fars,
+                      const float* z, const float* sigma, int32_t N, int32_t S1, int32_t S2, float bound, float density_scale,
+                      uint16_t* perm, float* w_row, float* T_row, float* delta_row, float* wsum, float* depth, float* depth_var,
+                      float* coords, void* stream);
+int aln_composite_out(const float* w_row, const int32_t* cidx_row, const void* color_out, const void* logits, const void* feat,
+                      const float* wsum, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad, int32_t D, float bg,
+                      float* image, float* semantic, float* features, void* stream);
+int aln_composite_bwd(const float* norms, const float* z, const float* sigma, const uint16_t* perm, const float* w_row,
+                      const float* T_row, const float* delta_row, const int32_t* cidx_row, const void* color_out,
+                      const void* logits, const void* feat, const void* sigma_out, const float* g_image, const float* g_depth,
+                      const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad,
+                      int32_t D, float bg, float density_scale, float* d_h0, void* d_color_out, void* d_logits, void* d_feat,
+                      int32_t* found_inf, void* stream);
+
+/* ---- loss: autolabel/trainer.py:72-92 (rgb MSE + depth L1 over depth > 0.01 + feature L1 + CE over labelled rays).
+ * Writes per-ray output gradients (times *loss_scale) and terms[5] = {rgb, depth, feature, semantic, total}. */
+int aln_loss_fwd_bwd(const float* image, const float* depth, const float* semantic, const float* features, const float* gt_rgb,
+                     const float* gt_depth, const int32_t* gt_sem, const float* gt_feat, int32_t N, int32_t C, int32_t D,
+                     int32_t Cf, float w_rgb, float w_depth, float w_sem, float w_feat, const float* loss_scale, int32_t* counts,
+                     float* g_image, float* g_depth, float* g_sem, float* g_feat, float* terms, void* stream);
+
+/* ---- optimizer: torch.optim.Adam of scripts/train.py:50-63 + GradScaler step/update of autolabel/trainer.py:45-48.
+ * state_i = {step, growth tracker, found_inf, -}, state_f = {loss scale}; skips the update (and backs the scale off)
+ * when found_inf is set; refreshes the fp16 table shadow; zeroes the gradients. */
+int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid, int64_t n_total,
+                  int32_t* state_i, float* state_f, float* consts, float lr, float beta1, float beta2, float eps, float wd_net,
+                  float growth, float backoff, int32_t growth_interval, void* stream);
+int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

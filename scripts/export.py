@@ -1,0 +1,89 @@
+"""Export per-frame semantic label maps of fitted scenes to <scene>/output/semantic/ (CLI of the reference's
+scripts/export.py).  The optional largest-connected-components filter uses scipy.ndimage instead of skimage."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from autolabel_amd import model_utils
+from autolabel_amd.dataset import SceneDataset
+from autolabel_amd.utils import Scene
+
+MAX_WIDTH = 640
+
+
+def read_args():
+    parser = model_utils.model_flag_parser()
+    parser.add_argument('scenes', nargs='+')
+    parser.add_argument('--workspace', type=str)
+    parser.add_argument('--objects', type=int, default=None,
+                        help='keep only this many largest connected components per class')
+    return parser.parse_args()
+
+
+def lookup_frame_size(scene):
+    width, height = Scene(scene).peak_image_size()
+    if width > MAX_WIDTH:
+        scale = MAX_WIDTH / width
+        width, height = width * scale, height * scale
+    return (int(np.round(width)), int(np.round(height)))
+
+
+def post_process(flags, p_semantic):
+    from scipy import ndimage
+    out = np.zeros_like(p_semantic)
+    for class_id in np.unique(p_semantic):
+        if class_id == 0:
+            continue
+        labels, n = ndimage.label(p_semantic == class_id)
+        counts = np.bincount(labels.flat)[1:]
+        for lab in np.argsort(counts)[::-1][:flags.objects] + 1:
+            out[labels == lab] = class_id
+    return out
+
+
+def render_frame(model, batch):
+    rays_o = torch.tensor(batch['rays_o']).cuda()
+    rays_d = torch.tensor(batch['rays_d']).cuda()
+    direction_norms = torch.tensor(batch['direction_norms']).cuda()
+    outputs = model.render(rays_o, rays_d, direction_norms, staged=True, perturb=False, num_steps=512, upsample_steps=0)
+    return outputs['semantic'].argmax(dim=-1).cpu().numpy()
+
+
+def export_labels(flags, scene):
+    from PIL import Image
+    scene = scene.rstrip(os.path.sep)
+    model_root = os.path.join(flags.workspace, os.path.basename(scene)) if flags.workspace is not None else os.path.join(scene, 'nerf')
+    models = os.listdir(model_root)
+    if len(models) == 0:
+        print(f'Warning: scene {scene} has no trained models. Skipping.')
+        return
+    if len(models) > 1:
+        print(f'Warning: scene {scene} has more than 1 model directory. Using {models[0]}.')
+    model_dir = os.path.join(model_root, models[0])
+    params = model_utils.read_params(model_dir)
+    dataset = SceneDataset('train', scene, size=lookup_frame_size(scene), batch_size=16384, features=params.features, load_semantic=False)
+    n_classes = dataset.n_classes if dataset.n_classes is not None else 2
+    model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, n_classes, params).cuda().eval()
+    model_utils.load_checkpoint(model, os.path.join(model_dir, 'checkpoints'))
+    output_path = os.path.join(scene, 'output', 'semantic')
+    os.makedirs(output_path, exist_ok=True)
+    with torch.inference_mode():
+        for frame_index, rgb_path in zip(dataset.indices, dataset.scene.rgb_paths()):
+            frame = render_frame(model, dataset._get_test(frame_index))
+            if flags.objects is not None:
+                frame = post_process(flags, frame)
+            name = os.path.splitext(os.path.basename(rgb_path))[0]
+            Image.fromarray(frame.astype(np.uint8)).save(os.path.join(output_path, f'{name}.png'))
+
+
+def main():
+    flags = read_args()
+    for scene in flags.scenes:
+        export_labels(flags, scene)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,193 @@
+"""The drop-in Python surface (models / renderer / trainer / scripts) on the GPU, checked against the oracle."""
+import math
+import os
+import subprocess
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_model(D=64, C_=3, bound=1.0, encoding='hg+freq', grid_scale=3e3):
+    from autolabel_amd.models import ALNetwork
+    m = ALNetwork(encoding=encoding, num_layers=2, hidden_dim=128, geo_feat_dim=15, num_layers_color=2, hidden_dim_color=128,
+                  hidden_dim_semantic=D, semantic_classes=C_, bound=bound, cuda_ray=False, density_scale=1)
+    with torch.no_grad():
+        if m._layout.n_grid:
+            m.encoder.grid_encoding.params.mul_(grid_scale)
+    return m.cuda()
+
+
+def oracle_of(model):
+    """Oracle with the model's current parameters (half_sim: same fp16 rounding points)."""
+    L = model._layout
+    cfg = O.ModelConfig(encoding=model.encoding, feature_dim=L.D, n_classes=L.C, bound=float(model.bound),
+                        grid=O.GridSpec(per_level_scale=float(L.enc.grid.per_level_scale)))
+    p = {}
+    if L.n_grid:
+        p['grid'] = model.encoder.grid_encoding.params.detach().cpu().view(-1, 2).half().float().clone()
+    for name, blk in [('sigma', model.sigma_net), ('color', model.color_net), ('semf', model.semantic_features), ('semo', model.semantic_out)]:
+        flat, o = blk.params.detach().cpu(), 0
+        for i, (no, ni) in enumerate(O.mlp_shapes(cfg)[name]):
+            p[f'{name}.{i}'] = flat[o:o + no * ni].view(no, ni).clone()
+            o += no * ni
+    return O.OracleModel(cfg, params=p, half_sim=True), cfg
+
+
+@pytest.mark.parametrize('encoding', ['hg+freq', 'freq', 'hg'])
+def test_point_queries_match_oracle(encoding):
+    model = make_model(encoding=encoding, bound=1.5)
+    oracle, cfg = oracle_of(model)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(500, 3, generator=g) * 2 - 1) * 1.5
+    d = torch.nn.functional.normalize(torch.randn(500, 3, generator=g), dim=1)
+    with torch.no_grad():
+        want = oracle.density(x)
+        got = model.density(x.cuda())
+        assert got['geo_feat'].shape == (500, 15)
+        assert (got['geo_feat'].float().cpu() - want['geo_feat']).abs().max() < 5e-3 * max(1.0, want['geo_feat'].abs().max().item())
+        assert (got['sigma'].cpu() / want['sigma'] - 1).abs().max() < 2e-2  # exp() of a 1-ulp-different fp16 logit
+        mask = torch.rand(500, generator=g) > 0.5
+        rgb_w = oracle.color(x, d, mask=mask, geo_feat=want['geo_feat'])
+        rgb = model.color(x.cuda(), d.cuda(), mask=mask.cuda(), geo_feat=want['geo_feat'].cuda())
+        assert (rgb.cpu() - rgb_w).abs().max() < 3e-3 and rgb.cpu()[~mask].abs().max() == 0
+        assert model.color(x.cuda(), d.cuda(), mask=torch.zeros(500, dtype=torch.bool).cuda(), geo_feat=want['geo_feat'].cuda()).abs().max() == 0
+        lw, fw = oracle.semantic(want['geo_feat'])
+        lg, fg = model.semantic(want['geo_feat'].cuda(), got['sigma'])
+        assert (lg.float().cpu() - lw).abs().max() < 5e-3 * max(1.0, lw.abs().max().item())
+        assert (fg.float().cpu() - fw).abs().max() < 5e-3 * max(1.0, fw.abs().max().item())
+        s, rgb2, sem = model(x.cuda(), d.cuda())
+        assert s.shape == (500,) and rgb2.shape == (500, 3) and torch.allclose(sem.sum(-1), torch.ones(500).cuda(), atol=1e-3)
+
+
+def test_unknown_encoding_and_cpu_model_raise():
+    from autolabel_amd.models import ALNetwork
+    with pytest.raises(NotImplementedError):
+        ALNetwork(encoding='nope')
+    m = ALNetwork(encoding='hg+freq', hidden_dim=128, hidden_dim_color=128, num_layers_color=2)
+    with pytest.raises(RuntimeError):
+        m.density(torch.zeros(4, 3))  # CPU model: no fallback
+
+
+def test_render_staged_shapes_and_state_dict_roundtrip():
+    model = make_model().eval()
+    H_, W_ = 12, 20
+    g = torch.Generator().manual_seed(1)
+    o = torch.zeros(H_, W_, 3).cuda()
+    d = torch.nn.functional.normalize(torch.randn(H_, W_, 3, generator=g), dim=-1).cuda()
+    n = torch.ones(H_ * W_, 1).cuda()  # the [H*W,1] quirk of _get_test
+    with torch.inference_mode():
+        out = model.render(o, d, n, staged=True, perturb=False, num_steps=64, upsample_steps=0, max_ray_batch=100,
+                           rgb_weight=1.0, feature_loss=False)  # extra opt entries are ignored like **vars(opt)
+    assert out['image'].shape == (H_, W_, 3) and out['depth'].shape == (H_, W_)
+    assert out['semantic'].shape == (H_, W_, 3) and out['semantic_features'].shape == (H_, W_, 64)
+    assert out['depth_variance'].shape == (H_, W_) and out['coordinates_map'].shape == (H_, W_, 3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert 'sigma_net.params' in sd and 'encoder.grid_encoding.params' in sd
+    m2 = make_model(grid_scale=1.0)
+    m2.load_state_dict(sd)
+    with torch.inference_mode():
+        out2 = m2.eval().render(o, d, n, staged=True, perturb=False, num_steps=64, upsample_steps=0)
+    assert torch.equal(out['image'], out2['image'])
+
+
+def _opt(feature_loss=True):
+    return Namespace(rand_pose=-1, color_space='srgb', feature_loss=feature_loss, rgb_weight=1.0, depth_weight=0.1,
+                     semantic_weight=1.0, feature_weight=0.5)
+
+
+def _trainer(model, fused, fp16=True):
+    from autolabel_amd.trainer import SimpleTrainer
+    optimizer = lambda model: torch.optim.Adam([{'name': 'encoding', 'params': list(model.encoder.parameters())},
+                                                {'name': 'net', 'params': model.network_parameters(), 'weight_decay': 1e-6}],
+                                               lr=5e-3, betas=(0.9, 0.99), eps=1e-15)
+    sched = lambda o: torch.optim.lr_scheduler.StepLR(o, gamma=0.5, step_size=1)
+    return SimpleTrainer('ngp', _opt(), model, device='cuda:0', workspace=None, optimizer=optimizer,
+                         criterion=torch.nn.MSELoss(reduction='none'), fp16=fp16, ema_decay=0.95, lr_scheduler=sched,
+                         scheduler_update_every_step=False, metrics=[], use_checkpoint='latest', fused=fused, mute=True)
+
+
+def _host_batches(n, B=512):
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import ArrayDataset
+    import random
+    scene = synthetic.make_room_scene(n_frames=6, w=64, h=48, fx=32.0, fy=32.0, cx=31.5, cy=23.5, feat_dim=16, feat_hw=(6, 8),
+                                      labelled_every=2)
+    ds = ArrayDataset(scene, batch_size=B)
+    np.random.seed(0); random.seed(0)
+    return ds, [ds._next_train() for _ in range(n)]
+
+
+def test_generic_and_fused_training_steps_agree():
+    """Reference-shaped loop (render -> torch loss -> GradScaler -> torch Adam) vs the fused engine, same batches."""
+    ds, batches = _host_batches(3)
+    bound = float(((ds.max_bounds - ds.min_bounds) - (ds.min_bounds + ds.max_bounds) * 0.5).max())
+    finals = []
+    for fused in (False, True):
+        torch.manual_seed(0)
+        model = make_model(D=64, C_=7, bound=bound, grid_scale=1.0)
+        tr = _trainer(model, fused)
+        assert tr.fused == fused
+        tr.train_iterations(iter(batches), 3)
+        finals.append(torch.cat([p.detach().reshape(-1).cpu() for _, p in model._param_blocks()]))
+        assert tr.optimizer.param_groups[0]['lr'] == 2.5e-3  # StepLR stepped once after the 3 iterations
+    a, b = finals
+    n_grid = model._layout.n_grid
+    moved = (b[:n_grid] - make_model(D=64, C_=7, bound=bound, grid_scale=1.0).encoder.grid_encoding.params.detach().cpu()).abs() > 0
+    assert moved.sum() > 1000
+    # Adam normalises the step size: compare the updates. fp16 gradient paths are identical kernels in both modes;
+    # differences come from torch's GradScaler/Adam op order only.
+    assert (a[n_grid:] - b[n_grid:]).abs().max() < 2e-3
+    assert ((a[:n_grid] - b[:n_grid]).abs() > 2e-3).float().mean() < 1e-3
+
+
+def test_training_reduces_loss_on_cube_scene():
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    scene = synthetic.make_cube_scene()
+    frames = DeviceFrames.from_scene(scene, 'cuda')
+    model = make_model(D=64, C_=3, bound=2.0, grid_scale=1.0)
+    eng = TrainEngine(model._ensure_device(), num_steps=64, upsample_steps=64)
+    batch = frames.alloc_batch(2048)
+    losses = []
+    for i in range(300):
+        frames.next_train(batch, seed=1, step=i)
+        eng.step(batch, seed=2, step=i)
+        if i % 50 == 0 or i == 299:
+            losses.append(eng.terms.tolist())
+    assert all(math.isfinite(v) for t in losses for v in t)
+    assert losses[-1][0] < 0.25 * losses[0][0], f'rgb loss did not drop: {losses[0]} -> {losses[-1]}'
+    assert losses[-1][1] < 0.5 * losses[0][1], 'depth loss did not drop'
+    # rendering a training view reproduces it
+    t = frames.get_test(0)
+    with torch.inference_mode():
+        out = model.eval().render(t['rays_o'], t['rays_d'], t['direction_norms'], staged=True, perturb=False, num_steps=128, upsample_steps=0)
+    psnr = -10 * math.log10(((out['image'] - t['pixels']) ** 2).mean().item())
+    assert psnr > 15.0, psnr
+
+
+def test_scripts_train_export_on_written_scene(tmp_path):
+    """scripts/train.py -> checkpoint + params.pkl -> scripts/export.py on a scene directory in the reference's layout."""
+    from autolabel_amd import synthetic
+    from autolabel_amd.utils import write_scene
+    scene_dir = str(tmp_path / 'scene1')
+    write_scene(synthetic.make_cube_scene(n_frames=6), scene_dir)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train.py'), scene_dir, '--iters', '1000', '--batch-size', '1024',
+                        '--factor-train', '1', '--workers', '0', '--eval', '--factor-test', '1'], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mdir = os.path.join(scene_dir, 'nerf', 'g15_hg+freq_plain_rgb1.0_d0.1_s1.0_f0.5')
+    assert os.path.exists(os.path.join(mdir, 'params.pkl')) and os.listdir(os.path.join(mdir, 'checkpoints'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'export.py'), scene_dir], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = sorted(os.listdir(os.path.join(scene_dir, 'output', 'semantic')))
+    assert len(outs) == 6
