@@ -23,7 +23,7 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays_o, rays_d, norms, cfg, *params):
         pipe = model._pipe
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        train = any(ctx.needs_input_grad[5:])  # (grad mode is off inside Function.forward)
         out, c = pipe.forward(rays_o, rays_d, norms, cfg['num_steps'], cfg['upsample_steps'], cfg['perturb'], train=train,
                               seed=cfg['seed'], step=cfg['step'], noise=cfg.get('noise'), u=cfg.get('u'), bg=cfg['bg'])
         ctx.model, ctx.c = model, (c if train else None)

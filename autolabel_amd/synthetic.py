@@ -132,7 +132,7 @@ def make_cube_scene(n_frames=12, size=32, seed=0, device='cpu'):
         a = 2 * math.pi * i / n_frames
         eye = torch.tensor([2.5 * math.cos(a), 2.5 * math.sin(a), 0.8], dtype=torch.float64)
         T_CWs.append(_look_at(eye, torch.zeros(3, dtype=torch.float64), up))
-    room = ([-4.0, -4.0, -4.0], [4.0, 4.0, 4.0])
+    room = ([-3.0, -3.0, -3.0], [3.0, 3.0, 3.0])  # cameras (radius 2.5) sit inside the room; bbox = room
     half = torch.tensor([0.5, 0.5, 0.5], dtype=torch.float64)
     boxes = [(-half, half, 2.0)]
     images, depths, sems_full = _render_frames(T_CWs, size, size, f, f, size / 2 - 0.5, size / 2 - 0.5, room, boxes, device, 0.0, gen)
@@ -140,7 +140,7 @@ def make_cube_scene(n_frames=12, size=32, seed=0, device='cpu'):
     sems[:2] = sems_full[:2]
     return dict(images=images, depths=depths, semantics=sems, semantics_full=sems_full, T_CW=torch.stack(T_CWs).numpy(),
                 w=size, h=size, intrinsics=(f, f, size / 2 - 0.5, size / 2 - 0.5), n_classes=3,
-                min_bounds=np.array([-1.0, -1.0, -1.0]), max_bounds=np.array([1.0, 1.0, 1.0]))
+                min_bounds=np.array(room[0]), max_bounds=np.array(room[1]))
 
 
 def subsample(scene, factor):
