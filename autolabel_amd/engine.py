@@ -64,13 +64,9 @@ class TrainEngine:
 
     def all_reduce_grads(self):
         """One collective for every gradient (flat buffer) + the overflow flag riding in its tail."""
-        if self.world == 1:
-            return
-        n = self.L.n_total
-        self.P.grad[n] = self.state_i[2].float()
-        torch.distributed.all_reduce(self.P.grad, op=torch.distributed.ReduceOp.AVG, group=self.pg)
-        self.state_i[2] = (self.P.grad[n] > 0).int()
-        self.P.grad[n] = 0
+        if self.world > 1:
+            from .parallel import allreduce_gradients
+            allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg)
 
     def optimizer_step(self):
         P, L, sc = self.P, self.L, self.scaler_cfg
