@@ -135,6 +135,7 @@ class HipPipeline:
         self.ws = Workspace(params.device)
         self.density_scale, self.min_near = float(density_scale), float(min_near)
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
+        self.kernel_events = None  # bench.py: list of (start, end) HIP events around the dominant kernel's launches
 
     # ---- point queries (models.py:175-188, 190-220, 248-256)
     def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train):
@@ -264,7 +265,11 @@ class HipPipeline:
         H.call('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), H.ptr(c['h1']), H.ptr(c['h2']), H.ptr(d_sout), M, None,
                H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream())
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
-        H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M1, S1, H.ptr(d_enc), H.ptr(P.grad), H.stream())
-        if S2 > 0:
-            H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, N * S2, S2, H.ptr(d_enc[M1:]),
-                   H.ptr(P.grad), H.stream())
+        for (zz, rows, stride, de) in [(z, M1, S1, d_enc)] + ([(z[M1:], N * S2, S2, d_enc[M1:])] if S2 > 0 else []):
+            if self.kernel_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de), H.ptr(P.grad), H.stream())
+            if self.kernel_events is not None:
+                ev[1].record()
+                self.kernel_events.append((ev, rows))

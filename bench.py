@@ -111,11 +111,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
+    eng.pipe.kernel_events = []  # HIP events around every launch of the dominant kernel, on the launch stream
     t0 = time.time()
     for i in range(args.steps):
         step(args.warmup + i)
     sync()
     dt = time.time() - t0
+    events, eng.pipe.kernel_events = eng.pipe.kernel_events, None
     if world > 1:
         t = torch.tensor([dt], device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -154,6 +156,20 @@ def main():
             'render_Mrays_per_s': render_mrays,
             'loss_terms_last_step': {'rgb': terms[0], 'depth': terms[1], 'feature': terms[2], 'semantic': terms[3], 'total': terms[4]},
         }
+        # roofline of the dominant kernel (k_encode_bwd: hash-grid gradient scatter, HBM/atomic bound).
+        # algorithmic bytes per sample row: 16 levels x 8 corners x 2 features x 4 B fp32 RMW counted once
+        # + the d_enc row (enc_pad x 2 B) + z (4 B).
+        L = eng.L
+        per_row = L.enc.grid.n_levels * 8 * 2 * 4 + L.enc.enc_pad * 2 + 4
+        durs = [e[0].elapsed_time(e[1]) * 1e-3 for e, _ in events]
+        rows = [r for _, r in events]
+        avg_s = sum(durs) / len(durs)
+        achieved = per_row * (sum(rows) / len(rows)) / avg_s / 1e9
+        res['roofline'] = {'kernel': 'k_encode_bwd', 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                           'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
+                           'algorithmic_bytes_per_launch': per_row * (sum(rows) / len(rows)),
+                           'note': 'scatter of 2x fp32 atomics per corner: bound by the atomic request rate (~21 G sector '
+                                   'requests/s measured, scripts/dev/probe_atomics3.hip), not by HBM bytes'}
         if not args.no_cpu_baseline and world == 1:
             lo, hi = scene['min_bounds'], scene['max_bounds']
             v, sample = cpu_baseline(None, args.feature_dim, scene['n_classes'], float(((hi - lo) - (lo + hi) * 0.5).max()))
