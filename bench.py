@@ -54,11 +54,21 @@ def build(args, device, rank, world):
     return scene, full, train, eng, (rank * per, (rank + 1) * per if rank < world - 1 else args.frames)
 
 
-def cpu_baseline(scene_small, feature_dim, n_classes, bound, B=256, steps=2):
-    """The CPU oracle (pure PyTorch fp32, all host threads) on a bounded sample of the same workload."""
+def host_threads():
+    """Cores this process may use (cgroup/affinity aware), capped: torch CPU ops on tiny tensors collapse when
+    oversubscribed (256 threads on the GPU box ran 25x slower than 8)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count()
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(scene_small, feature_dim, n_classes, bound, B=128, steps=2):
+    """The CPU oracle (pure PyTorch fp32) on a bounded sample of the same workload."""
     import numpy as np
     from oracle import nerf_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(host_threads())
     cfg = O.ModelConfig(feature_dim=feature_dim, n_classes=n_classes, bound=bound)
     m = O.OracleModel(cfg, seed=0)
     st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in m.params.items()}
@@ -173,7 +183,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             lo, hi = scene['min_bounds'], scene['max_bounds']
             v, sample = cpu_baseline(None, args.feature_dim, scene['n_classes'], float(((hi - lo) - (lo + hi) * 0.5).max()))
-            res['cpu_baseline'] = {'value': v, 'unit': 'rays/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': sample}
+            res['cpu_baseline'] = {'value': v, 'unit': 'rays/s', 'cores': host_threads(), 'kind': 'port', 'sample': sample}
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
