@@ -100,7 +100,7 @@ extern "C" int aln_loss_fwd_bwd(const float* image, const float* depth, const fl
   ALN_CHECK_LAUNCH("loss_counts");
   LossArgs a{image, depth, semantic, features, gt_rgb, gt_depth, gt_sem, gt_feat, N, C, D, Cf, w_rgb, w_depth, w_sem, w_feat,
              counts, loss_scale, g_image, g_depth, g_sem, g_feat, terms};
-  hipLaunchKernelGGL(k_loss, dim3(N < 2048 ? N : 2048), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_loss, dim3(N < 128 ? N : 128), dim3(64), 0, s, a);  // few blocks: the 5 loss-term atomics are same-address
   ALN_CHECK_LAUNCH("loss");
   return 0;
 }

@@ -345,18 +345,18 @@ __global__ __launch_bounds__(256) void k_dw_gemm(const h16* __restrict__ dA, int
 // block; lane i receives feature i of 4 consecutive samples -- semantics verified by scripts/dev/probe_trread.hip).
 // dW accumulators live in registers for the whole kernel (each wave owns a fixed subset of 32x32 C-blocks) and are flushed
 // once at the end: no per-layer dA round trip through HBM and no separate dW GEMM launches.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4v* lds_s16x4_ptr;
 __device__ inline h16x8 tr_frag(const h16* tile, int pitch, int col0, int ks, int lane) {
-  // operand fragment for mfma 32x32x16: lane (i = lane&31, hf = lane>>5) gets tile[16ks + 8hf + 0..7][col0 + i]
+  // operand fragment for mfma 32x32x16: lane (i = lane&31, hf = lane>>5) gets tile[16ks + 8hf + 0..7][col0 + i].
+  // (the builtin lets the compiler count lgkmcnt itself, so several fragment reads stay in flight)
   const int hf = lane >> 5;
   const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
   const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  uint32_t a0 = (uint32_t)(uintptr_t)(tile + (size_t)row * pitch + col);
-  uint32_t a1 = (uint32_t)(uintptr_t)(tile + (size_t)(row + 4) * pitch + col);
-  s16x4 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
-  union { struct { s16x4 l, h; } s; h16x8 v; } u;
+  const h16* p0 = tile + (size_t)row * pitch + col;
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 4 * (size_t)pitch));
+  union { struct { s16x4v l, h; } s; h16x8 v; } u;
   u.s.l = lo; u.s.h = hi;
   return u.v;
 }
@@ -376,7 +376,7 @@ __device__ inline void load_tile(h16* tile, int pitch, const h16* g, int ncols, 
 template <int NBLK, int NOB, int NIB>
 __device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], const h16* tA, int pA, const h16* tB, int pB, int wave, int lane) {
   constexpr bool IB_CONST = (4 % NIB) == 0;
-#pragma unroll 1
+#pragma unroll 2
   for (int ks = 0; ks < 128 / 16; ++ks) {
     h16x8 bc;
     if (IB_CONST) bc = tr_frag(tB, pB, 32 * (wave % NIB), ks, lane);

@@ -317,21 +317,35 @@ __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
       float r = (1.f - p.wsum[ray]) * p.bg;
       p.image[3 * (size_t)ray] = c0 + r; p.image[3 * (size_t)ray + 1] = c1 + r; p.image[3 * (size_t)ray + 2] = c2 + r;
     }
-    // channel-parallel sums: lane = channel, sequential over samples (coalesced row reads)
+    // channel-parallel sums: lane = channel, samples in groups of 8 independent loads (coalesced row reads)
     if (p.logits) {
       for (int c = lane; c < p.C; c += 64) {
         float acc = 0.f;
-        for (int k = 0; k < S; ++k) {
-          size_t row = row_of(ray, k, p.N, p.S1, p.S2);
-          acc += p.w_row[row] * (float)p.logits[row * p.Cpad + c];
+        for (int k0 = 0; k0 < S; k0 += 8) {
+          float w8[8], v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            int k = k0 + j; bool ok = k < S;
+            size_t row = row_of(ray, ok ? k : 0, p.N, p.S1, p.S2);
+            w8[j] = ok ? p.w_row[row] : 0.f; v8[j] = (float)p.logits[row * p.Cpad + c];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += w8[j] * v8[j];
         }
         p.semantic[(size_t)ray * p.C + c] = acc;
       }
       for (int d = lane; d < p.D; d += 64) {
         float acc = 0.f;
-        for (int k = 0; k < S; ++k) {
-          size_t row = row_of(ray, k, p.N, p.S1, p.S2);
-          acc += p.w_row[row] * (float)p.feat[row * p.D + d];
+        for (int k0 = 0; k0 < S; k0 += 8) {
+          float w8[8], v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            int k = k0 + j; bool ok = k < S;
+            size_t row = row_of(ray, ok ? k : 0, p.N, p.S1, p.S2);
+            w8[j] = ok ? p.w_row[row] : 0.f; v8[j] = (float)p.feat[row * p.D + d];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += w8[j] * v8[j];
         }
         p.features[(size_t)ray * p.D + d] = acc;
       }
