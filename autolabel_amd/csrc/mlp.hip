@@ -49,6 +49,20 @@ extern "C" int64_t aln_mlp_frag_halves(int32_t in_pad, int32_t hidden, int32_t o
   return (int64_t)frags * 512;
 }
 
+// row-major fp16 copy W_l[out][in + 8] (pitch padded by 8 halves): read straight for forward fragments and through
+// ds_read_b64_tr_b16 for the transposed (backward) fragments -- one LDS image serves both directions.
+__host__ __device__ inline size_t wrow_off(const MlpLayers& L, int l) {
+  size_t o = 0; for (int i = 0; i < l; ++i) o += (size_t)L.out_[i] * (L.in_[i] + 8); return o;
+}
+__global__ void k_mlp_rowmajor(const float* __restrict__ w, MlpLayers L, h16* __restrict__ wr) {
+  size_t total = wrow_off(L, L.n);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int l = 0; while (l + 1 < L.n && i >= wrow_off(L, l + 1)) ++l;
+    size_t e = i - wrow_off(L, l); int pitch = L.in_[l] + 8; int o = (int)(e / pitch), k = (int)(e % pitch);
+    wr[i] = (h16)(k < L.in_[l] ? w[L.w_off[l] + (size_t)o * L.in_[l] + k] : 0.f);
+  }
+}
+
 __global__ void k_mlp_repack(const float* __restrict__ w, MlpLayers L, h16* __restrict__ wf, h16* __restrict__ wb) {
   // one thread per (frag, lane, j)
   size_t nf = fwd_frag_off(L, L.n) * 512, nb = bwd_frag_off(L, -1) * 512;
@@ -74,14 +88,23 @@ __global__ void k_mlp_repack(const float* __restrict__ w, MlpLayers L, h16* __re
   }
 }
 
+extern "C" int64_t aln_mlp_rowmajor_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden) {
+  MlpLayers L = mlp_layers(in_pad, hidden, out_pad, n_hidden);
+  return (int64_t)wrow_off(L, L.n);
+}
+
 extern "C" int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
-                              void* wf, void* wb, void* stream) {
+                              void* wf, void* wb, void* wr, void* stream) {
   ALN_REQUIRE(w_master && wf && wb, "mlp_repack: NULL pointer");
   ALN_REQUIRE(in_pad % 16 == 0 && out_pad % 16 == 0 && (hidden == 64 || hidden == 128) && (n_hidden == 1 || n_hidden == 2),
               "mlp_repack: unsupported shape in=%d hid=%d out=%d nh=%d", in_pad, hidden, out_pad, n_hidden);
   MlpLayers L = mlp_layers(in_pad, hidden, out_pad, n_hidden);
   hipLaunchKernelGGL(k_mlp_repack, dim3(64), dim3(256), 0, (hipStream_t)stream, w_master, L, (h16*)wf, (h16*)wb);
   ALN_CHECK_LAUNCH("mlp_repack");
+  if (wr) {
+    hipLaunchKernelGGL(k_mlp_rowmajor, dim3(32), dim3(256), 0, (hipStream_t)stream, w_master, L, (h16*)wr);
+    ALN_CHECK_LAUNCH("mlp_rowmajor");
+  }
   return 0;
 }
 
@@ -535,6 +558,209 @@ static int launch_bwd_fused(const AlnMlpDesc* m, const void* x, const void* h1, 
   return 0;
 }
 
+// ---------------------------------------------------------------- fused backward WITH forward recompute
+// Nothing but the layer input x and dL/dout is read from HBM: the hidden activations are recomputed in registers
+// (forward chain) and parked in LDS only as operands of the weight-gradient MFMAs.  HBM traffic per sample drops from
+// 2*HID*NHID + IN + OUT halves read to IN + OUT (sigma head: 770 -> 224 B), which turns the kernel from latency/HBM bound
+// into MFMA bound.  Weights live in LDS ONCE, row-major: forward fragments are plain reads, transposed (backward)
+// fragments come from ds_read_b64_tr_b16.
+__device__ inline h16x8 tr_frag_chained(const h16* tile, int pitch, int col0, int ks, int lane) {
+  // as tr_frag, but the 8 rows follow the chained k-order of the register chain: base + 8*(j>>2) + 4*hf + (j&3)
+  const int hf = lane >> 5;
+  const int row = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * hf + ((lane & 15) >> 2);
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const h16* p0 = tile + (size_t)row * pitch + col;
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * (size_t)pitch));
+  union { struct { s16x4v l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+// forward A fragment (lane: output feature n = row, 8 input features) from the row-major weights
+__device__ inline h16x8 fwd_frag_natural(const h16* W, int pitch, int mb, int ks, int lane) {
+  return *(const h16x8*)(W + (size_t)(32 * mb + (lane & 31)) * pitch + 16 * ks + 8 * (lane >> 5));
+}
+__device__ inline h16x8 fwd_frag_chained(const h16* W, int pitch, int mb, int ks, int lane) {
+  const h16* p0 = W + (size_t)(32 * mb + (lane & 31)) * pitch + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (lane >> 5);
+  h16x4 a = *(const h16x4*)p0, b = *(const h16x4*)(p0 + 8);
+  h16x8 r; r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+template <int NB>
+__device__ inline void write_packed_tile(h16* tile, int pitch, int srow, const h16x8 (&p)[2 * NB], int hf) {
+#pragma unroll
+  for (int m = 0; m < NB; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
+      v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
+      *(h16x4*)(tile + (size_t)srow * pitch + 32 * m + 8 * q + 4 * hf) = v;
+    }
+}
+// relu'(h) mask taken from the packed forward activations (registers) instead of a saved tensor
+template <int NB>
+__device__ inline bool mask_pack_regs(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const h16x8 (&hact)[2 * NB]) {
+  bool bad = false;
+#pragma unroll
+  for (int m = 0; m < NB; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float g = ((float)hact[2 * m + (r >> 3)][r & 7] > 0.f) ? acc[m][r] : 0.f;
+      h16 gh = (h16)g;
+      bad |= !(fabsf((float)gh) <= 65504.f);
+      p[2 * m + (r >> 3)][r & 7] = gh;
+    }
+  return bad;
+}
+
+template <int IN, int HID, int OUT, int NHID>
+__global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ wr_g, size_t wr_halves, const h16* __restrict__ x,
+                                                       const h16* __restrict__ d_out, int rows, const int* __restrict__ rows_dev,
+                                                       h16* __restrict__ d_in, float* __restrict__ dW, int* __restrict__ found_inf) {
+  constexpr int NB = HID / 32, KS = HID / 16, KS0 = IN / 16, KSO = OUT / 16, IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
+  constexpr int PW0 = IN + 8, PW1 = HID + 8;                       // weight pitches
+  constexpr int PH = HID + 8, PX0 = IB * 32 + 8, PO = OB * 32 + 8;  // tile pitches
+  constexpr int TR = 128;
+  constexpr int NBLK_LAST = (OB * NB + 3) / 4, NBLK_MID = (NB * NB + 3) / 4, NBLK_FIRST = (NB * IB + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* wl = (h16*)smem;
+  h16* W0 = wl;                                    // [HID][IN+8]
+  h16* W1 = W0 + (size_t)HID * PW0;                // [HID][HID+8]   (NHID == 2)
+  h16* WL = (NHID == 2) ? W1 + (size_t)HID * PW1 : W1;   // [OUT][HID+8]
+  h16* tX0 = wl + ((wr_halves + 7) & ~(size_t)7);  // x tile        [TR][PX0]
+  h16* b1 = tX0 + TR * PX0;                        // h1            [TR][PH]
+  h16* b2 = b1 + TR * PH;                          // h2 / dA tiles [TR][PH]
+  h16* tO = b2 + TR * PH;                          // dOut tile     [TR][PO]
+  copy_to_lds(wl, wr_g, wr_halves);
+  for (int i = threadIdx.x; i < TR * (PX0 + PO); i += 256) { if (i < TR * PX0) tX0[i] = (h16)0.f; else tO[i - TR * PX0] = (h16)0.f; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
+  if (rows_dev) rows = min(rows, *rows_dev);
+  MlpLayers L = mlp_layers(IN, HID, OUT, NHID);
+  f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
+  zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
+  bool bad = false;
+  const int ntiles = (rows + TR - 1) / TR;
+  const int srow = wave * 32 + c;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * TR;
+    __syncthreads();
+    load_tile(tX0, PX0, x, IN, r0, TR, rows);
+    load_tile(tO, PO, d_out, OUT, r0, TR, rows);
+    __syncthreads();
+    // ---------------- forward recompute: h1 (and h2) in registers, parked in LDS for the dW MFMAs
+    f32x16 acc[NB];
+    zero_acc(acc);
+#pragma unroll
+    for (int ks = 0; ks < KS0; ++ks) {
+      h16x8 bfr = *(const h16x8*)(tX0 + (size_t)srow * PX0 + 16 * ks + 8 * hf);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma16(fwd_frag_natural(W0, PW0, m, ks, lane), bfr, acc[m]);
+    }
+    h16x8 ph1[KS], ph2[KS];
+    relu_pack_store<NB>(acc, ph1, nullptr, hf);
+    write_packed_tile<NB>(b1, PH, srow, ph1, hf);
+    if constexpr (NHID == 2) {
+      zero_acc(acc);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = mfma16(fwd_frag_chained(W1, PW1, m, ks, lane), ph1[ks], acc[m]);
+      relu_pack_store<NB>(acc, ph2, nullptr, hf);
+      write_packed_tile<NB>(b2, PH, srow, ph2, hf);
+    }
+    __syncthreads();
+    // ---------------- last layer: dW_last += dOut^T . h_last ; dA_last = relu'(h_last) * (W_last^T dOut)
+    dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, (NHID == 2) ? b2 : b1, PH, wave, lane);
+    zero_acc(acc);
+#pragma unroll
+    for (int ks = 0; ks < KSO; ++ks) {
+      h16x8 bfr = *(const h16x8*)(tO + (size_t)srow * PO + 16 * ks + 8 * hf);
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma16(tr_frag(WL, PW1, 32 * m, ks, lane), bfr, acc[m]);
+    }
+    h16x8 p[KS];
+    if constexpr (NHID == 2) {
+      bad |= mask_pack_regs<NB>(acc, p, ph2);
+      __syncthreads();                                   // dW_last readers are done with b2 (= h2)
+      write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA2
+      __syncthreads();
+      dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, wave, lane);
+      zero_acc(acc);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc[m] = mfma16(tr_frag_chained(W1, PW1, 32 * m, ks, lane), p[ks], acc[m]);
+      bad |= mask_pack_regs<NB>(acc, p, ph1);
+      __syncthreads();                                   // dW_mid readers are done with b2 / b1
+      write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1
+    } else {
+      bad |= mask_pack_regs<NB>(acc, p, ph1);
+      write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1 (b2 unused so far)
+    }
+    __syncthreads();
+    dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, b2, PH, tX0, PX0, wave, lane);
+    if (d_in) {
+      const int row = r0 + srow;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) o = mfma16(tr_frag_chained(W0, PW0, 32 * ib, ks, lane), p[ks], o);
+        if (row < rows) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int f = 32 * ib + 8 * q + 4 * hf;
+            if (f < IN) {
+              h16x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[r] = (h16)o[4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
+              *(h16x4*)(d_in + (size_t)row * IN + f) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+  auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, float* base) {
+    const int i = 32 * ib + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      if (o < OUTL && i < INL && a[r] != 0.f) unsafeAtomicAdd(base + (size_t)o * INL + i, a[r]);
+    }
+  };
+  if (dW) {
+#pragma unroll
+    for (int b = 0; b < NBLK_LAST; ++b) { int blk = wave + 4 * b; if (blk < OB * NB) flush(dw_last[b], blk / NB, blk % NB, OUT, HID, dW + L.w_off[L.n - 1]); }
+    if (NHID == 2) {
+#pragma unroll
+      for (int b = 0; b < NBLK_MID; ++b) { int blk = wave + 4 * b; if (blk < NB * NB) flush(dw_mid[b], blk / NB, blk % NB, HID, HID, dW + L.w_off[1]); }
+    }
+#pragma unroll
+    for (int b = 0; b < NBLK_FIRST; ++b) { int blk = wave + 4 * b; if (blk < NB * IB) flush(dw_first[b], blk / IB, blk % IB, HID, IN, dW + L.w_off[0]); }
+  }
+  if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
+}
+
+template <int IN, int HID, int OUT, int NHID>
+static int launch_bwd_recomp(const AlnMlpDesc* m, const void* x, const void* d_out, int rows, const int* rows_dev, void* d_in,
+                             float* dW, int* found_inf, hipStream_t s) {
+  constexpr int IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
+  constexpr int PH = HID + 8, PX0 = IB * 32 + 8, PO = OB * 32 + 8;
+  size_t halves = (size_t)aln_mlp_rowmajor_halves(IN, HID, OUT, NHID);
+  size_t lds = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(PX0 + 2 * PH + PO)) * 2;
+  ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_recomp: LDS %zu B exceeds 160 KiB", lds);
+  int tiles = (rows + 127) / 128;
+  int g = tiles < 256 ? tiles : 256;
+  hipFuncSetAttribute((const void*)k_mlp_bwd_recomp<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_mlp_bwd_recomp<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wr, halves, (const h16*)x,
+                     (const h16*)d_out, rows, rows_dev, (h16*)d_in, dW, found_inf);
+  ALN_CHECK_LAUNCH("mlp_bwd_recomp");
+  return 0;
+}
+
 // ---------------------------------------------------------------- launchers
 static int mlp_grid(int rows) {
   int tiles = (rows + 127) / 128;
@@ -582,7 +808,19 @@ static int launch_dw(const h16* dA, int OW, const h16* X, int IW, int rows, cons
 extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out,
                            int32_t rows, const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW,
                            int32_t* found_inf, void* stream) {
-  ALN_REQUIRE(m && d_out && h1 && m->wb, "mlp_bwd: NULL pointer");
+  ALN_REQUIRE(m && d_out && m->wb, "mlp_bwd: NULL pointer");
+  if (!h1) {  // no saved activations: recompute them inside the fused kernel
+    ALN_REQUIRE(x && m->wr, "mlp_bwd: recompute path needs x and the row-major weight copy (wr)");
+    if (rows <= 0) return 0;
+#define TRYR(I, H, O, N)                                                                                  \
+    if (m->in_pad == I && m->hidden == H && m->out_pad == O && m->n_hidden == N)                          \
+      return launch_bwd_recomp<I, H, O, N>(m, x, d_out, rows, rows_dev, d_in, dW, found_inf, (hipStream_t)stream);
+    TRYR(48, 128, 16, 2) TRYR(32, 128, 16, 2) TRYR(64, 128, 16, 2) TRYR(16, 64, 64, 2) TRYR(80, 64, 16, 1) TRYR(80, 64, 32, 1)
+#undef TRYR
+    aln_set_error("mlp_bwd: no recompute kernel for in=%d hid=%d out=%d nh=%d (pass saved activations)", m->in_pad, m->hidden,
+                  m->out_pad, m->n_hidden);
+    return -1;
+  }
   ALN_REQUIRE(m->n_hidden == 1 || h2, "mlp_bwd: h2 required for 2 hidden layers");
   ALN_REQUIRE(!dW || (x && dA1 && (m->n_hidden == 1 || dA2)), "mlp_bwd: dW needs x, dA1, dA2 buffers");
   if (rows <= 0) return 0;

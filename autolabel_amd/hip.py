@@ -27,7 +27,7 @@ class AlnEncDesc(C.Structure):
 
 
 class AlnMlpDesc(C.Structure):
-    _fields_ = [('in_pad', i32), ('hidden', i32), ('out_pad', i32), ('n_hidden', i32), ('wf', vp), ('wb', vp)]
+    _fields_ = [('in_pad', i32), ('hidden', i32), ('out_pad', i32), ('n_hidden', i32), ('wf', vp), ('wb', vp), ('wr', vp)]
 
 
 class AlnFrames(C.Structure):
@@ -51,7 +51,8 @@ _SIGS = {
     'aln_sample_fine': (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, u32, u32, vp, vp, vp]),
     'aln_encode_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'aln_encode_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
-    'aln_mlp_repack': (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
+    'aln_mlp_repack': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),
     'aln_mlp_frag_halves': (i64, [i32, i32, i32, i32, i32]),
     'aln_mlp_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),

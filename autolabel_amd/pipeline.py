@@ -70,10 +70,12 @@ class Params:
         for k, s in L.nets.items():
             nf = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 0)
             nb = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 1)
+            nr = H.lib().aln_mlp_rowmajor_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
             wf = torch.zeros(nf, dtype=torch.float16, device=device)
             wb = torch.zeros(nb, dtype=torch.float16, device=device)
-            self.frags[k] = (wf, wb)
-            self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr())
+            wr = torch.zeros((nr + 7) // 8 * 8, dtype=torch.float16, device=device)
+            self.frags[k] = (wf, wb, wr)
+            self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr())
 
     def init_(self, seed=0):
         """tcnn default initialisation: grid U(-1e-4,1e-4), MLP weights xavier-uniform per padded [out,in] matrix."""
@@ -104,9 +106,9 @@ class Params:
         if grid and L.n_grid:
             H.call('aln_cast_f16', H.ptr(self.flat), H.ptr(self.table16), L.n_grid, H.stream())
         for k, s in L.nets.items():
-            wf, wb = self.frags[k]
+            wf, wb, wr = self.frags[k]
             H.call('aln_mlp_repack', C.c_void_p(self.flat.data_ptr() + 4 * L.offsets[k]), s.in_pad, s.hidden, s.out_pad,
-                   s.n_hidden, H.ptr(wf), H.ptr(wb), H.stream())
+                   s.n_hidden, H.ptr(wf), H.ptr(wb), H.ptr(wr), H.stream())
 
 
 class Workspace:
@@ -135,6 +137,7 @@ class HipPipeline:
         self.ws = Workspace(params.device)
         self.density_scale, self.min_near = float(density_scale), float(min_near)
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
+        self.recompute = True  # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward)
         self.kernel_events = None  # bench.py: list of (start, end) HIP events around the dominant kernel's launches
 
     # ---- point queries (models.py:175-188, 190-220, 248-256)
@@ -142,8 +145,9 @@ class HipPipeline:
         e, s = self.L.enc, self.L.nets['sigma']
         H.call('aln_encode_fwd', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows,
                stride, H.ptr(enc), H.stream())
-        H.call('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, H.ptr(h1) if train else None,
-               H.ptr(h2) if train else None, H.ptr(out), H.stream())
+        save = train and not self.recompute
+        H.call('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, H.ptr(h1) if save else None,
+               H.ptr(h2) if save else None, H.ptr(out), H.stream())
         H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sigma), H.stream())
 
     def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
@@ -157,12 +161,13 @@ class HipPipeline:
         g = lambda n, shp, dt: ws.get(n, shp, dt)
         c = dict(N=N, S1=S1, S2=S2, M=M, train=train, want_semantic=want_semantic, bg=float(bg),
                  rays_o=rays_o, rays_d=rays_d, norms=norms)
+        save = train and not self.recompute
         c['nears'], c['fars'] = g('nears', (N,), f32_), g('fars', (N,), f32_)
         z = c['z'] = g('z', (M,), f32_)
         enc = c['enc'] = g('enc', (M, e.enc_pad), f16)
         hs = nets['sigma'].hidden
-        h1 = c['h1'] = g('h1', (M if train else 1, hs), f16)
-        h2 = c['h2'] = g('h2', (M if train else 1, hs), f16)
+        h1 = c['h1'] = g('h1', (M if save else 1, hs), f16)
+        h2 = c['h2'] = g('h2', (M if save else 1, hs), f16)
         sout = c['sigma_out'] = g('sigma_out', (M, 16), f16)
         sigma = c['sigma'] = g('sigma', (M,), f32_)
         H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
@@ -172,8 +177,8 @@ class HipPipeline:
             zf = z[M1:]
             H.call('aln_sample_fine', H.ptr(z), H.ptr(sigma), H.ptr(c['nears']), H.ptr(c['fars']), N, S1, S2,
                    self.density_scale, int(perturb), seed, step, H.ptr(u), H.ptr(zf), H.stream())
-            self.density_rows(N * S2, rays_o, rays_d, zf, None, S2, enc[M1:], h1[M1:] if train else h1,
-                              h2[M1:] if train else h2, sout[M1:], sigma[M1:], train)
+            self.density_rows(N * S2, rays_o, rays_d, zf, None, S2, enc[M1:], h1[M1:] if save else h1,
+                              h2[M1:] if save else h2, sout[M1:], sigma[M1:], train)
         perm = c['perm'] = g('perm', (N, S), torch.int16)
         w_row, T_row, d_row = g('w_row', (M,), f32_), g('T_row', (M,), f32_), g('delta_row', (M,), f32_)
         c.update(w_row=w_row, T_row=T_row, delta_row=d_row)
@@ -190,28 +195,28 @@ class HipPipeline:
         H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.stream())
         cs = nets['color']
         cin = c['color_in'] = g('color_in', (M, cs.in_pad), f16)
-        ch1 = c['ch1'] = g('ch1', (M if train else 1, cs.hidden), f16)
-        ch2 = c['ch2'] = g('ch2', (M if train else 1, cs.hidden), f16)
+        ch1 = c['ch1'] = g('ch1', (M if save else 1, cs.hidden), f16)
+        ch2 = c['ch2'] = g('ch2', (M if save else 1, cs.hidden), f16)
         cout = c['color_out'] = g('color_out', (M, cs.out_pad), f16)
         H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G,
                cs.in_pad, H.ptr(cin), H.stream())
-        H.call('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if train else None,
-               H.ptr(ch2) if train else None, H.ptr(cout), H.stream())
+        H.call('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if save else None,
+               H.ptr(ch2) if save else None, H.ptr(cout), H.stream())
         logits = feat = None
         if want_semantic:
             fs, os_ = nets['semf'], nets['semo']
             fin = c['semf_in'] = g('semf_in', (M, fs.in_pad), f16)
-            fh1 = c['fh1'] = g('fh1', (M if train else 1, fs.hidden), f16)
-            fh2 = c['fh2'] = g('fh2', (M if train else 1, fs.hidden), f16)
+            fh1 = c['fh1'] = g('fh1', (M if save else 1, fs.hidden), f16)
+            fh2 = c['fh2'] = g('fh2', (M if save else 1, fs.hidden), f16)
             feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
             oin = c['semo_in'] = g('semo_in', (M, os_.in_pad), f16)
-            oh1 = c['oh1'] = g('oh1', (M if train else 1, os_.hidden), f16)
+            oh1 = c['oh1'] = g('oh1', (M if save else 1, os_.hidden), f16)
             logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
             H.call('aln_build_sem_in', H.ptr(sout), None, M, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
-            H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if train else None,
-                   H.ptr(fh2) if train else None, H.ptr(feat), H.stream())
+            H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if save else None,
+                   H.ptr(fh2) if save else None, H.ptr(feat), H.stream())
             H.call('aln_build_sem_in', H.ptr(sout), H.ptr(feat), M, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
-            H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if train else None, None,
+            H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if save else None, None,
                    H.ptr(logits), H.stream())
             out['semantic'] = torch.empty((N, L.C), dtype=f32_, device=dev)
             out['semantic_features'] = torch.empty((N, L.D), dtype=f32_, device=dev)
@@ -244,25 +249,27 @@ class HipPipeline:
                H.ptr(g_depth), H.ptr(g_sem) if sem else None, H.ptr(g_feat) if sem else None, N, S1, S2, L.C, L.Cpad, L.D,
                c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), H.ptr(d_logits), H.ptr(d_feat), fi, H.stream())
         # color head
-        dA1, dA2 = g('dA1', (M, 128), f16), g('dA2', (M, 128), f16)
+        rc = self.recompute
+        hp = (lambda t: None) if rc else H.ptr   # saved activations are not passed on the recompute path
+        dA1, dA2 = (None, None) if rc else (g('dA1', (M, 128), f16), g('dA2', (M, 128), f16))
         d_cin = g('d_color_in', (M, cs.in_pad), f16)
-        H.call('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), H.ptr(c['ch1']), H.ptr(c['ch2']), H.ptr(d_cout),
+        H.call('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), hp(c['ch1']), hp(c['ch2']), H.ptr(d_cout),
                M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream())
         d_fin = d_oin = None
         if sem:
             fs, os_ = nets['semf'], nets['semo']
             d_oin = g('d_semo_in', (M, os_.in_pad), f16)
-            H.call('aln_mlp_bwd', C.byref(P.descs['semo']), H.ptr(c['semo_in']), H.ptr(c['oh1']), None, H.ptr(d_logits), M, None,
+            H.call('aln_mlp_bwd', C.byref(P.descs['semo']), H.ptr(c['semo_in']), hp(c['oh1']), None, H.ptr(d_logits), M, None,
                    H.ptr(dA1), None, H.ptr(d_oin), gp('semo'), fi, H.stream())
             H.call('aln_assemble_dsemf_out', H.ptr(d_feat), H.ptr(c['feat']), H.ptr(d_oin), M, L.D, os_.in_pad, fi, H.stream())
             d_fin = g('d_semf_in', (M, fs.in_pad), f16)
-            H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), H.ptr(c['fh1']), H.ptr(c['fh2']), H.ptr(d_feat), M,
+            H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
                    None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
         d_sout = g('d_sigma_out', (M, 16), f16)
         H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), nets['semo'].in_pad, L.D,
                H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
         d_enc = g('d_enc', (M, e.enc_pad), f16)
-        H.call('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), H.ptr(c['h1']), H.ptr(c['h2']), H.ptr(d_sout), M, None,
+        H.call('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
                H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream())
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
         for (zz, rows, stride, de) in [(z, M1, S1, d_enc)] + ([(z[M1:], N * S2, S2, d_enc[M1:])] if S2 > 0 else []):

@@ -52,6 +52,7 @@ typedef struct {
   int32_t in_pad, hidden, out_pad, n_hidden; /* n_hidden in {1,2}; hidden in {64,128} */
   const void* wf;   /* forward fragments  */
   const void* wb;   /* backward (transposed) fragments */
+  const void* wr;   /* row-major fp16 copy, pitch in+8 (recompute backward); may be NULL */
 } AlnMlpDesc;
 
 const char* aln_last_error(void);
@@ -113,13 +114,15 @@ int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d
 
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
-                   void* wf, void* wb, void* stream);
+                   void* wf, void* wb, void* wr /*optional*/, void* stream);
 int64_t aln_mlp_frag_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden, int32_t backward);
+int64_t aln_mlp_rowmajor_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden);
 /* h1/h2: [rows,hidden] f16 saved post-ReLU activations (NULL at inference).  rows_dev (optional, device int32)
  * clamps the row count on the device (compacted live samples). */
 int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t* rows_dev, void* h1, void* h2,
                 void* out, void* stream);
-/* d_in (optional) [rows,in_pad] f16; dW (optional) += weight gradients in the fp32 master layout; dA1/dA2 are scratch
+/* h1 == NULL selects the recompute backward: hidden activations are rebuilt from x inside the kernel (needs m->wr).
+ * d_in (optional) [rows,in_pad] f16; dW (optional) += weight gradients in the fp32 master layout; dA1/dA2 are scratch
  * [rows,hidden] f16 (only touched by the unfused fallback); found_inf is OR-ed when an fp16 gradient overflows. */
 int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
                 const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW, int32_t* found_inf, void* stream);

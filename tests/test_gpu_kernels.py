@@ -223,9 +223,10 @@ def _mlp_setup(H, n_in, hid, n_out, nh, seed=0):
     nb = H.lib().aln_mlp_frag_halves(n_in, hid, n_out, nh, 1)
     wf = torch.zeros(nf, dtype=torch.float16, device='cuda')
     wb = torch.zeros(nb, dtype=torch.float16, device='cuda')
-    H.call('aln_mlp_repack', H.ptr(flat), n_in, hid, n_out, nh, H.ptr(wf), H.ptr(wb), H.stream())
-    desc = H.AlnMlpDesc(n_in, hid, n_out, nh, wf.data_ptr(), wb.data_ptr())
-    return Ws, desc, (flat, wf, wb)
+    wr = torch.zeros((H.lib().aln_mlp_rowmajor_halves(n_in, hid, n_out, nh) + 7) // 8 * 8, dtype=torch.float16, device='cuda')
+    H.call('aln_mlp_repack', H.ptr(flat), n_in, hid, n_out, nh, H.ptr(wf), H.ptr(wb), H.ptr(wr), H.stream())
+    desc = H.AlnMlpDesc(n_in, hid, n_out, nh, wf.data_ptr(), wb.data_ptr(), wr.data_ptr())
+    return Ws, desc, (flat, wf, wb, wr)
 
 
 @pytest.mark.parametrize('name,n_in,hid,n_out,nh', MLP_SHAPES)
@@ -264,6 +265,13 @@ def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh):
         got = dW[o:o + w.numel()].cpu().view_as(w)
         assert (got - w.grad).abs().max() <= 1e-2 * w.grad.abs().max().item() + 1e-4, name
         o += w.numel()
+    # recompute backward (no saved activations): same gradients from x and d_out alone
+    d_in2 = torch.zeros_like(d_in); dW2 = torch.zeros_like(dW)
+    H.call('aln_mlp_bwd', C.byref(desc), H.ptr(xd), None, None, H.ptr(dod), rows, None, None, None, H.ptr(d_in2), H.ptr(dW2),
+           H.ptr(flag), H.stream())
+    assert flag.item() == 0
+    assert (d_in2.float() - d_in.float()).abs().max().item() <= 2e-3 * gi.abs().max().item() + 1e-5, name
+    assert (dW2 - dW).abs().max().item() <= 2e-3 * dW.abs().max().item() + 1e-5, name
 
 
 def test_mlp_device_row_count_and_inf_flag(H):
