@@ -399,18 +399,27 @@ __device__ inline void load_tile(h16* tile, int pitch, const h16* g, int ncols, 
 template <int NBLK, int NOB, int NIB>
 __device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], const h16* tA, int pA, const h16* tB, int pB, int wave, int lane) {
   constexpr bool IB_CONST = (4 % NIB) == 0;
-#pragma unroll 2
-  for (int ks = 0; ks < 128 / 16; ++ks) {
-    h16x8 bc;
-    if (IB_CONST) bc = tr_frag(tB, pB, 32 * (wave % NIB), ks, lane);
+  constexpr int NBF = IB_CONST ? 1 : NBLK;
+  h16x8 a[2][NBLK], bq[2][NBF];
+  auto fetch = [&](int ks, int slot) {
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
       const int blk = wave + 4 * b;
       if (blk < NOB * NIB) {
-        h16x8 a = tr_frag(tA, pA, 32 * (blk / NIB), ks, lane);
-        h16x8 bb = IB_CONST ? bc : tr_frag(tB, pB, 32 * (blk % NIB), ks, lane);
-        dw[b] = mfma16(a, bb, dw[b]);
+        a[slot][b] = tr_frag(tA, pA, 32 * (blk / NIB), ks, lane);
+        if (!IB_CONST) bq[slot][b < NBF ? b : 0] = tr_frag(tB, pB, 32 * (blk % NIB), ks, lane);
       }
+    }
+    if (IB_CONST) bq[slot][0] = tr_frag(tB, pB, 32 * (wave % NIB), ks, lane);
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int ks = 0; ks < 128 / 16; ++ks) {
+    if (ks + 1 < 128 / 16) fetch(ks + 1, (ks + 1) & 1);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      const int blk = wave + 4 * b;
+      if (blk < NOB * NIB) dw[b] = mfma16(a[ks & 1][b], bq[ks & 1][IB_CONST ? 0 : (b < NBF ? b : 0)], dw[b]);
     }
   }
 }
@@ -558,6 +567,44 @@ static int launch_bwd_fused(const AlnMlpDesc* m, const void* x, const void* h1, 
   return 0;
 }
 
+// One layer of the register chain with software-pipelined A fragments: the NB fragments of k-step ks+1 are requested
+// before the NB MFMAs of k-step ks are issued (one wave per SIMD: nothing else hides the ~150-cycle LDS latency).
+template <int NB, int KSN, class FragFn, class BFn>
+__device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
+  h16x8 a[2][NB];
+#pragma unroll
+  for (int m = 0; m < NB; ++m) a[0][m] = frag(m, 0);
+#pragma unroll
+  for (int ks = 0; ks < KSN; ++ks) {
+    if (ks + 1 < KSN) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) a[(ks + 1) & 1][m] = frag(m, ks + 1);
+    }
+    h16x8 b = bop(ks);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b, acc[m]);
+  }
+}
+// relu'(h) mask read back from the LDS tile holding h (C-layout 8-byte chunks)
+template <int NB>
+__device__ inline bool mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const h16* act_row, int hf) {
+  bool bad = false;
+#pragma unroll
+  for (int m = 0; m < NB; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h16x4 a = *(const h16x4*)(act_row + 32 * m + 8 * q + 4 * hf);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float g = ((float)a[r] > 0.f) ? acc[m][4 * q + r] : 0.f;
+        h16 gh = (h16)g;
+        bad |= !(fabsf((float)gh) <= 65504.f);
+        p[2 * m + (q >> 1)][4 * (q & 1) + r] = gh;
+      }
+    }
+  return bad;
+}
+
 // ---------------------------------------------------------------- fused backward WITH forward recompute
 // Nothing but the layer input x and dL/dout is read from HBM: the hidden activations are recomputed in registers
 // (forward chain) and parked in LDS only as operands of the weight-gradient MFMAs.  HBM traffic per sample drops from
@@ -647,79 +694,61 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
     load_tile(tX0, PX0, x, IN, r0, TR, rows);
     load_tile(tO, PO, d_out, OUT, r0, TR, rows);
     __syncthreads();
-    // ---------------- forward recompute: h1 (and h2) in registers, parked in LDS for the dW MFMAs
+    // ---------------- forward recompute: h1 (and h2) go through registers into LDS tiles (dW operands + relu masks)
     f32x16 acc[NB];
+    h16x8 p[KS];
     zero_acc(acc);
-#pragma unroll
-    for (int ks = 0; ks < KS0; ++ks) {
-      h16x8 bfr = *(const h16x8*)(tX0 + (size_t)srow * PX0 + 16 * ks + 8 * hf);
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma16(fwd_frag_natural(W0, PW0, m, ks, lane), bfr, acc[m]);
-    }
-    h16x8 ph1[KS], ph2[KS];
-    relu_pack_store<NB>(acc, ph1, nullptr, hf);
-    write_packed_tile<NB>(b1, PH, srow, ph1, hf);
+    chain_layer<NB, KS0>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); },
+                         [&](int ks) { return *(const h16x8*)(tX0 + (size_t)srow * PX0 + 16 * ks + 8 * hf); });
+    relu_pack_store<NB>(acc, p, nullptr, hf);
+    write_packed_tile<NB>(b1, PH, srow, p, hf);
     if constexpr (NHID == 2) {
       zero_acc(acc);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int m = 0; m < NB; ++m) acc[m] = mfma16(fwd_frag_chained(W1, PW1, m, ks, lane), ph1[ks], acc[m]);
-      relu_pack_store<NB>(acc, ph2, nullptr, hf);
-      write_packed_tile<NB>(b2, PH, srow, ph2, hf);
+      chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(W1, PW1, m, ks, lane); }, [&](int ks) { return p[ks]; });
+      relu_pack_store<NB>(acc, p, nullptr, hf);
+      write_packed_tile<NB>(b2, PH, srow, p, hf);
     }
     __syncthreads();
     // ---------------- last layer: dW_last += dOut^T . h_last ; dA_last = relu'(h_last) * (W_last^T dOut)
     dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, (NHID == 2) ? b2 : b1, PH, wave, lane);
     zero_acc(acc);
-#pragma unroll
-    for (int ks = 0; ks < KSO; ++ks) {
-      h16x8 bfr = *(const h16x8*)(tO + (size_t)srow * PO + 16 * ks + 8 * hf);
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma16(tr_frag(WL, PW1, 32 * m, ks, lane), bfr, acc[m]);
-    }
-    h16x8 p[KS];
+    chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(WL, PW1, 32 * m, ks, lane); },
+                         [&](int ks) { return *(const h16x8*)(tO + (size_t)srow * PO + 16 * ks + 8 * hf); });
     if constexpr (NHID == 2) {
-      bad |= mask_pack_regs<NB>(acc, p, ph2);
+      bad |= mask_pack_lds<NB>(acc, p, b2 + (size_t)srow * PH, hf);
       __syncthreads();                                   // dW_last readers are done with b2 (= h2)
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA2
       __syncthreads();
       dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, wave, lane);
       zero_acc(acc);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int m = 0; m < NB; ++m) acc[m] = mfma16(tr_frag_chained(W1, PW1, 32 * m, ks, lane), p[ks], acc[m]);
-      bad |= mask_pack_regs<NB>(acc, p, ph1);
+      chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(W1, PW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
+      bad |= mask_pack_lds<NB>(acc, p, b1 + (size_t)srow * PH, hf);
       __syncthreads();                                   // dW_mid readers are done with b2 / b1
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1
     } else {
-      bad |= mask_pack_regs<NB>(acc, p, ph1);
+      bad |= mask_pack_lds<NB>(acc, p, b1 + (size_t)srow * PH, hf);
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1 (b2 unused so far)
     }
     __syncthreads();
     dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, b2, PH, tX0, PX0, wave, lane);
     if (d_in) {
       const int row = r0 + srow;
+      f32x16 o[IB];
+      zero_acc(o);
+      chain_layer<IB, KS>(o, [&](int ib, int ks) { return tr_frag_chained(W0, PW0, 32 * ib, ks, lane); }, [&](int ks) { return p[ks]; });
+      if (row < rows) {
 #pragma unroll
-      for (int ib = 0; ib < IB; ++ib) {
-        f32x16 o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) o = mfma16(tr_frag_chained(W0, PW0, 32 * ib, ks, lane), p[ks], o);
-        if (row < rows) {
+        for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int f = 32 * ib + 8 * q + 4 * hf;
             if (f < IN) {
               h16x4 v;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) { v[r] = (h16)o[4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
+              for (int r = 0; r < 4; ++r) { v[r] = (h16)o[ib][4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
               *(h16x4*)(d_in + (size_t)row * IN + f) = v;
             }
           }
-        }
       }
     }
   }
