@@ -98,10 +98,14 @@ def main():
     args = parse()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    backend = os.environ.get('ALN_DIST_BACKEND', 'nccl')  # 'gloo' lets two ranks share one GPU (functional test only)
+    if backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        kw = {'device_id': torch.device('cuda', local)} if backend == 'nccl' else {}
+        torch.distributed.init_process_group(backend, **kw)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     scene, full, train, eng, frange = build(args, device, rank, world)
