@@ -219,9 +219,15 @@ class ALNetwork(NeRFRenderer):
         oin = torch.empty(n, os_.in_pad, dtype=f16, device=dev)
         logits = torch.empty(n, os_.out_pad, dtype=f16, device=dev)
         H.call('aln_build_sem_in', H.ptr(so), None, n, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
-        H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semf']), H.ptr(fin), n, None, None, None, H.ptr(feat), H.stream())
+        if fs.lib:
+            feat, _ = pipe._lib_fwd('semf', fin, False)
+        else:
+            H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semf']), H.ptr(fin), n, None, None, None, H.ptr(feat), H.stream())
         H.call('aln_build_sem_in', H.ptr(so), H.ptr(feat), n, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
-        H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semo']), H.ptr(oin), n, None, None, None, H.ptr(logits), H.stream())
+        if os_.lib:
+            logits, _ = pipe._lib_fwd('semo', oin, False)
+        else:
+            H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semo']), H.ptr(oin), n, None, None, None, H.ptr(logits), H.stream())
         return logits[:, :L.C], feat[:, :L.D]
 
     @torch.no_grad()

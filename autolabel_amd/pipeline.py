@@ -28,9 +28,12 @@ class MlpSpec:
         self.in_pad, self.out_pad = pad16(n_in), pad16(n_out)
         self.shapes = [(hidden, self.in_pad)] + [(hidden, hidden)] * (n_hidden - 1) + [(self.out_pad, hidden)]
         self.n_params = sum(o * i for o, i in self.shapes)
-        if hidden not in (64, 128) or n_hidden not in (1, 2):
-            raise NotImplementedError(f'{name}: hidden={hidden}, n_hidden={n_hidden} has no HIP kernel yet '
-                                      '(supported: hidden in {64,128}, 1-2 hidden layers)')
+        if n_hidden not in (1, 2):
+            raise NotImplementedError(f'{name}: n_hidden={n_hidden} is not supported (1-2 hidden layers)')
+        # Heads too wide for the register-chained MFMA kernels (LSeg: D=512 -> semf 16->512->512->512, semo 528->64->C;
+        # or hundreds of classes) run as plain library GEMMs (hipBLASLt through torch.mm): they are ordinary large
+        # dense layers (512x512 weights do not fit LDS), exactly the case the design rules reserve for the library.
+        self.lib = hidden not in (64, 128) or self.in_pad > 96 or self.out_pad > 64
 
 
 class ModelLayout:
@@ -66,8 +69,11 @@ class Params:
         self.flat = torch.zeros(L.n_total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(L.n_total + 8, dtype=torch.float32, device=device)  # +8: side channel for DP (found_inf)
         self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
-        self.frags, self.descs = {}, {}
+        self.frags, self.descs, self.lib_w = {}, {}, {}
         for k, s in L.nets.items():
+            if s.lib:
+                self.lib_w[k] = [torch.zeros(o, i, dtype=torch.float16, device=device) for o, i in s.shapes]
+                continue
             nf = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 0)
             nb = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 1)
             nr = H.lib().aln_mlp_rowmajor_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
@@ -106,6 +112,12 @@ class Params:
         if grid and L.n_grid:
             H.call('aln_cast_f16', H.ptr(self.flat), H.ptr(self.table16), L.n_grid, H.stream())
         for k, s in L.nets.items():
+            if s.lib:
+                o = L.offsets[k]
+                for w in self.lib_w[k]:
+                    w.copy_(self.flat[o:o + w.numel()].view_as(w))
+                    o += w.numel()
+                continue
             wf, wb, wr = self.frags[k]
             H.call('aln_mlp_repack', C.c_void_p(self.flat.data_ptr() + 4 * L.offsets[k]), s.in_pad, s.hidden, s.out_pad,
                    s.n_hidden, H.ptr(wf), H.ptr(wb), H.ptr(wr), H.stream())
@@ -139,6 +151,34 @@ class HipPipeline:
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
         self.recompute = True  # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward)
         self.kernel_events = None  # bench.py: list of (start, end) HIP events around the dominant kernel's launches
+
+    # ---- library-GEMM heads (MlpSpec.lib): y = relu(x W0^T) ... ; fp16 operands, fp32 accumulate (hipBLASLt)
+    def _lib_fwd(self, k, x, save):
+        ws, h, hs = self.P.lib_w[k], x, []
+        for i, w in enumerate(ws):
+            h = h @ w.t()
+            if i + 1 < len(ws):
+                h = torch.relu_(h)
+                if save:
+                    hs.append(h)
+        return h, hs
+
+    def _lib_bwd(self, k, x, hs, d_out):
+        """Accumulates dW into the flat gradient buffer (fp32 GEMM output) and returns dL/dx [rows, in_pad] fp16."""
+        ws, L = self.P.lib_w[k], self.L
+        acts, g = [x] + hs, d_out
+        offs, o = [], L.offsets[k]
+        for w in ws:
+            offs.append(o)
+            o += w.numel()
+        for i in reversed(range(len(ws))):
+            dW = torch.mm(g.t(), acts[i], out_dtype=torch.float32)
+            self.P.grad[offs[i]:offs[i] + ws[i].numel()].add_(dW.view(-1))
+            g = g @ ws[i]
+            if i > 0:
+                g.mul_(acts[i] > 0)
+        self.found_inf.bitwise_or_((~torch.isfinite(g).all()).to(torch.int32))
+        return g
 
     # ---- point queries (models.py:175-188, 190-220, 248-256)
     def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train):
@@ -206,18 +246,26 @@ class HipPipeline:
         if want_semantic:
             fs, os_ = nets['semf'], nets['semo']
             fin = c['semf_in'] = g('semf_in', (M, fs.in_pad), f16)
-            fh1 = c['fh1'] = g('fh1', (M if save else 1, fs.hidden), f16)
-            fh2 = c['fh2'] = g('fh2', (M if save else 1, fs.hidden), f16)
-            feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
             oin = c['semo_in'] = g('semo_in', (M, os_.in_pad), f16)
-            oh1 = c['oh1'] = g('oh1', (M if save else 1, os_.hidden), f16)
-            logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
             H.call('aln_build_sem_in', H.ptr(sout), None, M, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
-            H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if save else None,
-                   H.ptr(fh2) if save else None, H.ptr(feat), H.stream())
+            if fs.lib:
+                feat, c['fhs'] = self._lib_fwd('semf', fin, train)
+                c['feat'] = feat
+            else:
+                fh1 = c['fh1'] = g('fh1', (M if save else 1, fs.hidden), f16)
+                fh2 = c['fh2'] = g('fh2', (M if save else 1, fs.hidden), f16)
+                feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
+                H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if save else None,
+                       H.ptr(fh2) if save else None, H.ptr(feat), H.stream())
             H.call('aln_build_sem_in', H.ptr(sout), H.ptr(feat), M, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
-            H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if save else None, None,
-                   H.ptr(logits), H.stream())
+            if os_.lib:
+                logits, c['ohs'] = self._lib_fwd('semo', oin, train)
+                c['logits'] = logits
+            else:
+                oh1 = c['oh1'] = g('oh1', (M if save else 1, os_.hidden), f16)
+                logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
+                H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if save else None, None,
+                       H.ptr(logits), H.stream())
             out['semantic'] = torch.empty((N, L.C), dtype=f32_, device=dev)
             out['semantic_features'] = torch.empty((N, L.D), dtype=f32_, device=dev)
         H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(logits), H.ptr(feat), H.ptr(out['weights_sum']),
@@ -258,13 +306,19 @@ class HipPipeline:
         d_fin = d_oin = None
         if sem:
             fs, os_ = nets['semf'], nets['semo']
-            d_oin = g('d_semo_in', (M, os_.in_pad), f16)
-            H.call('aln_mlp_bwd', C.byref(P.descs['semo']), H.ptr(c['semo_in']), hp(c['oh1']), None, H.ptr(d_logits), M, None,
-                   H.ptr(dA1), None, H.ptr(d_oin), gp('semo'), fi, H.stream())
+            if os_.lib:
+                d_oin = self._lib_bwd('semo', c['semo_in'], c['ohs'], d_logits)
+            else:
+                d_oin = g('d_semo_in', (M, os_.in_pad), f16)
+                H.call('aln_mlp_bwd', C.byref(P.descs['semo']), H.ptr(c['semo_in']), hp(c['oh1']), None, H.ptr(d_logits), M, None,
+                       H.ptr(dA1), None, H.ptr(d_oin), gp('semo'), fi, H.stream())
             H.call('aln_assemble_dsemf_out', H.ptr(d_feat), H.ptr(c['feat']), H.ptr(d_oin), M, L.D, os_.in_pad, fi, H.stream())
-            d_fin = g('d_semf_in', (M, fs.in_pad), f16)
-            H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
-                   None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
+            if fs.lib:
+                d_fin = self._lib_bwd('semf', c['semf_in'], c['fhs'], d_feat)
+            else:
+                d_fin = g('d_semf_in', (M, fs.in_pad), f16)
+                H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
+                       None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
         d_sout = g('d_sigma_out', (M, 16), f16)
         H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), nets['semo'].in_pad, L.D,
                H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())

@@ -167,6 +167,40 @@ def test_train_step_gradients_match_oracle_autograd():
     assert (touched_h != touched_o).float().mean().item() < 1e-3
 
 
+def test_lseg_width_heads_match_oracle():
+    """LSeg configuration (docs/vision-language.md:19, scripts/ros/node.py:166-176): 512-d feature head, many classes.
+    The wide heads run as library GEMMs; everything else is the HIP path.  Forward and gradients vs the oracle."""
+    oracle, pipe, cfg = build_pair(L=4, D=512, C_=40)
+    assert pipe.L.nets['semf'].lib and pipe.L.nets['semo'].lib and not pipe.L.nets['sigma'].lib
+    N, S1, S2, C_, D, Cf = 24, 32, 32, 40, 512, 512
+    o, d, norms = make_rays(N, seed=3)
+    g = torch.Generator().manual_seed(5)
+    noise, u = torch.rand(N, S1, generator=g), torch.rand(N, S2, generator=g)
+    batch = _batch(N, C_, Cf, seed=6)
+    od, dd, nd, nz, ud = o.cuda(), d.cuda(), norms.cuda().reshape(-1), noise.cuda(), u.cuda()
+    out, ctx = pipe.forward(od, dd, nd, S1, S2, True, train=True, noise=nz, u=ud)
+    want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=True, noise_coarse=noise, u_fine=u,
+                      z_fine_override=ctx['z'][N * S1:].view(N, S2).cpu())
+    assert (out['semantic_features'].cpu() - want['semantic_features']).abs().max() < 1e-2 * max(1.0, want['semantic_features'].abs().max().item())
+    assert (out['semantic'].cpu() - want['semantic']).abs().max() < 1e-2 * max(1.0, want['semantic'].abs().max().item())
+    loss, _ = O.loss_fn(want, batch, feature_loss=True)
+    loss.backward()
+    gw = flat_grads(oracle, cfg)
+    scale = 256.0
+    gi, gd, gs, gf, t = hip_loss(pipe, out, batch, N, C_, D, Cf, scale=scale)
+    pipe.P.grad.zero_()
+    pipe.backward(ctx, gi, gd, gs, gf)
+    torch.cuda.synchronize()
+    assert pipe.found_inf.item() == 0
+    got = pipe.P.grad[:pipe.L.n_total].cpu() / scale
+    L = pipe.L
+    for k in ['sigma', 'color', 'semf', 'semo']:
+        a = L.offsets[k]
+        b = a + L.nets[k].n_params
+        assert rel(got[a:b], gw[a:b]) < 2e-2, k
+    assert rel(got[:L.n_grid], gw[:L.n_grid]) < 2e-2
+
+
 def test_adam_step_matches_torch_adam_and_skips_on_inf():
     from autolabel_amd import hip as H
     n_grid, n = 1000, 1600
