@@ -141,10 +141,74 @@ __device__ inline void relu_pack_store(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], h1
   }
 }
 
+// ---------------------------------------------------------------- virtual input rows
+// The heads' inputs / output gradients are cheap functions of tensors that already exist (models.py:248-256 plumbing);
+// instead of materialising them ([rows,80] + [rows,64] + [rows,16] fp16 round trips through HBM) the MLP kernels build
+// each 8-feature chunk on the fly.
+enum { SRC_PLAIN = 0, SRC_SEMF_IN = 1, SRC_SEMO_IN = 2, SRC_DLOGITS = 3, SRC_DSEMF_OUT = 4 };
+struct RowSrc {
+  int mode;
+  const h16* a; int lda;      // PLAIN: x ; SEMF_IN: sigma_out (ld 16) ; SEMO_IN / DSEMF_OUT: f (ld D)
+  const h16* b; int ldb;      // SEMO_IN: sigma_out ; DSEMF_OUT: d_semo_in
+  const float* w_row; const float* g;   // DLOGITS / DSEMF_OUT: per-row weight, per-ray output gradient [N, gw]
+  int N, S1, S2, D, G, gw;
+};
+__device__ inline h16x8 geo_chunk(const h16* sigma_out, size_t row, int j0, int G) {
+  // [geo_feat (G), 1, 1, ...] features j0..j0+7 ; geo_feat[g] = sigma_out[row][1 + g]
+  const h16* r = sigma_out + row * 16;
+  uint4 lo = *(const uint4*)r, hi = *(const uint4*)(r + 8);
+  union { uint4 u[2]; h16 h[16]; } v; v.u[0] = lo; v.u[1] = hi;
+  h16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (j0 + j < G) ? v.h[1 + j0 + j < 16 ? 1 + j0 + j : 15] : (h16)1.0f;
+  return o;
+}
+__device__ inline h16x8 load_chunk8(const RowSrc& s, int row, int c0) {
+  switch (s.mode) {
+    case SRC_SEMF_IN: return geo_chunk(s.a, (size_t)row, c0, s.G);
+    case SRC_SEMO_IN: {
+      if (c0 >= s.D) return geo_chunk(s.b, (size_t)row, c0 - s.D, s.G);
+      h16x8 v = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)v[j] > 0.f ? v[j] : (h16)0.f;
+      return v;
+    }
+    case SRC_DLOGITS: case SRC_DSEMF_OUT: {
+      const int ray = row < s.N * s.S1 ? row / s.S1 : (row - s.N * s.S1) / s.S2;
+      const float w = s.w_row[row];
+      const float* g = s.g + (size_t)ray * s.gw;
+      h16x8 o;
+      if (s.mode == SRC_DLOGITS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (h16)((c0 + j < s.gw) ? w * g[c0 + j] : 0.f);
+      } else {
+        h16x8 f = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
+        h16x8 d = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (h16)(w * g[c0 + j] + ((float)f[j] > 0.f ? (float)d[j] : 0.f));
+      }
+      return o;
+    }
+    default: return *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
+  }
+}
+static RowSrc plain_src(const void* p, int ld) {
+  RowSrc s{}; s.mode = SRC_PLAIN; s.a = (const h16*)p; s.lda = ld; return s;
+}
+__device__ inline void load_tile_src(h16* tile, int pitch, const RowSrc& s, int ncols, int r0, int nrows, int limit) {
+  const int per_row = ncols / 8;
+  for (int i = threadIdx.x; i < nrows * per_row; i += 256) {
+    int r = i / per_row, k = i % per_row;
+    h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r0 + r < limit) v = load_chunk8(s, r0 + r, 8 * k);
+    *(h16x8*)(tile + (size_t)r * pitch + 8 * k) = v;
+  }
+}
+
 // ---------------------------------------------------------------- forward
 template <int HID, int NHID>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
-                                                const h16* __restrict__ x, int rows, const int* __restrict__ rows_dev,
+                                                RowSrc xs, int rows, const int* __restrict__ rows_dev,
                                                 h16* __restrict__ h1, h16* __restrict__ h2, h16* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h16* wl = (h16*)smem;
@@ -165,7 +229,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, s
     zero_acc(acc);
     for (int ks = 0; ks < KS0; ++ks) {
       h16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (valid) b = *(const h16x8*)(x + (size_t)row * in_pad + 16 * ks + 8 * hf);
+      if (valid) b = load_chunk8(xs, row, 16 * ks + 8 * hf);
 #pragma unroll
       for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KS0 + ks) * 64 + lane], b, acc[m]);
     }
@@ -661,8 +725,8 @@ __device__ inline bool mask_pack_regs(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], con
 }
 
 template <int IN, int HID, int OUT, int NHID>
-__global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ wr_g, size_t wr_halves, const h16* __restrict__ x,
-                                                       const h16* __restrict__ d_out, int rows, const int* __restrict__ rows_dev,
+__global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ wr_g, size_t wr_halves, RowSrc xs, RowSrc ds,
+                                                       int rows, const int* __restrict__ rows_dev,
                                                        h16* __restrict__ d_in, float* __restrict__ dW, int* __restrict__ found_inf) {
   constexpr int NB = HID / 32, KS = HID / 16, KS0 = IN / 16, KSO = OUT / 16, IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
   constexpr int PW0 = IN + 8, PW1 = HID + 8;                       // weight pitches
@@ -691,8 +755,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * TR;
     __syncthreads();
-    load_tile(tX0, PX0, x, IN, r0, TR, rows);
-    load_tile(tO, PO, d_out, OUT, r0, TR, rows);
+    load_tile_src(tX0, PX0, xs, IN, r0, TR, rows);
+    load_tile_src(tO, PO, ds, OUT, r0, TR, rows);
     __syncthreads();
     // ---------------- forward recompute: h1 (and h2) go through registers into LDS tiles (dW operands + relu masks)
     f32x16 acc[NB];
@@ -774,7 +838,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
 }
 
 template <int IN, int HID, int OUT, int NHID>
-static int launch_bwd_recomp(const AlnMlpDesc* m, const void* x, const void* d_out, int rows, const int* rows_dev, void* d_in,
+static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in,
                              float* dW, int* found_inf, hipStream_t s) {
   constexpr int IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
   constexpr int PH = HID + 8, PX0 = IB * 32 + 8, PO = OB * 32 + 8;
@@ -784,8 +848,8 @@ static int launch_bwd_recomp(const AlnMlpDesc* m, const void* x, const void* d_o
   int tiles = (rows + 127) / 128;
   int g = tiles < 256 ? tiles : 256;
   hipFuncSetAttribute((const void*)k_mlp_bwd_recomp<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_mlp_bwd_recomp<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wr, halves, (const h16*)x,
-                     (const h16*)d_out, rows, rows_dev, (h16*)d_in, dW, found_inf);
+  hipLaunchKernelGGL((k_mlp_bwd_recomp<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wr, halves, xs, ds,
+                     rows, rows_dev, (h16*)d_in, dW, found_inf);
   ALN_CHECK_LAUNCH("mlp_bwd_recomp");
   return 0;
 }
@@ -797,9 +861,9 @@ static int mlp_grid(int rows) {
   return g < 1 ? 1 : g;
 }
 
-extern "C" int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t* rows_dev, void* h1, void* h2,
-                           void* out, void* stream) {
-  ALN_REQUIRE(m && x && out && m->wf, "mlp_fwd: NULL pointer");
+static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32_t* rows_dev, void* h1, void* h2, void* out,
+                       void* stream) {
+  ALN_REQUIRE(m && xs.a && out && m->wf, "mlp_fwd: NULL pointer");
   ALN_REQUIRE(m->in_pad % 16 == 0 && m->out_pad % 16 == 0, "mlp_fwd: widths must be multiples of 16");
   if (rows <= 0) return 0;
   size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 0);
@@ -810,7 +874,7 @@ extern "C" int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, con
 #define LAUNCH(H, N)                                                                                                   \
   do {                                                                                                                 \
     hipFuncSetAttribute((const void*)k_mlp_fwd<H, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-    hipLaunchKernelGGL((k_mlp_fwd<H, N>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, (const h16*)x, \
+    hipLaunchKernelGGL((k_mlp_fwd<H, N>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, xs, \
                        rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out);                                                 \
   } while (0)
   if (m->hidden == 128 && m->n_hidden == 2) LAUNCH(128, 2);
@@ -821,6 +885,26 @@ extern "C" int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, con
 #undef LAUNCH
   ALN_CHECK_LAUNCH("mlp_fwd");
   return 0;
+}
+
+extern "C" int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t* rows_dev, void* h1, void* h2,
+                           void* out, void* stream) {
+  ALN_REQUIRE(m && x, "mlp_fwd: NULL pointer");
+  return mlp_fwd_src(m, plain_src(x, m->in_pad), rows, rows_dev, h1, h2, out, stream);
+}
+
+static int mlp_bwd_recomp_src(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in, float* dW,
+                              int* found_inf, hipStream_t s) {
+  ALN_REQUIRE(m && m->wr && xs.a && (ds.a || ds.g), "mlp_bwd: recompute path needs x, dL/dout and the row-major weight copy (wr)");
+  if (rows <= 0) return 0;
+#define TRYR(I, H, O, N)                                                                                  \
+  if (m->in_pad == I && m->hidden == H && m->out_pad == O && m->n_hidden == N)                            \
+    return launch_bwd_recomp<I, H, O, N>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
+  TRYR(48, 128, 16, 2) TRYR(32, 128, 16, 2) TRYR(64, 128, 16, 2) TRYR(16, 64, 64, 2) TRYR(80, 64, 16, 1) TRYR(80, 64, 32, 1)
+#undef TRYR
+  aln_set_error("mlp_bwd: no recompute kernel for in=%d hid=%d out=%d nh=%d (pass saved activations)", m->in_pad, m->hidden,
+                m->out_pad, m->n_hidden);
+  return -1;
 }
 
 static int launch_dw(const h16* dA, int OW, const h16* X, int IW, int rows, const int* rows_dev, float* dW, hipStream_t s) {
@@ -839,16 +923,9 @@ extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, c
                            int32_t* found_inf, void* stream) {
   ALN_REQUIRE(m && d_out && m->wb, "mlp_bwd: NULL pointer");
   if (!h1) {  // no saved activations: recompute them inside the fused kernel
-    ALN_REQUIRE(x && m->wr, "mlp_bwd: recompute path needs x and the row-major weight copy (wr)");
-    if (rows <= 0) return 0;
-#define TRYR(I, H, O, N)                                                                                  \
-    if (m->in_pad == I && m->hidden == H && m->out_pad == O && m->n_hidden == N)                          \
-      return launch_bwd_recomp<I, H, O, N>(m, x, d_out, rows, rows_dev, d_in, dW, found_inf, (hipStream_t)stream);
-    TRYR(48, 128, 16, 2) TRYR(32, 128, 16, 2) TRYR(64, 128, 16, 2) TRYR(16, 64, 64, 2) TRYR(80, 64, 16, 1) TRYR(80, 64, 32, 1)
-#undef TRYR
-    aln_set_error("mlp_bwd: no recompute kernel for in=%d hid=%d out=%d nh=%d (pass saved activations)", m->in_pad, m->hidden,
-                  m->out_pad, m->n_hidden);
-    return -1;
+    ALN_REQUIRE(x, "mlp_bwd: recompute path needs x");
+    return mlp_bwd_recomp_src(m, plain_src(x, m->in_pad), plain_src(d_out, m->out_pad), rows, rows_dev, d_in, dW, found_inf,
+                              (hipStream_t)stream);
   }
   ALN_REQUIRE(m->n_hidden == 1 || h2, "mlp_bwd: h2 required for 2 hidden layers");
   ALN_REQUIRE(!dW || (x && dA1 && (m->n_hidden == 1 || dA2)), "mlp_bwd: dW needs x, dA1, dA2 buffers");
@@ -891,4 +968,35 @@ extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, c
     }
   }
   return 0;
+}
+
+// ---------------------------------------------------------------- semantic heads with on-the-fly inputs / gradients
+// semantic_features(geo_feat) -> f ; semantic_out(cat[relu(f), geo_feat]) -> logits   (autolabel/models.py:248-256)
+extern "C" int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, int32_t rows, int32_t D,
+                                 int32_t G, void* feat, void* logits, void* stream) {
+  ALN_REQUIRE(semf && semo && sigma_out && feat && logits, "sem_heads_fwd: NULL pointer");
+  ALN_REQUIRE(semf->out_pad == D && semo->in_pad >= D + G + 1 && D % 8 == 0, "sem_heads_fwd: shape mismatch");
+  RowSrc a{}; a.mode = SRC_SEMF_IN; a.a = (const h16*)sigma_out; a.lda = 16; a.G = G; a.D = D;
+  if (int rc = mlp_fwd_src(semf, a, rows, nullptr, nullptr, nullptr, feat, stream)) return rc;
+  RowSrc b{}; b.mode = SRC_SEMO_IN; b.a = (const h16*)feat; b.lda = D; b.b = (const h16*)sigma_out; b.ldb = 16; b.G = G; b.D = D;
+  return mlp_fwd_src(semo, b, rows, nullptr, nullptr, nullptr, logits, stream);
+}
+
+// backward of both heads from the per-ray output gradients: dL/dlogits[row] = w_row * g_sem[ray],
+// dL/df[row] = w_row * g_feat[ray] + relu'(f) * dL/d(semo input)[row][:D].  Writes d_semo_in [rows, semo.in_pad] and
+// d_semf_in [rows, semf.in_pad] (their geo_feat columns feed the sigma head) and accumulates both heads' dW.
+extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat,
+                                 const float* w_row, const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2,
+                                 int32_t C, int32_t rows, int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf,
+                                 float* dW_semo, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(semf && semo && sigma_out && feat && w_row && g_sem && g_feat && d_semo_in && d_semf_in,
+              "sem_heads_bwd: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  RowSrc xo{}; xo.mode = SRC_SEMO_IN; xo.a = (const h16*)feat; xo.lda = D; xo.b = (const h16*)sigma_out; xo.ldb = 16; xo.G = G; xo.D = D;
+  RowSrc go{}; go.mode = SRC_DLOGITS; go.w_row = w_row; go.g = g_sem; go.gw = C; go.N = N; go.S1 = S1; go.S2 = S2 > 0 ? S2 : 1;
+  if (int rc = mlp_bwd_recomp_src(semo, xo, go, rows, nullptr, d_semo_in, dW_semo, found_inf, s)) return rc;
+  RowSrc xf{}; xf.mode = SRC_SEMF_IN; xf.a = (const h16*)sigma_out; xf.lda = 16; xf.G = G; xf.D = D;
+  RowSrc gf{}; gf.mode = SRC_DSEMF_OUT; gf.a = (const h16*)feat; gf.lda = D; gf.b = (const h16*)d_semo_in; gf.ldb = semo->in_pad;
+  gf.w_row = w_row; gf.g = g_feat; gf.gw = D; gf.N = N; gf.S1 = S1; gf.S2 = S2 > 0 ? S2 : 1;
+  return mlp_bwd_recomp_src(semf, xf, gf, rows, nullptr, d_semf_in, dW_semf, found_inf, s);
 }

@@ -420,14 +420,14 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
           h16x8 v = *(const h16x8*)(lg + c), o8;
 #pragma unroll
           for (int j = 0; j < 8; ++j) { dw += (float)v[j] * gs[c + j]; o8[j] = (h16)(w * gs[c + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
-          *(h16x8*)(dl + c) = o8;
+          if (p.d_logits) *(h16x8*)(dl + c) = o8;
         }
         const h16* ft = p.feat + row * p.D; h16* df = p.d_feat + row * p.D;
         for (int d = 0; d < p.D; d += 8) {
           h16x8 v = *(const h16x8*)(ft + d), o8;
 #pragma unroll
           for (int j = 0; j < 8; ++j) { dw += (float)v[j] * gf[d + j]; o8[j] = (h16)(w * gf[d + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
-          *(h16x8*)(df + d) = o8;
+          if (p.d_feat) *(h16x8*)(df + d) = o8;
         }
       }
       dws[k] = dw; P[k] = dw * w;
@@ -460,7 +460,7 @@ extern "C" int aln_composite_bwd(const float* norms, const float* z, const float
                                  int32_t* found_inf, void* stream) {
   ALN_REQUIRE(norms && z && sigma && perm && w_row && T_row && delta_row && cidx_row && color_out && sigma_out && g_image &&
                   g_depth && d_h0 && d_color_out, "composite_bwd: NULL pointer");
-  ALN_REQUIRE(!logits || (feat && g_sem && d_logits && d_feat), "composite_bwd: semantic buffers missing");
+  ALN_REQUIRE(!logits || (feat && g_sem), "composite_bwd: semantic buffers missing");
   ALN_REQUIRE(Cpad % 8 == 0 && D % 8 == 0, "composite_bwd: Cpad and D must be multiples of 8");
   if (N <= 0) return 0;
   CompBwd p{norms, z, sigma, perm, w_row, T_row, delta_row, cidx_row, (const h16*)color_out, (const h16*)logits,

@@ -245,27 +245,34 @@ class HipPipeline:
         logits = feat = None
         if want_semantic:
             fs, os_ = nets['semf'], nets['semo']
-            fin = c['semf_in'] = g('semf_in', (M, fs.in_pad), f16)
-            oin = c['semo_in'] = g('semo_in', (M, os_.in_pad), f16)
-            H.call('aln_build_sem_in', H.ptr(sout), None, M, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
-            if fs.lib:
-                feat, c['fhs'] = self._lib_fwd('semf', fin, train)
-                c['feat'] = feat
-            else:
-                fh1 = c['fh1'] = g('fh1', (M if save else 1, fs.hidden), f16)
-                fh2 = c['fh2'] = g('fh2', (M if save else 1, fs.hidden), f16)
+            c['sem_fused'] = self.recompute and not fs.lib and not os_.lib
+            if c['sem_fused']:  # inputs are built inside the kernels from sigma_out / f (no semf_in / semo_in tensors)
                 feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
-                H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if save else None,
-                       H.ptr(fh2) if save else None, H.ptr(feat), H.stream())
-            H.call('aln_build_sem_in', H.ptr(sout), H.ptr(feat), M, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
-            if os_.lib:
-                logits, c['ohs'] = self._lib_fwd('semo', oin, train)
-                c['logits'] = logits
-            else:
-                oh1 = c['oh1'] = g('oh1', (M if save else 1, os_.hidden), f16)
                 logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
-                H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if save else None, None,
-                       H.ptr(logits), H.stream())
+                H.call('aln_sem_heads_fwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sout), M, L.D, L.G,
+                       H.ptr(feat), H.ptr(logits), H.stream())
+            else:
+                fin = c['semf_in'] = g('semf_in', (M, fs.in_pad), f16)
+                oin = c['semo_in'] = g('semo_in', (M, os_.in_pad), f16)
+                H.call('aln_build_sem_in', H.ptr(sout), None, M, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
+                if fs.lib:
+                    feat, c['fhs'] = self._lib_fwd('semf', fin, train)
+                    c['feat'] = feat
+                else:
+                    fh1 = c['fh1'] = g('fh1', (M if save else 1, fs.hidden), f16)
+                    fh2 = c['fh2'] = g('fh2', (M if save else 1, fs.hidden), f16)
+                    feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
+                    H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if save else None,
+                           H.ptr(fh2) if save else None, H.ptr(feat), H.stream())
+                H.call('aln_build_sem_in', H.ptr(sout), H.ptr(feat), M, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
+                if os_.lib:
+                    logits, c['ohs'] = self._lib_fwd('semo', oin, train)
+                    c['logits'] = logits
+                else:
+                    oh1 = c['oh1'] = g('oh1', (M if save else 1, os_.hidden), f16)
+                    logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
+                    H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if save else None, None,
+                           H.ptr(logits), H.stream())
             out['semantic'] = torch.empty((N, L.C), dtype=f32_, device=dev)
             out['semantic_features'] = torch.empty((N, L.D), dtype=f32_, device=dev)
         H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(logits), H.ptr(feat), H.ptr(out['weights_sum']),
@@ -287,8 +294,9 @@ class HipPipeline:
         d_h0 = g('d_h0', (M,), f32_)
         cs = nets['color']
         d_cout = g('d_color_out', (M, cs.out_pad), f16)
-        d_logits = g('d_logits', (M, L.Cpad), f16) if sem else None
-        d_feat = g('d_feat', (M, L.D), f16) if sem else None
+        sem_fused = sem and c.get('sem_fused', False)
+        d_logits = g('d_logits', (M, L.Cpad), f16) if sem and not sem_fused else None
+        d_feat = g('d_feat', (M, L.D), f16) if sem and not sem_fused else None
         if sem and g_feat is None:
             g_feat = torch.zeros((N, L.D), dtype=f32_, device=g_image.device)
         H.call('aln_composite_bwd', H.ptr(c['norms']), H.ptr(c['z']), H.ptr(c['sigma']), H.ptr(c['perm']), H.ptr(c['w_row']),
@@ -304,7 +312,13 @@ class HipPipeline:
         H.call('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), hp(c['ch1']), hp(c['ch2']), H.ptr(d_cout),
                M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream())
         d_fin = d_oin = None
-        if sem:
+        if sem_fused:
+            fs, os_ = nets['semf'], nets['semo']
+            d_oin, d_fin = g('d_semo_in', (M, os_.in_pad), f16), g('d_semf_in', (M, fs.in_pad), f16)
+            H.call('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),
+                   H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_oin), H.ptr(d_fin),
+                   gp('semf'), gp('semo'), fi, H.stream())
+        elif sem:
             fs, os_ = nets['semf'], nets['semo']
             if os_.lib:
                 d_oin = self._lib_bwd('semo', c['semo_in'], c['ohs'], d_logits)

@@ -127,6 +127,15 @@ int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t*
 int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
                 const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW, int32_t* found_inf, void* stream);
 
+/* Both semantic heads (models.py:248-256) with their inputs / output gradients built on the fly from sigma_out, f, the
+ * compositing weights and the per-ray output gradients (no [rows,80] / [rows,64] intermediates in HBM). */
+int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, int32_t rows, int32_t D, int32_t G,
+                      void* feat, void* logits, void* stream);
+int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat, const float* w_row,
+                      const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t rows,
+                      int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf, float* dW_semo, int32_t* found_inf,
+                      void* stream);
+
 /* ---- head plumbing: autolabel/models.py:175-188 (sigma = trunc_exp(h0), geo_feat = h[1:]), :190-220 (boolean-mask
  * gather + SH(dir) ++ geo_feat), :248-256 (cat[relu(f), geo_feat]) and the matching gradient assembly */
 int aln_sigma_act(const void* sigma_out /*[rows,16] f16*/, int32_t rows, float* sigma, void* stream);
