@@ -47,7 +47,7 @@ extern "C" int aln_compute_direction(const float* R_WC, const int64_t* idx, int3
 
 struct RaygenArgs {
   AlnFrames fr; AlnBatch out; int B, chunk, frame_lo, frame_hi;
-  uint32_t k_frame, k_pix, k_jx, k_jy;
+  uint32_t k_frame, k_pix, k_jx, k_jy, k_cls;
   const int* chunk_frames; const int* ray_idx; const float* jitter;
 };
 
@@ -72,9 +72,27 @@ __device__ inline void gather_pixel(const AlnFrames& fr, const AlnBatch& out, in
 __global__ void k_raygen_train(RaygenArgs a) {
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x) {
     int ch = b / a.chunk;
-    int frame = a.chunk_frames ? a.chunk_frames[ch]
-                               : a.frame_lo + (int)(aln_rand_u32(a.k_frame, (uint32_t)ch) % (uint32_t)(a.frame_hi - a.frame_lo));
-    int64_t pix = a.ray_idx ? a.ray_idx[b] : a.fr.pixel_indices[aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)a.fr.n_pix];
+    int frame; int64_t pix;
+    // class-weighted chunk (dataset.py:207-211): every ray of the chunk takes the same (class, frame) decision
+    bool labelled = !a.chunk_frames && !a.ray_idx && a.fr.n_classes > 0 && a.fr.sem_ratio > 0.f &&
+                    aln_rand_uniform(a.k_cls, 3u * (uint32_t)ch) < a.fr.sem_ratio;
+    if (labelled) {
+      int k = (int)(aln_rand_u32(a.k_cls, 3u * (uint32_t)ch + 1u) % (uint32_t)a.fr.n_classes);
+      const int* off = a.fr.cls_offsets + (size_t)k * (a.fr.n_frames + 1);
+      int lo_o = off[a.frame_lo], hi_o = off[a.frame_hi];
+      if (hi_o > lo_o) {
+        int r = lo_o + (int)(aln_rand_u32(a.k_cls, 3u * (uint32_t)ch + 2u) % (uint32_t)(hi_o - lo_o));
+        int f0 = a.frame_lo, f1 = a.frame_hi;      // largest f with off[f] <= r
+        while (f1 - f0 > 1) { int m = (f0 + f1) >> 1; if (off[m] <= r) f0 = m; else f1 = m; }
+        frame = f0;
+        pix = a.fr.cls_pixels[off[f0] + (int)(aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)(off[f0 + 1] - off[f0]))];
+      } else labelled = false;                     // this rank's frame shard has no pixel of that class
+    }
+    if (!labelled) {
+      frame = a.chunk_frames ? a.chunk_frames[ch]
+                             : a.frame_lo + (int)(aln_rand_u32(a.k_frame, (uint32_t)ch) % (uint32_t)(a.frame_hi - a.frame_lo));
+      pix = a.ray_idx ? a.ray_idx[b] : a.fr.pixel_indices[aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)a.fr.n_pix];
+    }
     float jx = a.jitter ? a.jitter[2 * b] : aln_rand_uniform(a.k_jx, (uint32_t)b);
     float jy = a.jitter ? a.jitter[2 * b + 1] : aln_rand_uniform(a.k_jy, (uint32_t)b);
     float d[3], nn;
@@ -120,10 +138,11 @@ extern "C" int aln_raygen_train(const AlnFrames* fr, const AlnBatch* out, int32_
   ALN_REQUIRE(chunk > 0 && B % chunk == 0, "raygen_train: batch %d is not a multiple of chunk %d", B, chunk);
   ALN_REQUIRE(chunk_frames || (0 <= frame_lo && frame_lo < frame_hi && frame_hi <= fr->n_frames), "raygen_train: bad frame range");
   ALN_REQUIRE(ray_idx || (fr->pixel_indices && fr->n_pix > 0), "raygen_train: pixel_indices missing");
+  ALN_REQUIRE(fr->n_classes == 0 || (fr->cls_offsets && fr->cls_pixels), "raygen_train: class index arrays missing");
   if (B <= 0) return 0;
   RaygenArgs a{*fr, *out, B, chunk, frame_lo, frame_hi, aln_rand_key(seed, ALN_STREAM_FRAME, step),
                aln_rand_key(seed, ALN_STREAM_PIXEL, step), aln_rand_key(seed, ALN_STREAM_JX, step),
-               aln_rand_key(seed, ALN_STREAM_JY, step), chunk_frames, ray_idx, jitter};
+               aln_rand_key(seed, ALN_STREAM_JY, step), aln_rand_key(seed, ALN_STREAM_CLASS, step), chunk_frames, ray_idx, jitter};
   hipLaunchKernelGGL(k_raygen_train, dim3(aln_grid_for(B, 256)), dim3(256), 0, (hipStream_t)stream, a);
   ALN_CHECK_LAUNCH("raygen_train");
   return 0;

@@ -446,6 +446,32 @@ class DeviceFrames:
             fr.feat_h, fr.feat_w, fr.feat_c = int(feat_hw[0]), int(feat_hw[1]), int(self.features.shape[-1])
             self.feature_dim = int(self.features.shape[-1])
         self.device = dv
+        self.set_class_index(np.asarray(semantics.cpu() if torch.is_tensor(semantics) else semantics))
+
+    def set_class_index(self, semantics, ratio=BaseDataset.semantic_image_sample_ratio):
+        """Device copy of IndexSampler (autolabel/dataset.py:80-151): per class, per frame pixel lists in CSR form.
+        Call again after the labels change (SceneDataset.update_sampler)."""
+        sem = np.asarray(semantics).reshape(self.n_frames, -1)
+        classes = np.unique(sem)
+        classes = classes[classes != 0]
+        fr = self.desc
+        fr.n_classes, fr.sem_ratio = 0, 0.0
+        if len(classes) == 0:
+            return
+        offs, pix, base = [], [], 0
+        for c in classes:
+            row = [base]
+            for f in range(self.n_frames):
+                idx = np.flatnonzero(sem[f] == c)
+                pix.append(idx)
+                base += len(idx)
+                row.append(base)
+            offs.append(row)
+        self.cls_offsets = torch.as_tensor(np.asarray(offs, dtype=np.int32)).to(self.device).contiguous()
+        self.cls_pixels = torch.as_tensor(np.concatenate(pix).astype(np.int32)).to(self.device).contiguous()
+        self.classes = classes
+        fr.cls_offsets, fr.cls_pixels = self.cls_offsets.data_ptr(), self.cls_pixels.data_ptr()
+        fr.n_classes, fr.sem_ratio = len(classes), float(ratio)
 
     @classmethod
     def from_dataset(cls, ds, device='cuda'):

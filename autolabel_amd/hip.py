@@ -33,7 +33,8 @@ class AlnMlpDesc(C.Structure):
 class AlnFrames(C.Structure):
     _fields_ = [('images', vp), ('depths', vp), ('semantics', vp), ('features', vp), ('rotations', vp), ('origins', vp),
                 ('pixel_indices', vp), ('n_frames', i32), ('w', i32), ('h', i32), ('n_pix', i32), ('feat_w', i32),
-                ('feat_h', i32), ('feat_c', i32), ('fx', f64), ('fy', f64), ('cx', f64), ('cy', f64)]
+                ('feat_h', i32), ('feat_c', i32), ('fx', f64), ('fy', f64), ('cx', f64), ('cy', f64), ('cls_offsets', vp),
+                ('cls_pixels', vp), ('n_classes', i32), ('sem_ratio', f32)]
 
 
 class AlnBatch(C.Structure):

@@ -71,6 +71,13 @@ typedef struct {
   const int32_t* pixel_indices; /* [n_pix] valid pixels (dataset.py:295-311) */
   int32_t n_frames, w, h, n_pix, feat_w, feat_h, feat_c;
   double fx, fy, cx, cy;
+  /* optional class index (IndexSampler, dataset.py:80-151): for class k, cls_offsets[k*(n_frames+1) + f .. f+1] delimit the
+   * pixels of that class in frame f inside cls_pixels; a labelled chunk (probability sem_ratio, dataset.py:207-211) draws a
+   * class uniformly, a frame proportionally to its pixel count of that class, then pixels of that class in that frame. */
+  const int32_t* cls_offsets; /* [n_classes, n_frames+1] */
+  const int32_t* cls_pixels;
+  int32_t n_classes;
+  float sem_ratio;            /* 0.5 in the reference; 0 disables */
 } AlnFrames;
 
 typedef struct {

@@ -130,6 +130,40 @@ def test_raygen_train_counter_rng_matches_oracle_rng(H, golden_dir):
         assert np.array_equal(t['pixels'][s].cpu().numpy(), f['images'][frames[c]][pix[s]])
 
 
+def test_raygen_class_weighted_chunks_follow_index_sampler(H, golden_dir):
+    """Device version of the class-weighted branch (dataset.py:207-211) vs a numpy replay of the same counter RNG:
+    labelled chunks pick a class, a frame ~ its pixel count of that class, and only pixels of that class."""
+    from autolabel_amd.dataset import DeviceFrames
+    f = np.load(os.path.join(golden_dir, 'raygen_f2_labelled.npz'))
+    w, h, fx, fy, cx, cy = f['intr']
+    fr = DeviceFrames(f['images'], f['depths'], f['semantics'], f['poses'], f['pixel_indices'], int(w), int(h), (fx, fy, cx, cy))
+    B, seed, step = 512 * 64, 5, 3
+    out = fr.alloc_batch(B)
+    fr.next_train(out, seed, step)
+    sem = f['semantics']
+    classes = np.unique(sem); classes = classes[classes != 0]
+    lab = out['semantic'].cpu().numpy().reshape(-1, 512)
+    org = out['rays_o'].cpu().numpy().reshape(-1, 512, 3)[:, 0]
+    frames = np.array([int(np.argmin(np.abs(f['poses'][:, :3, 3] - o).sum(1))) for o in org])
+    ch = np.arange(B // 512)
+    u0 = O.rand_uniform(seed, O.STREAM_CLASS, step, 3 * ch)
+    k = O.rand_u32(seed, O.STREAM_CLASS, step, 3 * ch + 1) % np.uint32(len(classes))
+    r = O.rand_u32(seed, O.STREAM_CLASS, step, 3 * ch + 2)
+    n_lab = 0
+    for c in ch:
+        if u0[c] < 0.5:
+            n_lab += 1
+            cls = classes[k[c]]
+            counts = (sem == cls).sum(1)
+            pick = int(r[c] % np.uint32(counts.sum()))
+            want_frame = int(np.searchsorted(np.cumsum(counts), pick, side='right'))
+            assert frames[c] == want_frame
+            assert (lab[c] == int(cls) - 1).all()  # every ray of the chunk carries that class
+        else:
+            assert frames[c] == int(O.rand_u32(seed, O.STREAM_FRAME, step, np.array([c]))[0] % np.uint32(fr.n_frames))
+    assert 20 <= n_lab <= 44  # ~ half of 64 chunks
+
+
 def test_raygen_frame_matches_reference_get_test(H, golden_dir):
     f2 = np.load(os.path.join(golden_dir, 'raygen_f2_plain.npz'))
     f3 = np.load(os.path.join(golden_dir, 'raygen_f3.npz'))
