@@ -6,23 +6,39 @@
 #include "common.h"
 #include <math.h>
 
-// state (device, int32/float32 mixed view):
-//   si[0] = optimizer step count t (counts applied steps only)   si[1] = growth tracker   si[2] = found_inf flag
+// Parameter blocks follow torch's per-tensor semantics: a block whose gradient is None in the reference (the semantic heads
+// when a batch has no labelled ray and no feature loss: autolabel/trainer.py:61-62,80-92) is skipped entirely -- no moment
+// decay, no weight decay, and its private step counter (bias correction) does not advance.
+//
+// state (device):
+//   si[0] = applied optimizer steps   si[1] = growth tracker   si[2] = found_inf flag   si[3] = -   si[4+b] = step count of block b
 //   sf[0] = loss scale
-// consts (written by k_adam_prepare): c[0] = skip (0/1), c[1] = lr / bc1, c[2] = 1/sqrt(bc2), c[3] = 1/scale_used
+// consts (written by k_adam_prepare): c[0] = skip all (0/1), c[3] = 1/scale_used, c[4+2b] = lr / bc1_b (0 = block inactive),
+//                                     c[5+2b] = 1/sqrt(bc2_b)
+#define ADAM_MAX_BLOCKS 8
 struct AdamHyper { float lr, beta1, beta2, eps, wd_net, growth, backoff; int growth_interval; };
+struct AdamBlocks { int n; long long end[ADAM_MAX_BLOCKS]; int needs_sem[ADAM_MAX_BLOCKS]; int needs_sem_or_feat[ADAM_MAX_BLOCKS]; int feat_on; };
 
-__global__ void k_adam_prepare(int* si, float* sf, float* c, AdamHyper h) {
+__global__ void k_adam_prepare(int* si, float* sf, float* c, AdamHyper h, AdamBlocks blk, const int* counts) {
   int found = si[2];
   float scale = sf[0];
   c[3] = 1.0f / scale;
+  const bool has_sem = !counts || counts[1] > 0;
   if (found) {
-    c[0] = 1.f; c[1] = 0.f; c[2] = 1.f;
+    c[0] = 1.f;
     sf[0] = scale * h.backoff; si[1] = 0;
   } else {
-    int t = si[0] + 1; si[0] = t;
-    double bc1 = 1.0 - pow((double)h.beta1, (double)t), bc2 = 1.0 - pow((double)h.beta2, (double)t);
-    c[0] = 0.f; c[1] = (float)((double)h.lr / bc1); c[2] = (float)(1.0 / sqrt(bc2));
+    c[0] = 0.f;
+    si[0] += 1;
+    for (int b = 0; b < blk.n; ++b) {
+      bool active = true;
+      if (blk.needs_sem[b]) active = has_sem;
+      if (blk.needs_sem_or_feat[b]) active = has_sem || blk.feat_on;
+      if (!active) { c[4 + 2 * b] = 0.f; c[5 + 2 * b] = 1.f; continue; }
+      int t = si[4 + b] + 1; si[4 + b] = t;
+      double bc1 = 1.0 - pow((double)h.beta1, (double)t), bc2 = 1.0 - pow((double)h.beta2, (double)t);
+      c[4 + 2 * b] = (float)((double)h.lr / bc1); c[5 + 2 * b] = (float)(1.0 / sqrt(bc2));
+    }
     int tr = si[1] + 1;
     if (tr >= h.growth_interval) { sf[0] = scale * h.growth; tr = 0; }
     si[1] = tr;
@@ -31,13 +47,18 @@ __global__ void k_adam_prepare(int* si, float* sf, float* c, AdamHyper h) {
 }
 
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                       h16* __restrict__ table16, size_t n_grid, size_t n_total, const float* __restrict__ c, AdamHyper h) {
+                       h16* __restrict__ table16, size_t n_grid, size_t n_total, const float* __restrict__ c, AdamHyper h,
+                       AdamBlocks blk) {
   const bool skip = c[0] != 0.f;
-  const float step_size = c[1], inv_sqrt_bc2 = c[2], inv_scale = c[3];
+  const float inv_scale = c[3];
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
     g[i] = 0.f;
     if (skip) continue;
+    int b = 0;
+    while (b + 1 < blk.n && (long long)i >= blk.end[b]) ++b;
+    const float step_size = c[4 + 2 * b], inv_sqrt_bc2 = c[5 + 2 * b];
+    if (step_size == 0.f) continue;   // block without gradient this step (torch: grad is None)
     float pi = p[i];
     gi *= inv_scale;
     if (i >= n_grid) gi += h.wd_net * pi;
@@ -51,18 +72,30 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
   }
 }
 
+// block_end[n_blocks] (host): exclusive end offsets of the parameter blocks in the flat buffer (last = n_total);
+// block_kind[b]: 0 = always has a gradient, 1 = only with labelled rays (semantic_out), 2 = labelled rays or feature loss
+// (semantic_features).  counts (device, from aln_loss_fwd_bwd) may be NULL: every block is then active.
 extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid,
                              int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
                              float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
-                             void* stream) {
+                             int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
+                             const int32_t* counts, void* stream) {
   ALN_REQUIRE(params && grads && m && v && state_i && state_f && consts, "adam: NULL pointer");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
+  ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
   AdamHyper h{lr, beta1, beta2, eps, wd_net, growth, backoff, growth_interval};
+  AdamBlocks blk{};
+  if (n_blocks == 0) { blk.n = 1; blk.end[0] = n_total; }
+  else {
+    blk.n = n_blocks;
+    for (int b = 0; b < n_blocks; ++b) { blk.end[b] = block_end[b]; blk.needs_sem[b] = block_kind[b] == 1; blk.needs_sem_or_feat[b] = block_kind[b] == 2; }
+  }
+  blk.feat_on = feature_loss;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(1), 0, s, state_i, state_f, consts, h);
+  hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(1), 0, s, state_i, state_f, consts, h, blk, counts);
   ALN_CHECK_LAUNCH("adam_prepare");
   hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_total, 256, 256 * 16)), dim3(256), 0, s, params, grads, m, v, (h16*)table_f16,
-                     (size_t)n_grid, (size_t)n_total, consts, h);
+                     (size_t)n_grid, (size_t)n_total, consts, h, blk);
   ALN_CHECK_LAUNCH("adam");
   return 0;
 }

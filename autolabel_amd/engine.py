@@ -29,9 +29,17 @@ class TrainEngine:
         n = self.L.n_total
         self.m = torch.zeros(n, device=dv)
         self.v = torch.zeros(n, device=dv)
-        self.state_i = torch.zeros(4, dtype=torch.int32, device=dv)  # [adam step, growth tracker, found_inf, -]
+        self.state_i = torch.zeros(16, dtype=torch.int32, device=dv)  # [steps, growth tracker, found_inf, -, per-block steps]
         self.state_f = torch.tensor([sc['init_scale'], 0, 0, 0], dtype=torch.float32, device=dv)  # [loss scale]
-        self.consts = torch.zeros(4, device=dv)
+        self.consts = torch.zeros(24, device=dv)
+        # parameter blocks = the reference's parameter tensors (torch skips tensors whose grad is None)
+        L = self.L
+        ends, kinds = ([L.n_grid] if L.n_grid else []), ([0] if L.n_grid else [])
+        for k, kind in [('sigma', 0), ('color', 0), ('semf', 2), ('semo', 1)]:
+            ends.append(L.offsets[k] + L.nets[k].n_params)
+            kinds.append(kind)
+        self._blk_end = (C.c_int64 * len(ends))(*ends)
+        self._blk_kind = (C.c_int32 * len(kinds))(*kinds)
         self.counts = torch.zeros(2, dtype=torch.int32, device=dv)
         self.terms = torch.zeros(5, device=dv)  # rgb, depth, feature, semantic, total (last step)
         pipe.found_inf = self.state_i[2:3]
@@ -72,7 +80,8 @@ class TrainEngine:
         P, L, sc = self.P, self.L, self.scaler_cfg
         H.call('aln_adam_step', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
                H.ptr(self.state_i), H.ptr(self.state_f), H.ptr(self.consts), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-               sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), H.stream())
+               sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), len(self._blk_kind), self._blk_end,
+               self._blk_kind, int(bool(self.feature_loss)), H.ptr(self.counts), H.stream())
         P.refresh_shadows(grid=False)
 
     def step(self, batch, seed, step, noise=None, u=None):

@@ -27,6 +27,7 @@ class _RenderFn(torch.autograd.Function):
         out, c = pipe.forward(rays_o, rays_d, norms, cfg['num_steps'], cfg['upsample_steps'], cfg['perturb'], train=train,
                               seed=cfg['seed'], step=cfg['step'], noise=cfg.get('noise'), u=cfg.get('u'), bg=cfg['bg'])
         ctx.model, ctx.c = model, (c if train else None)
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None: their heads then get grad None like in the reference
         keys = ['image', 'depth', 'semantic', 'semantic_features', 'depth_variance', 'coordinates_map', 'weights_sum']
         ctx.mark_non_differentiable(out['depth_variance'], out['coordinates_map'], out['weights_sum'])
         return tuple(out[k] for k in keys)
@@ -41,10 +42,15 @@ class _RenderFn(torch.autograd.Function):
         z = lambda g, shape: (torch.zeros(shape, device=pipe.P.device) if g is None else g.float().contiguous())
         pipe.P.grad.zero_()
         pipe.backward(c, z(g_image, (N, 3)), z(g_depth, (N,)), z(g_sem, (N, L.C)), z(g_feat, (N, L.D)))
+        no_grad = set()
+        if g_sem is None:
+            no_grad.add('semo')
+            if g_feat is None:
+                no_grad.add('semf')
         grads = []
         for name, p in model._param_blocks():
             a, b = model._block_range(name)
-            grads.append(pipe.P.grad[a:b].view_as(p).clone() if p.requires_grad else None)
+            grads.append(pipe.P.grad[a:b].view_as(p).clone() if p.requires_grad and name not in no_grad else None)
         return (None, None, None, None, None, *grads)
 
 

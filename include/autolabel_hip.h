@@ -184,11 +184,16 @@ int aln_loss_fwd_bwd(const float* image, const float* depth, const float* semant
                      float* g_image, float* g_depth, float* g_sem, float* g_feat, float* terms, void* stream);
 
 /* ---- optimizer: torch.optim.Adam of scripts/train.py:50-63 + GradScaler step/update of autolabel/trainer.py:45-48.
- * state_i = {step, growth tracker, found_inf, -}, state_f = {loss scale}; skips the update (and backs the scale off)
- * when found_inf is set; refreshes the fp16 table shadow; zeroes the gradients. */
+ * state_i = {applied steps, growth tracker, found_inf, -, step count per block...} (>= 4 + n_blocks ints), state_f = {loss
+ * scale}, consts >= 4 + 2*n_blocks floats.  Skips the update (and backs the scale off) when found_inf is set; refreshes the
+ * fp16 table shadow; zeroes the gradients.  Parameter blocks follow torch's per-tensor semantics: block_kind 1 (semantic_out)
+ * is skipped when the batch has no labelled ray, kind 2 (semantic_features) when additionally there is no feature loss
+ * (their gradient is None in the reference, so torch.optim.Adam leaves them and their step counters untouched). */
 int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid, int64_t n_total,
                   int32_t* state_i, float* state_f, float* consts, float lr, float beta1, float beta2, float eps, float wd_net,
-                  float growth, float backoff, int32_t growth_interval, void* stream);
+                  float growth, float backoff, int32_t growth_interval, int32_t n_blocks, const int64_t* block_end /*host*/,
+                  const int32_t* block_kind /*host*/, int32_t feature_loss, const int32_t* counts /*device, optional*/,
+                  void* stream);
 int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -10,16 +10,16 @@ pytestmark = pytest.mark.gpu
 from oracle import nerf_oracle as O
 
 
-def build_pair(encoding='hg+freq', L=16, D=64, C_=3, bound=1.0, seed=0, grid_scale=1e4):
+def build_pair(encoding='hg+freq', L=16, D=64, C_=3, bound=1.0, seed=0, grid_scale=1e4, log2_T=19):
     """Same parameters in the oracle (named tensors) and in the HIP flat buffer."""
     from autolabel_amd import hip as H
     from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
-    cfg = O.ModelConfig(encoding=encoding, feature_dim=D, n_classes=C_, bound=bound, grid=O.GridSpec(n_levels=L))
+    cfg = O.ModelConfig(encoding=encoding, feature_dim=D, n_classes=C_, bound=bound, grid=O.GridSpec(n_levels=L, log2_hashmap_size=log2_T))
     p = O.init_params(cfg, seed)
     if 'grid' in p:
         p['grid'] = (p['grid'] * grid_scale).half().float()  # non-trivial density; exactly representable in the fp16 table
     oracle = O.OracleModel(cfg, params=p, half_sim=True)
-    layout = ModelLayout(encoding, 15, 128, 128, D, C_, bound=bound, grid=H.make_grid_desc(n_levels=L))
+    layout = ModelLayout(encoding, 15, 128, 128, D, C_, bound=bound, grid=H.make_grid_desc(n_levels=L, log2_hashmap_size=log2_T))
     P = Params(layout, 'cuda')
     parts = [p['grid'].reshape(-1)] if 'grid' in p else []
     for name in ['sigma', 'color', 'semf', 'semo']:
@@ -201,6 +201,62 @@ def test_lseg_width_heads_match_oracle():
     assert rel(got[:L.n_grid], gw[:L.n_grid]) < 2e-2
 
 
+def test_training_converges_like_the_oracle():
+    """Matched quality: the HIP engine and the fp32 CPU oracle train the same small model (S0 cube scene, L=4, T=2^14) from
+    the same initialisation on the same batches / random numbers for 50 Adam steps; the loss trajectories and the PSNR of
+    a training view agree (fp16 vs fp32 arithmetic, independently drawn importance samples)."""
+    import math
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import ArrayDataset
+    from autolabel_amd.engine import TrainEngine
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    oracle, pipe, cfg = build_pair(L=4, D=64, C_=3, bound=6.0, grid_scale=1.0, log2_T=14)
+    oracle.half_sim = False
+    scene = synthetic.make_cube_scene()
+    ds = ArrayDataset(scene, batch_size=512)
+    import random
+    np.random.seed(0); random.seed(0)
+    N, S1, S2, steps = 512, 32, 32, 50
+    eng = TrainEngine(pipe, num_steps=S1, upsample_steps=S2, feature_loss=False)
+    st = {k: [torch.zeros_like(v), torch.zeros_like(v), 0] for k, v in oracle.params.items()}
+    lh, lo = [], []
+    for it in range(steps):
+        b = ds._next_train()
+        bt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()}
+        dev = {k: v.cuda().float().contiguous() for k, v in bt.items() if k != 'semantic'}
+        dev['semantic'] = bt['semantic'].int().cuda()
+        eng.step(dev, seed=7, step=it)
+        lh.append(eng.terms[4].item())
+        noise = torch.from_numpy(O.rand_uniform(7, O.STREAM_PERTURB, it, np.arange(N * S1))).view(N, S1)
+        u = torch.from_numpy(O.rand_uniform(7, O.STREAM_PDF, it, np.arange(N * S2))).view(N, S2)
+        out = oracle.run(bt['rays_o'], bt['rays_d'], bt['direction_norms'], S1, S2, perturb=True, noise_coarse=noise, u_fine=u)
+        loss, _ = O.loss_fn(out, {'pixels': bt['pixels'], 'depth': bt['depth'], 'semantic': bt['semantic']})
+        for p in oracle.params.values():
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for k, p in oracle.params.items():
+                if p.grad is None:   # torch.optim.Adam skips tensors without gradient (heads unused by this batch's loss)
+                    continue
+                st[k][2] += 1
+                O.adam_update(p, p.grad, st[k][0], st[k][1], st[k][2], 5e-3, weight_decay=0.0 if k == 'grid' else 1e-6)
+        lo.append(loss.item())
+    assert eng.state_i[0].item() == steps, 'no step may be skipped by the loss scaler in this run'
+    assert lo[-1] < 0.6 * lo[0] and lh[-1] < 0.6 * lh[0]
+    # same trajectory: mean loss over the last 10 steps within 10 %
+    a, b_ = sum(lh[-10:]) / 10, sum(lo[-10:]) / 10
+    assert abs(a - b_) < 0.1 * b_, (a, b_)
+    t = ds._get_test(0)
+    ro, rd, dn = [torch.from_numpy(np.ascontiguousarray(t[k])).float() for k in ['rays_o', 'rays_d', 'direction_norms']]
+    gt = torch.from_numpy(t['pixels']).reshape(-1, 3)
+    with torch.no_grad():
+        img_o = oracle.run(ro.reshape(-1, 3), rd.reshape(-1, 3), dn, 64, 0, perturb=False)['image']
+    img_h, _ = pipe.forward(ro.reshape(-1, 3).cuda(), rd.reshape(-1, 3).cuda(), dn.reshape(-1).cuda(), 64, 0, False, train=False)
+    psnr = lambda x: -10 * math.log10(((x - gt) ** 2).mean().item())
+    ph, po = psnr(img_h['image'].cpu()), psnr(img_o)
+    assert abs(ph - po) < 1.0, (ph, po)   # +-1 dB after 50 steps from identical init
+
+
 def test_adam_step_matches_torch_adam_and_skips_on_inf():
     from autolabel_amd import hip as H
     n_grid, n = 1000, 1600
@@ -210,11 +266,14 @@ def test_adam_step_matches_torch_adam_and_skips_on_inf():
     opt = torch.optim.Adam([{'params': [p_ref]}], lr=5e-3, betas=(0.9, 0.99), eps=1e-15)
     p, gr, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
     t16 = torch.zeros(n_grid, dtype=torch.float16, device='cuda')
-    si, sf, cst = torch.zeros(4, dtype=torch.int32, device='cuda'), torch.tensor([128.0, 0, 0, 0], device='cuda'), torch.zeros(4, device='cuda')
+    si, sf, cst = torch.zeros(16, dtype=torch.int32, device='cuda'), torch.tensor([128.0, 0, 0, 0], device='cuda'), torch.zeros(24, device='cuda')
+    import ctypes
+    ends, kinds = (ctypes.c_int64 * 2)(n_grid, n), (ctypes.c_int32 * 2)(0, 1)
+    counts = torch.tensor([0, 1], dtype=torch.int32, device='cuda')
 
     def step():
         H.call('aln_adam_step', H.ptr(p), H.ptr(gr), H.ptr(m), H.ptr(v), H.ptr(t16), n_grid, n, H.ptr(si), H.ptr(sf), H.ptr(cst),
-               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, H.stream())
+               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, H.ptr(counts), H.stream())
     for it in range(4):
         gt = torch.randn(n, generator=g)
         pr = p_ref.detach().clone()
@@ -233,3 +292,9 @@ def test_adam_step_matches_torch_adam_and_skips_on_inf():
     gr.fill_(1.0); si[2] = 1
     step()
     assert torch.equal(p, before) and sf[0].item() == 128.0 and si[0].item() == 4 and si[2].item() == 0
+    # a block whose gradient is None in the reference (no labelled ray) is left untouched, its step counter too
+    counts[1] = 0
+    gr.fill_(128.0)
+    step()
+    assert torch.equal(p[n_grid:], before[n_grid:]) and not torch.equal(p[:n_grid], before[:n_grid])
+    assert si[4].item() == 5 and si[5].item() == 4
