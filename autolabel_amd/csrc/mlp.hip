@@ -14,6 +14,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+typedef __attribute__((address_space(3))) h16 lds_h16;   // LDS-typed element: ds_* with 32-bit addresses + immediate offsets
+#define LDS_VEC(T) __attribute__((address_space(3))) T
+
 // ---------------------------------------------------------------- fragment bookkeeping
 struct MlpLayers {
   int n;          // number of weight matrices (n_hidden + 1)
@@ -195,13 +198,13 @@ __device__ inline h16x8 load_chunk8(const RowSrc& s, int row, int c0) {
 static RowSrc plain_src(const void* p, int ld) {
   RowSrc s{}; s.mode = SRC_PLAIN; s.a = (const h16*)p; s.lda = ld; return s;
 }
-__device__ inline void load_tile_src(h16* tile, int pitch, const RowSrc& s, int ncols, int r0, int nrows, int limit) {
+__device__ inline void load_tile_src(lds_h16* tile, int pitch, const RowSrc& s, int ncols, int r0, int nrows, int limit) {
   const int per_row = ncols / 8;
-  for (int i = threadIdx.x; i < nrows * per_row; i += 256) {
+  for (int i = threadIdx.x; i < nrows * per_row; i += blockDim.x) {
     int r = i / per_row, k = i % per_row;
     h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (r0 + r < limit) v = load_chunk8(s, r0 + r, 8 * k);
-    *(h16x8*)(tile + (size_t)r * pitch + 8 * k) = v;
+    *(LDS_VEC(h16x8)*)(tile + r * pitch + 8 * k) = v;
   }
 }
 
@@ -434,15 +437,16 @@ __global__ __launch_bounds__(256) void k_dw_gemm(const h16* __restrict__ dA, int
 // once at the end: no per-layer dA round trip through HBM and no separate dW GEMM launches.
 typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4v* lds_s16x4_ptr;
-__device__ inline h16x8 tr_frag(const h16* tile, int pitch, int col0, int ks, int lane) {
+template <class TP>
+__device__ inline h16x8 tr_frag(TP tile, int pitch, int col0, int ks, int lane) {
   // operand fragment for mfma 32x32x16: lane (i = lane&31, hf = lane>>5) gets tile[16ks + 8hf + 0..7][col0 + i].
   // (the builtin lets the compiler count lgkmcnt itself, so several fragment reads stay in flight)
   const int hf = lane >> 5;
   const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
   const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const h16* p0 = tile + (size_t)row * pitch + col;
+  auto p0 = tile + row * pitch + col;
   s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
-  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 4 * (size_t)pitch));
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 4 * pitch));
   union { struct { s16x4v l, h; } s; h16x8 v; } u;
   u.s.l = lo; u.s.h = hi;
   return u.v;
@@ -460,8 +464,8 @@ __device__ inline void load_tile(h16* tile, int pitch, const h16* g, int ncols, 
 
 // dW accumulate over the block tile: wave owns C-blocks blk = wave + 4b (blk -> (ob, ib) = (blk / NIB, blk % NIB)).
 // When 4 % NIB == 0 the input block ib is the same for all owned blocks, so its fragment is fetched once per k-step.
-template <int NBLK, int NOB, int NIB>
-__device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], const h16* tA, int pA, const h16* tB, int pB, int wave, int lane) {
+template <int NBLK, int NOB, int NIB, class TPA, class TPB>
+__device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], TPA tA, int pA, TPB tB, int pB, int wave, int lane) {
   constexpr bool IB_CONST = (4 % NIB) == 0;
   constexpr int NBF = IB_CONST ? 1 : NBLK;
   h16x8 a[2][NBLK], bq[2][NBF];
@@ -636,6 +640,7 @@ static int launch_bwd_fused(const AlnMlpDesc* m, const void* x, const void* h1, 
 template <int NB, int KSN, class FragFn, class BFn>
 __device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
   h16x8 a[2][NB];
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int m = 0; m < NB; ++m) a[0][m] = frag(m, 0);
 #pragma unroll
@@ -646,18 +651,18 @@ __device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
     }
     h16x8 b = bop(ks);
 #pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b, acc[m]);
+    for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b, ks == 0 ? zero : acc[m]);   // C = 0 inline: no accumulator zeroing
   }
 }
 // relu'(h) mask read back from the LDS tile holding h (C-layout 8-byte chunks)
 template <int NB>
-__device__ inline bool mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const h16* act_row, int hf) {
+__device__ inline bool mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const lds_h16* act_row, int hf) {
   bool bad = false;
 #pragma unroll
   for (int m = 0; m < NB; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      h16x4 a = *(const h16x4*)(act_row + 32 * m + 8 * q + 4 * hf);
+      h16x4 a = *(const LDS_VEC(h16x4)*)(act_row + 32 * m + 8 * q + 4 * hf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float g = ((float)a[r] > 0.f) ? acc[m][4 * q + r] : 0.f;
@@ -675,37 +680,38 @@ __device__ inline bool mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], cons
 // 2*HID*NHID + IN + OUT halves read to IN + OUT (sigma head: 770 -> 224 B), which turns the kernel from latency/HBM bound
 // into MFMA bound.  Weights live in LDS ONCE, row-major: forward fragments are plain reads, transposed (backward)
 // fragments come from ds_read_b64_tr_b16.
-__device__ inline h16x8 tr_frag_chained(const h16* tile, int pitch, int col0, int ks, int lane) {
+template <class TP>
+__device__ inline h16x8 tr_frag_chained(TP tile, int pitch, int col0, int ks, int lane) {
   // as tr_frag, but the 8 rows follow the chained k-order of the register chain: base + 8*(j>>2) + 4*hf + (j&3)
   const int hf = lane >> 5;
   const int row = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * hf + ((lane & 15) >> 2);
   const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const h16* p0 = tile + (size_t)row * pitch + col;
+  auto p0 = tile + row * pitch + col;
   s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
-  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * (size_t)pitch));
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * pitch));
   union { struct { s16x4v l, h; } s; h16x8 v; } u;
   u.s.l = lo; u.s.h = hi;
   return u.v;
 }
 // forward A fragment (lane: output feature n = row, 8 input features) from the row-major weights
-__device__ inline h16x8 fwd_frag_natural(const h16* W, int pitch, int mb, int ks, int lane) {
-  return *(const h16x8*)(W + (size_t)(32 * mb + (lane & 31)) * pitch + 16 * ks + 8 * (lane >> 5));
+__device__ inline h16x8 fwd_frag_natural(const lds_h16* W, int pitch, int mb, int ks, int lane) {
+  return *(const LDS_VEC(h16x8)*)(W + (32 * mb + (lane & 31)) * pitch + 16 * ks + 8 * (lane >> 5));
 }
-__device__ inline h16x8 fwd_frag_chained(const h16* W, int pitch, int mb, int ks, int lane) {
-  const h16* p0 = W + (size_t)(32 * mb + (lane & 31)) * pitch + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (lane >> 5);
-  h16x4 a = *(const h16x4*)p0, b = *(const h16x4*)(p0 + 8);
+__device__ inline h16x8 fwd_frag_chained(const lds_h16* W, int pitch, int mb, int ks, int lane) {
+  const lds_h16* p0 = W + (32 * mb + (lane & 31)) * pitch + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (lane >> 5);
+  h16x4 a = *(const LDS_VEC(h16x4)*)p0, b = *(const LDS_VEC(h16x4)*)(p0 + 8);
   h16x8 r; r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
   return r;
 }
 template <int NB>
-__device__ inline void write_packed_tile(h16* tile, int pitch, int srow, const h16x8 (&p)[2 * NB], int hf) {
+__device__ inline void write_packed_tile(lds_h16* tile, int pitch, int srow, const h16x8 (&p)[2 * NB], int hf) {
 #pragma unroll
   for (int m = 0; m < NB; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
       v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
-      *(h16x4*)(tile + (size_t)srow * pitch + 32 * m + 8 * q + 4 * hf) = v;
+      *(LDS_VEC(h16x4)*)(tile + srow * pitch + 32 * m + 8 * q + 4 * hf) = v;
     }
 }
 // relu'(h) mask taken from the packed forward activations (registers) instead of a saved tensor
@@ -734,17 +740,18 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
   constexpr int TR = 128;
   constexpr int NBLK_LAST = (OB * NB + 3) / 4, NBLK_MID = (NB * NB + 3) / 4, NBLK_FIRST = (NB * IB + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  h16* wl = (h16*)smem;
-  h16* W0 = wl;                                    // [HID][IN+8]
-  h16* W1 = W0 + (size_t)HID * PW0;                // [HID][HID+8]   (NHID == 2)
-  h16* WL = (NHID == 2) ? W1 + (size_t)HID * PW1 : W1;   // [OUT][HID+8]
-  h16* tX0 = wl + ((wr_halves + 7) & ~(size_t)7);  // x tile        [TR][PX0]
-  h16* b1 = tX0 + TR * PX0;                        // h1            [TR][PH]
-  h16* b2 = b1 + TR * PH;                          // h2 / dA tiles [TR][PH]
-  h16* tO = b2 + TR * PH;                          // dOut tile     [TR][PO]
-  copy_to_lds(wl, wr_g, wr_halves);
+  lds_h16* wl = (lds_h16*)smem;
+  lds_h16* W0 = wl;                                    // [HID][IN+8]
+  lds_h16* W1 = W0 + HID * PW0;                        // [HID][HID+8]   (NHID == 2)
+  lds_h16* WL = (NHID == 2) ? W1 + HID * PW1 : W1;     // [OUT][HID+8]
+  lds_h16* tX0 = wl + (int)((wr_halves + 7) & ~(size_t)7);  // x tile        [TR][PX0]
+  lds_h16* b1 = tX0 + TR * PX0;                        // h1            [TR][PH]
+  lds_h16* b2 = b1 + TR * PH;                          // h2 / dA tiles [TR][PH]
+  lds_h16* tO = b2 + TR * PH;                          // dOut tile     [TR][PO]
+  copy_to_lds((h16*)smem, wr_g, wr_halves);
   for (int i = threadIdx.x; i < TR * (PX0 + PO); i += 256) { if (i < TR * PX0) tX0[i] = (h16)0.f; else tO[i - TR * PX0] = (h16)0.f; }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
+  const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: uniform branches in the dW block loops
   if (rows_dev) rows = min(rows, *rows_dev);
   MlpLayers L = mlp_layers(IN, HID, OUT, NHID);
   f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
@@ -761,13 +768,11 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
     // ---------------- forward recompute: h1 (and h2) go through registers into LDS tiles (dW operands + relu masks)
     f32x16 acc[NB];
     h16x8 p[KS];
-    zero_acc(acc);
     chain_layer<NB, KS0>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); },
-                         [&](int ks) { return *(const h16x8*)(tX0 + (size_t)srow * PX0 + 16 * ks + 8 * hf); });
+                         [&](int ks) { return *(const LDS_VEC(h16x8)*)(tX0 + srow * PX0 + 16 * ks + 8 * hf); });
     relu_pack_store<NB>(acc, p, nullptr, hf);
     write_packed_tile<NB>(b1, PH, srow, p, hf);
     if constexpr (NHID == 2) {
-      zero_acc(acc);
       chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(W1, PW1, m, ks, lane); }, [&](int ks) { return p[ks]; });
       relu_pack_store<NB>(acc, p, nullptr, hf);
       write_packed_tile<NB>(b2, PH, srow, p, hf);
@@ -775,22 +780,20 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
     __syncthreads();
     // ---------------- last layer: dW_last += dOut^T . h_last ; dA_last = relu'(h_last) * (W_last^T dOut)
     dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, (NHID == 2) ? b2 : b1, PH, wave, lane);
-    zero_acc(acc);
     chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(WL, PW1, 32 * m, ks, lane); },
-                         [&](int ks) { return *(const h16x8*)(tO + (size_t)srow * PO + 16 * ks + 8 * hf); });
+                         [&](int ks) { return *(const LDS_VEC(h16x8)*)(tO + srow * PO + 16 * ks + 8 * hf); });
     if constexpr (NHID == 2) {
-      bad |= mask_pack_lds<NB>(acc, p, b2 + (size_t)srow * PH, hf);
+      bad |= mask_pack_lds<NB>(acc, p, b2 + srow * PH, hf);
       __syncthreads();                                   // dW_last readers are done with b2 (= h2)
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA2
       __syncthreads();
       dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, wave, lane);
-      zero_acc(acc);
       chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(W1, PW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
-      bad |= mask_pack_lds<NB>(acc, p, b1 + (size_t)srow * PH, hf);
+      bad |= mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
       __syncthreads();                                   // dW_mid readers are done with b2 / b1
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1
     } else {
-      bad |= mask_pack_lds<NB>(acc, p, b1 + (size_t)srow * PH, hf);
+      bad |= mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1 (b2 unused so far)
     }
     __syncthreads();
@@ -798,7 +801,6 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
     if (d_in) {
       const int row = r0 + srow;
       f32x16 o[IB];
-      zero_acc(o);
       chain_layer<IB, KS>(o, [&](int ib, int ks) { return tr_frag_chained(W0, PW0, 32 * ib, ks, lane); }, [&](int ks) { return p[ks]; });
       if (row < rows) {
 #pragma unroll
@@ -837,6 +839,138 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
   if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
 }
 
+// ---------------------------------------------------------------- recompute backward, wave-specialised (8 waves)
+// Profiling the 4-wave kernel (rocprofv3 + ISA): ~6500 issued instructions per 128-row tile and wave, of which 152 are
+// MFMAs -- with 428 registers per wave the accumulators spill into the AGPR half (1900 v_accvgpr moves) and only ONE wave
+// per SIMD is resident, so nothing hides the dependent-issue latency.  Here the two jobs get their own waves: waves 0-3 run
+// the register chain (forward recompute + backward data path, ~170 VGPRs), waves 4-7 only accumulate the weight gradients
+// (112 accumulator registers + fragments).  Both fit 256 registers, so the block runs 2 waves per SIMD and the chain wave
+// and the dW wave of a SIMD overlap their MFMA / LDS latencies.
+template <int IN, int HID, int OUT, int NHID>
+__global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__ wr_g, size_t wr_halves, RowSrc xs, RowSrc ds,
+                                                        int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
+                                                        float* __restrict__ dW, int* __restrict__ found_inf) {
+  constexpr int NB = HID / 32, KS = HID / 16, KS0 = IN / 16, KSO = OUT / 16, IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
+  constexpr int PW0 = IN + 8, PW1 = HID + 8;
+  constexpr int PH = HID + 8, PX0 = IB * 32 + 8, PO = OB * 32 + 8;
+  constexpr int TR = 128;
+  constexpr int NBLK_LAST = (OB * NB + 3) / 4, NBLK_MID = (NB * NB + 3) / 4, NBLK_FIRST = (NB * IB + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  lds_h16* wl = (lds_h16*)smem;
+  lds_h16* W0 = wl;
+  lds_h16* W1 = W0 + HID * PW0;
+  lds_h16* WL = (NHID == 2) ? W1 + HID * PW1 : W1;
+  lds_h16* tX0 = wl + (int)((wr_halves + 7) & ~(size_t)7);
+  lds_h16* b1 = tX0 + TR * PX0;
+  lds_h16* b2 = b1 + TR * PH;
+  lds_h16* tO = b2 + TR * PH;
+  copy_to_lds((h16*)smem, wr_g, wr_halves);
+  for (int i = threadIdx.x; i < TR * (PX0 + PO); i += 512) { if (i < TR * PX0) tX0[i] = (h16)0.f; else tO[i - TR * PX0] = (h16)0.f; }
+  const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool chain = wave < 4;
+  const int cw = wave & 3;                     // chain waves: 32-row slice ; dW waves: C-block owner id
+  const int srow = cw * 32 + c;
+  if (rows_dev) rows = min(rows, *rows_dev);
+  const int ntiles = (rows + TR - 1) / TR;
+  // The two roles run SEPARATE tile loops with the same barrier sequence (s_barrier only counts arrivals, and the role is
+  // wave-uniform), so the register allocator never sees the chain state and the dW accumulators live at the same time.
+  if (chain) {
+    bool bad = false;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int r0 = tile * TR;
+      __syncthreads();                                                   // B0
+      load_tile_src(tX0, PX0, xs, IN, r0, TR, rows);
+      load_tile_src(tO, PO, ds, OUT, r0, TR, rows);
+      __syncthreads();                                                   // B1
+      f32x16 acc[NB];
+      h16x8 p[KS];
+      chain_layer<NB, KS0>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); },
+                           [&](int ks) { return *(const LDS_VEC(h16x8)*)(tX0 + srow * PX0 + 16 * ks + 8 * hf); });
+      relu_pack_store<NB>(acc, p, nullptr, hf);
+      write_packed_tile<NB>(b1, PH, srow, p, hf);
+      if constexpr (NHID == 2) {
+        chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(W1, PW1, m, ks, lane); }, [&](int ks) { return p[ks]; });
+        relu_pack_store<NB>(acc, p, nullptr, hf);
+        write_packed_tile<NB>(b2, PH, srow, p, hf);
+      }
+      __syncthreads();                                                   // B2
+      chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(WL, PW1, 32 * m, ks, lane); },
+                           [&](int ks) { return *(const LDS_VEC(h16x8)*)(tO + srow * PO + 16 * ks + 8 * hf); });
+      bad |= mask_pack_lds<NB>(acc, p, ((NHID == 2) ? b2 : b1) + srow * PH, hf);
+      __syncthreads();                                                   // B3
+      if constexpr (NHID == 2) {
+        write_packed_tile<NB>(b2, PH, srow, p, hf);                      // dA2 over h2
+        __syncthreads();                                                 // B4
+        chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(W1, PW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
+        bad |= mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
+        __syncthreads();                                                 // B5
+      }
+      write_packed_tile<NB>(b2, PH, srow, p, hf);                        // dA1
+      __syncthreads();                                                   // B6
+      if (d_in) {
+        const int row = r0 + srow;
+        f32x16 o[IB];
+        chain_layer<IB, KS>(o, [&](int ib, int ks) { return tr_frag_chained(W0, PW0, 32 * ib, ks, lane); }, [&](int ks) { return p[ks]; });
+        if (row < rows) {
+#pragma unroll
+          for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int f = 32 * ib + 8 * q + 4 * hf;
+              if (f < IN) {
+                h16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = (h16)o[ib][4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
+                *(h16x4*)(d_in + (size_t)row * IN + f) = v;
+              }
+            }
+        }
+      }
+    }
+    if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
+  } else {
+    MlpLayers L = mlp_layers(IN, HID, OUT, NHID);
+    f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
+    zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int r0 = tile * TR;
+      __syncthreads();                                                   // B0
+      load_tile_src(tX0, PX0, xs, IN, r0, TR, rows);
+      load_tile_src(tO, PO, ds, OUT, r0, TR, rows);
+      __syncthreads();                                                   // B1
+      __syncthreads();                                                   // B2
+      dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, (NHID == 2) ? b2 : b1, PH, cw, lane);
+      __syncthreads();                                                   // B3
+      if constexpr (NHID == 2) {
+        __syncthreads();                                                 // B4
+        dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, cw, lane);
+        __syncthreads();                                                 // B5
+      }
+      __syncthreads();                                                   // B6
+      dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, b2, PH, tX0, PX0, cw, lane);
+    }
+    if (dW) {
+      auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, float* base) {
+        const int i = 32 * ib + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          if (o < OUTL && i < INL && a[r] != 0.f) unsafeAtomicAdd(base + (size_t)o * INL + i, a[r]);
+        }
+      };
+#pragma unroll
+      for (int b = 0; b < NBLK_LAST; ++b) { int blk = cw + 4 * b; if (blk < OB * NB) flush(dw_last[b], blk / NB, blk % NB, OUT, HID, dW + L.w_off[L.n - 1]); }
+      if constexpr (NHID == 2) {
+#pragma unroll
+        for (int b = 0; b < NBLK_MID; ++b) { int blk = cw + 4 * b; if (blk < NB * NB) flush(dw_mid[b], blk / NB, blk % NB, HID, HID, dW + L.w_off[1]); }
+      }
+#pragma unroll
+      for (int b = 0; b < NBLK_FIRST; ++b) { int blk = cw + 4 * b; if (blk < NB * IB) flush(dw_first[b], blk / IB, blk % IB, HID, IN, dW + L.w_off[0]); }
+    }
+  }
+}
+
 template <int IN, int HID, int OUT, int NHID>
 static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in,
                              float* dW, int* found_inf, hipStream_t s) {
@@ -847,9 +981,16 @@ static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_recomp: LDS %zu B exceeds 160 KiB", lds);
   int tiles = (rows + 127) / 128;
   int g = tiles < 256 ? tiles : 256;
-  hipFuncSetAttribute((const void*)k_mlp_bwd_recomp<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_mlp_bwd_recomp<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wr, halves, xs, ds,
-                     rows, rows_dev, (h16*)d_in, dW, found_inf);
+  static const bool four = getenv("ALN_MLP_BWD_4WAVE") != nullptr;
+  if (four) {
+    hipFuncSetAttribute((const void*)k_mlp_bwd_recomp<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_mlp_bwd_recomp<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wr, halves, xs, ds,
+                       rows, rows_dev, (h16*)d_in, dW, found_inf);
+  } else {
+    hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_mlp_bwd_recomp8<IN, HID, OUT, NHID>), dim3(g), dim3(512), lds, s, (const h16*)m->wr, halves, xs, ds,
+                       rows, rows_dev, (h16*)d_in, dW, found_inf);
+  }
   ALN_CHECK_LAUNCH("mlp_bwd_recomp");
   return 0;
 }
