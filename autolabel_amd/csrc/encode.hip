@@ -83,12 +83,20 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
     if (p.e.use_grid) {
       normalize_pos(x, p.e.bound, true, xn);
       for (int l = wave; l < p.e.grid.n_levels; l += 4) {
-        uint32_t idx[8]; float w[8];
-        grid_corners(p.e.grid, l, xn, idx, w);
+        uint32_t idx[8]; float w[8]; uint32_t cell[3];
+        grid_corners(p.e.grid, l, xn, idx, w, cell);
         const uint32_t* tab = p.table + p.e.grid.offset[l];
+        // run-dedupe of the gathers: consecutive samples in the same cell read the same 8 entries; only the first lane
+        // of a run loads them, the others take them over the cross-lane network (gathers are request-rate bound)
+        uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
+        const bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
+        const unsigned long long hm = __ballot(head);
+        const int hl = 63 - __clzll(hm & ((2ull << lane) - 1ull));   // head lane of this lane's run
         uint32_t v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = valid ? tab[idx[c]] : 0u;
+        for (int c = 0; c < 8; ++c) v[c] = (head && valid) ? tab[idx[c]] : 0u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = __shfl(v[c], hl);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
