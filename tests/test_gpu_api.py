@@ -193,3 +193,85 @@ def test_scripts_train_export_on_written_scene(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     outs = sorted(os.listdir(os.path.join(scene_dir, 'output', 'semantic')))
     assert len(outs) == 6
+
+
+@pytest.mark.parametrize('encoding', ['freq', 'hg'])
+def test_other_encodings_train_one_step_like_the_oracle(encoding):
+    """--encoding freq / hg (autolabel/model_utils.py:25-29): forward + gradients vs the oracle, then one fused step."""
+    from autolabel_amd.engine import TrainEngine
+    from test_gpu_pipeline import _batch, flat_grads, hip_loss, make_rays, rel
+    model = make_model(encoding=encoding, bound=1.0, C_=3, grid_scale=3e3)
+    oracle, cfg = oracle_of(model)
+    pipe = model._ensure_device()
+    N, S1, S2 = 48, 32, 32
+    o, d, norms = make_rays(N, seed=4)
+    g = torch.Generator().manual_seed(9)
+    noise, u = torch.rand(N, S1, generator=g), torch.rand(N, S2, generator=g)
+    batch = _batch(N, 3, 16, seed=2)
+    od, dd, nd, nz, ud = o.cuda(), d.cuda(), norms.cuda().reshape(-1), noise.cuda(), u.cuda()
+    out, ctx = pipe.forward(od, dd, nd, S1, S2, True, train=True, noise=nz, u=ud)
+    want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=True, noise_coarse=noise, u_fine=u,
+                      z_fine_override=ctx['z'][N * S1:].view(N, S2).cpu())
+    assert (out['image'].cpu() - want['image']).abs().max() < 5e-3
+    loss, _ = O.loss_fn(want, batch, feature_loss=True)
+    loss.backward()
+    gi, gd, gs, gf, t = hip_loss(pipe, out, batch, N, 3, 64, 16, scale=512.0)
+    pipe.P.grad.zero_()
+    pipe.backward(ctx, gi, gd, gs, gf)
+    got = pipe.P.grad[:pipe.L.n_total].cpu() / 512.0
+    assert rel(got, flat_grads(oracle, cfg)) < 1.5e-2
+    eng = TrainEngine(pipe, num_steps=S1, upsample_steps=S2, feature_loss=True)
+    before = pipe.P.flat.clone()
+    dev = {k: v.cuda().float().contiguous() for k, v in batch.items() if k != 'semantic'}
+    dev.update(rays_o=od, rays_d=dd, direction_norms=nd, semantic=batch['semantic'].int().cuda())
+    eng.step(dev, seed=1, step=0)
+    assert eng.state_i[0].item() == 1 and not torch.equal(before, pipe.P.flat) and torch.isfinite(pipe.P.flat).all()
+
+
+def test_interactive_trainer_and_eval_steps():
+    """InteractiveTrainer.init/take_step (GUI / ROS loop) and SimpleTrainer.test_step / eval_step / evaluate shapes."""
+    from autolabel_amd.trainer import InteractiveTrainer
+    ds, batches = _host_batches(4, B=512)
+    bound = float(((ds.max_bounds - ds.min_bounds) - (ds.min_bounds + ds.max_bounds) * 0.5).max())
+    model = make_model(D=64, C_=7, bound=bound, grid_scale=1.0)
+    optimizer = lambda model: torch.optim.Adam([{'name': 'encoding', 'params': list(model.encoder.parameters())},
+                                                {'name': 'net', 'params': model.network_parameters(), 'weight_decay': 1e-6}],
+                                               lr=5e-3, betas=(0.9, 0.99), eps=1e-15)
+    tr = InteractiveTrainer('ngp', _opt(feature_loss=False), model, device='cuda:0', workspace=None, optimizer=optimizer,
+                            criterion=torch.nn.MSELoss(reduction='none'), fp16=True, ema_decay=0.95,
+                            lr_scheduler=lambda o: torch.optim.lr_scheduler.StepLR(o, gamma=0.5, step_size=1), metrics=[],
+                            use_checkpoint='latest', mute=True)
+
+    class Loader:
+        _data = ds
+
+        def __iter__(self):
+            return iter(batches)
+    tr.init(Loader())
+    l0 = float(tr.take_step())
+    for _ in range(3):
+        l1 = float(tr.take_step())
+    assert tr.step == 4 and np.isfinite(l0) and np.isfinite(l1)
+    ds.split = 'test'
+    frame = ds._get_test(0)
+    with torch.no_grad():
+        rgb, depth, sem, feat = tr.test_step(frame)
+        assert rgb.shape == (1, 48, 64, 3) and depth.shape == (1, 48, 64) and sem.shape == (1, 48, 64, 7) and feat.shape == (48, 64, 64)
+        p_rgb, p_depth, p_sem, gt_rgb, loss = tr.eval_step(frame)
+        assert p_rgb.shape == (1, 48, 64, 3) and p_sem.shape == (1, 48, 64, 7) and torch.isfinite(loss)
+    assert np.isfinite(tr.evaluate([ds._get_test(i) for i in range(2)]))
+
+
+def test_render_options_bg_color_and_chunking_consistency():
+    model = make_model().eval()
+    g = torch.Generator().manual_seed(2)
+    o = ((torch.rand(300, 3, generator=g) - 0.5) * 0.4).cuda()
+    d = torch.nn.functional.normalize(torch.randn(300, 3, generator=g), dim=-1).cuda()
+    n = torch.ones(300, 1).cuda()
+    with torch.inference_mode():
+        a = model.render(o, d, n, staged=False, perturb=False, num_steps=64, upsample_steps=32)
+        b = model.render(o, d, n, staged=True, perturb=False, num_steps=64, upsample_steps=32, max_ray_batch=77)
+        c = model.render(o, d, n, staged=False, perturb=False, num_steps=64, upsample_steps=32, bg_color=0.0)
+    for k in ['image', 'depth', 'semantic', 'semantic_features', 'weights_sum']:
+        assert torch.allclose(a[k], b[k], atol=1e-6), k          # chunking does not change per-ray results
+    assert torch.allclose(a['image'] - c['image'], (1 - a['weights_sum'])[:, None].expand(-1, 3), atol=1e-6)
