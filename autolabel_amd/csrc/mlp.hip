@@ -157,13 +157,18 @@ struct RowSrc {
   int N, S1, S2, D, G, gw;
 };
 __device__ inline h16x8 geo_chunk(const h16* sigma_out, size_t row, int j0, int G) {
-  // [geo_feat (G), 1, 1, ...] features j0..j0+7 ; geo_feat[g] = sigma_out[row][1 + g]
+  // [geo_feat (G), 1, 1, ...] features j0..j0+7 ; geo_feat[g] = sigma_out[row][1 + g].  j0 is 0 or 8: both cases use
+  // compile-time element indices (a runtime-indexed local array would live in scratch memory)
   const h16* r = sigma_out + row * 16;
-  uint4 lo = *(const uint4*)r, hi = *(const uint4*)(r + 8);
-  union { uint4 u[2]; h16 h[16]; } v; v.u[0] = lo; v.u[1] = hi;
+  const h16x8 lo = *(const h16x8*)r, hi = *(const h16x8*)(r + 8);
   h16x8 o;
+  if (j0 == 0) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (j0 + j < G) ? v.h[1 + j0 + j < 16 ? 1 + j0 + j : 15] : (h16)1.0f;
+    for (int j = 0; j < 8; ++j) { h16 v = (j < 7) ? lo[j + 1] : hi[0]; o[j] = (j < G) ? v : (h16)1.0f; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h16 v = (j < 7) ? hi[j + 1] : (h16)1.0f; o[j] = (8 + j < G) ? v : (h16)1.0f; }
+  }
   return o;
 }
 __device__ inline h16x8 load_chunk8(const RowSrc& s, int row, int c0) {
@@ -655,9 +660,16 @@ __device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
   }
 }
 // relu'(h) mask read back from the LDS tile holding h (C-layout 8-byte chunks)
+// fp16 overflow detection without converting every value back: track max |g| (overflow <=> > 65504) and fold the values
+// into a NaN catcher (g * 0 is NaN for NaN / inf); two VALU ops per element instead of four.
+struct InfTrack {
+  float mx = 0.f, nanz = 0.f;
+  __device__ inline void see(float g) { mx = fmaxf(mx, fabsf(g)); nanz = fmaf(g, 0.f, nanz); }
+  __device__ inline bool bad() const { return !(mx <= 65504.f) || !(nanz == 0.f); }
+};
 template <int NB>
 __device__ inline bool mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const lds_h16* act_row, int hf) {
-  bool bad = false;
+  InfTrack trk;
 #pragma unroll
   for (int m = 0; m < NB; ++m)
 #pragma unroll
@@ -665,13 +677,12 @@ __device__ inline bool mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], cons
       h16x4 a = *(const LDS_VEC(h16x4)*)(act_row + 32 * m + 8 * q + 4 * hf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float g = ((float)a[r] > 0.f) ? acc[m][4 * q + r] : 0.f;
-        h16 gh = (h16)g;
-        bad |= !(fabsf((float)gh) <= 65504.f);
-        p[2 * m + (q >> 1)][4 * (q & 1) + r] = gh;
+        float g = (a[r] > (h16)0.f) ? acc[m][4 * q + r] : 0.f;
+        trk.see(g);
+        p[2 * m + (q >> 1)][4 * (q & 1) + r] = (h16)g;
       }
     }
-  return bad;
+  return trk.bad();
 }
 
 // ---------------------------------------------------------------- fused backward WITH forward recompute
@@ -920,8 +931,10 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
               const int f = 32 * ib + 8 * q + 4 * hf;
               if (f < IN) {
                 h16x4 v;
+                InfTrack trk;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = (h16)o[ib][4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
+                for (int r = 0; r < 4; ++r) { v[r] = (h16)o[ib][4 * q + r]; trk.see(o[ib][4 * q + r]); }
+                bad |= trk.bad();
                 *(h16x4*)(d_in + (size_t)row * IN + f) = v;
               }
             }
