@@ -179,11 +179,18 @@ def main():
         rows = [r for _, r in events]
         avg_s = sum(durs) / len(durs)
         achieved = per_row * (sum(rows) / len(rows)) / avg_s / 1e9
+        traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
+                traffic = json.load(f).get('k_encode_bwd_traffic_bytes_per_launch')
+        except (OSError, ValueError):
+            pass
         res['roofline'] = {'kernel': 'k_encode_bwd', 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                           'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
+                           'frac': achieved / 8000.0, 'traffic': traffic, 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
                            'algorithmic_bytes_per_launch': per_row * (sum(rows) / len(rows)),
-                           'note': 'scatter of 2x fp32 atomics per corner: bound by the atomic request rate (~21 G sector '
-                                   'requests/s measured, scripts/dev/probe_atomics3.hip), not by HBM bytes'}
+                           'note': 'scatter of 2x fp32 atomics per corner: bound by the atomic request rate (~21 G 64-byte '
+                                   'requests/s measured, scripts/dev/probe_atomics3.hip), not by HBM bytes; traffic = '
+                                   '(FETCH_SIZE + WRITE_SIZE) KB * 1024 from profiles/r01_pmc_summary.json'}
         if not args.no_cpu_baseline and world == 1:
             lo, hi = scene['min_bounds'], scene['max_bounds']
             v, sample = cpu_baseline(None, args.feature_dim, scene['n_classes'], float(((hi - lo) - (lo + hi) * 0.5).max()))
