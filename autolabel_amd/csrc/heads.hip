@@ -84,6 +84,31 @@ __device__ inline void sh4(float x, float y, float z, float* o) {
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
+// the remap of models.py:205 ((d+1)/2, which tcnn maps back with 2x-1) followed by SH deg 4
+__device__ inline void sh4_of_dir(const float* d, float* sh) {
+  float v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { float d01 = (d[k] + 1.0f) / 2.0f; v[k] = d01 * 2.0f - 1.0f; }
+  sh4(v[0], v[1], v[2], sh);
+}
+
+__global__ void k_sh4(const float* __restrict__ dirs, int rows, int pitch, h16* __restrict__ out) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    float sh[16];
+    sh4_of_dir(dirs + 3 * (size_t)r, sh);
+    h16* o = out + (size_t)r * pitch;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = (h16)sh[j];
+  }
+}
+extern "C" int aln_sh4(const float* dirs, int32_t rows, int32_t out_pitch, void* out, void* stream) {
+  ALN_REQUIRE(dirs && out && out_pitch >= 16, "sh4: bad arguments");
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(k_sh4, dim3(aln_grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, dirs, rows, out_pitch, (h16*)out);
+  ALN_CHECK_LAUNCH("sh4");
+  return 0;
+}
+
 // color_in[ci] = [SH16(dir(ray(row))), geo_feat[row] (G), 1...]   width in_pad
 __global__ void k_build_color_in(const int* __restrict__ live_idx, const int* __restrict__ n_live, int max_rows,
                                  const float* __restrict__ rd, const float* __restrict__ dirs, int N, int S1, int S2,
@@ -94,11 +119,8 @@ __global__ void k_build_color_in(const int* __restrict__ live_idx, const int* __
     const float* d;
     if (dirs) d = dirs + 3 * (size_t)row;
     else { int ray = row < N * S1 ? row / S1 : (row - N * S1) / S2; d = rd + 3 * (size_t)ray; }
-    float v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { float d01 = (d[k] + 1.0f) / 2.0f; v[k] = d01 * 2.0f - 1.0f; }
     float sh[16];
-    sh4(v[0], v[1], v[2], sh);
+    sh4_of_dir(d, sh);
     h16* o = cin + (size_t)ci * in_pad;
     for (int j = 0; j < 16; ++j) o[j] = (h16)sh[j];
     for (int g = 0; g < G; ++g) o[16 + g] = sigma_out[(size_t)row * 16 + 1 + g];

@@ -126,23 +126,49 @@ __device__ inline void zero_acc(f32x16 (&acc)[NB]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 }
-// ReLU + fp16 pack of a layer's C registers into next-layer B fragments; optional natural-layout store
+// ReLU + fp16 pack of a layer's C registers into next-layer B fragments; optional natural-layout store.
+// Convert first (v_cvt_pk_f16_f32, RNE), then clamp the PACKED halves as signed 16-bit integers: every negative float
+// (and -0) has the sign bit set, so max_i16(bits, 0) is ReLU on two values per instruction and never leaves a -0 behind
+// (the backward masks below rely on "h > 0  <=>  bits != 0").
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t cvt_pk(float a, float b) {   // v_cvt_pk_f16_f32 (RNE)
+  union { h16x2 h; uint32_t w; } u; u.h = __builtin_convertvector((f32x2){a, b}, h16x2);
+  return u.w;
+}
+__device__ inline uint32_t relu2(float a, float b) {
+  union { s16x2 i; uint32_t w; } u; u.w = cvt_pk(a, b);
+  u.i = __builtin_elementwise_max(u.i, (s16x2){0, 0});
+  return u.w;
+}
 template <int NB>
 __device__ inline void relu_pack_store(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], h16* dst_row /*row base or null*/, int hf) {
 #pragma unroll
   for (int m = 0; m < NB; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[2 * m + (r >> 3)][r & 7] = (h16)fmaxf(acc[m][r], 0.f);
+    for (int r = 0; r < 16; r += 2) ((uint32_t*)&p[2 * m + (r >> 3)])[(r & 7) >> 1] = relu2(acc[m][r], acc[m][r + 1]);
     if (dst_row) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
-        v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
-        *(h16x4*)(dst_row + 32 * m + 8 * q + 4 * hf) = v;
+        const uint32_t* w = (const uint32_t*)&p[2 * m + (q >> 1)];
+        *(u32x2*)(dst_row + 32 * m + 8 * q + 4 * hf) = (u32x2){w[2 * (q & 1)], w[2 * (q & 1) + 1]};
       }
     }
   }
 }
+// g * relu'(h) on two packed halves without compares or VCC traffic: h comes from relu2 (bits in [0, 0x7fff]), so
+// min_u16(bits, 1) is 1 exactly where h > 0 and the 16-bit integer product with it keeps or clears the gradient bits.
+// (inline asm: LLVM folds every C spelling of this back into compare + select)
+__device__ inline uint32_t mask2(float g0, float g1, uint32_t h) {
+  uint32_t g = cvt_pk(g0, g1), m;
+  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(m) : "v"(h));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(g) : "v"(g), "v"(m));
+  return g;
+}
+// non-finite catcher on packed halves: x * 0 is NaN for inf / NaN, 0 otherwise
+__device__ inline h16x2 nan_fold(h16x2 v, h16x2 acc) { return __builtin_elementwise_fma(v, (h16x2){0, 0}, acc); }
+__device__ inline bool nan_bad(h16x2 acc) { return !((float)acc[0] == 0.f) || !((float)acc[1] == 0.f); }
 
 // ---------------------------------------------------------------- virtual input rows
 // The heads' inputs / output gradients are cheap functions of tensors that already exist (models.py:248-256 plumbing);
@@ -667,22 +693,20 @@ struct InfTrack {
   __device__ inline void see(float g) { mx = fmaxf(mx, fabsf(g)); nanz = fmaf(g, 0.f, nanz); }
   __device__ inline bool bad() const { return !(mx <= 65504.f) || !(nanz == 0.f); }
 };
+// The recompute kernels do not watch the intermediate fp16 gradients for overflow: an inf in dA either dies under the
+// ReLU mask (no effect, as in torch) or reaches dW / d_in as inf / NaN, and those endpoints are checked (GradScaler only
+// ever inspects parameter gradients: torch/amp/grad_scaler.py _unscale_grads_).
 template <int NB>
-__device__ inline bool mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const lds_h16* act_row, int hf) {
-  InfTrack trk;
+__device__ inline void mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const lds_h16* act_row, int hf) {
 #pragma unroll
   for (int m = 0; m < NB; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      h16x4 a = *(const LDS_VEC(h16x4)*)(act_row + 32 * m + 8 * q + 4 * hf);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float g = (a[r] > (h16)0.f) ? acc[m][4 * q + r] : 0.f;
-        trk.see(g);
-        p[2 * m + (q >> 1)][4 * (q & 1) + r] = (h16)g;
-      }
+      const u32x2 a = *(const LDS_VEC(u32x2)*)(act_row + 32 * m + 8 * q + 4 * hf);
+      uint32_t* w = (uint32_t*)&p[2 * m + (q >> 1)];
+      w[2 * (q & 1)] = mask2(acc[m][4 * q], acc[m][4 * q + 1], a.x);
+      w[2 * (q & 1) + 1] = mask2(acc[m][4 * q + 2], acc[m][4 * q + 3], a.y);
     }
-  return trk.bad();
 }
 
 // ---------------------------------------------------------------- fused backward WITH forward recompute
@@ -768,6 +792,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
   f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
   zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
   bool bad = false;
+  h16x2 nanz = {0, 0};
   const int ntiles = (rows + TR - 1) / TR;
   const int srow = wave * 32 + c;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -794,17 +819,17 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
     chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(WL, PW1, 32 * m, ks, lane); },
                          [&](int ks) { return *(const LDS_VEC(h16x8)*)(tO + srow * PO + 16 * ks + 8 * hf); });
     if constexpr (NHID == 2) {
-      bad |= mask_pack_lds<NB>(acc, p, b2 + srow * PH, hf);
+      mask_pack_lds<NB>(acc, p, b2 + srow * PH, hf);
       __syncthreads();                                   // dW_last readers are done with b2 (= h2)
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA2
       __syncthreads();
       dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, wave, lane);
       chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(W1, PW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
-      bad |= mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
+      mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
       __syncthreads();                                   // dW_mid readers are done with b2 / b1
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1
     } else {
-      bad |= mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
+      mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
       write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1 (b2 unused so far)
     }
     __syncthreads();
@@ -822,7 +847,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
             if (f < IN) {
               h16x4 v;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) { v[r] = (h16)o[ib][4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
+              for (int r = 0; r < 4; ++r) v[r] = (h16)o[ib][4 * q + r];
+              nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
               *(h16x4*)(d_in + (size_t)row * IN + f) = v;
             }
           }
@@ -834,6 +860,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      bad |= !(fabsf(a[r]) <= 3.0e38f);
       if (o < OUTL && i < INL && a[r] != 0.f) unsafeAtomicAdd(base + (size_t)o * INL + i, a[r]);
     }
   };
@@ -847,6 +874,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
 #pragma unroll
     for (int b = 0; b < NBLK_FIRST; ++b) { int blk = wave + 4 * b; if (blk < NB * IB) flush(dw_first[b], blk / IB, blk % IB, HID, IN, dW + L.w_off[0]); }
   }
+  bad |= nan_bad(nanz);
   if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
 }
 
@@ -857,7 +885,26 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
 // the register chain (forward recompute + backward data path, ~170 VGPRs), waves 4-7 only accumulate the weight gradients
 // (112 accumulator registers + fragments).  Both fit 256 registers, so the block runs 2 waves per SIMD and the chain wave
 // and the dW wave of a SIMD overlap their MFMA / LDS latencies.
-template <int IN, int HID, int OUT, int NHID>
+// Dev-only phase timing (scripts/dev/probe_bwd_phases.py builds with -DALN_PHASE_TIMING): block 0 accumulates the shader
+// clock spent between consecutive stamps, per role (0 = chain wave 0, 1 = dW wave 4).
+#ifdef ALN_PHASE_TIMING
+__device__ long long g_phase_cycles[2][16];
+extern "C" int aln_debug_read_phases(long long* host_out, int reset) {
+  if (reset) { long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 32);
+}
+#define PT_DECL long long pt_acc[16] = {0}; long long pt_last = clock64();
+#define PT_STAMP(i) { long long pt_now = clock64(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; }
+#define PT_FLUSH(role) if (blockIdx.x == 0 && cw == 0 && lane == 0) { for (int i = 0; i < 16; ++i) g_phase_cycles[role][i] += pt_acc[i]; }
+#else
+#define PT_DECL
+#define PT_STAMP(i)
+#define PT_FLUSH(role)
+#endif
+
+// PF (plain row sources only): the x / dOut chunks of the NEXT tile are requested right after B1 and sit in registers
+// through the whole tile, so the global-load latency (15 % of a tile when exposed) hides behind the MFMA phases.
+template <int IN, int HID, int OUT, int NHID, bool PF>
 __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__ wr_g, size_t wr_halves, RowSrc xs, RowSrc ds,
                                                         int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
                                                         float* __restrict__ dW, int* __restrict__ found_inf) {
@@ -884,16 +931,47 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
   const int srow = cw * 32 + c;
   if (rows_dev) rows = min(rows, *rows_dev);
   const int ntiles = (rows + TR - 1) / TR;
+  constexpr int XCH = IN / 8, OCH = OUT / 8;                       // 8-half chunks per row
+  constexpr int NXS = (TR * XCH + 511) / 512, NOS = (TR * OCH + 511) / 512;
+  h16x8 px[PF ? NXS : 1], po[PF ? NOS : 1];
+  auto prefetch = [&](int r0) {
+    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < NXS; ++q) {
+      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
+      px[q] = (i < TR * XCH && r0 + r < rows) ? *(const h16x8*)(xs.a + (size_t)(r0 + r) * xs.lda + 8 * k) : z;
+    }
+#pragma unroll
+    for (int q = 0; q < NOS; ++q) {
+      const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
+      po[q] = (i < TR * OCH && r0 + r < rows) ? *(const h16x8*)(ds.a + (size_t)(r0 + r) * ds.lda + 8 * k) : z;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int q = 0; q < NXS; ++q) {
+      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
+      if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX0 + r * PX0 + 8 * k) = px[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NOS; ++q) {
+      const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
+      if (i < TR * OCH) *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = po[q];
+    }
+  };
+  if constexpr (PF) { if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x * TR); }
   // The two roles run SEPARATE tile loops with the same barrier sequence (s_barrier only counts arrivals, and the role is
   // wave-uniform), so the register allocator never sees the chain state and the dW accumulators live at the same time.
   if (chain) {
-    bool bad = false;
+    h16x2 nanz = {0, 0};
+    PT_DECL
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int r0 = tile * TR;
-      __syncthreads();                                                   // B0
-      load_tile_src(tX0, PX0, xs, IN, r0, TR, rows);
-      load_tile_src(tO, PO, ds, OUT, r0, TR, rows);
-      __syncthreads();                                                   // B1
+      PT_STAMP(0) __syncthreads(); PT_STAMP(1)   // B0
+      if constexpr (PF) stash();
+      else { load_tile_src(tX0, PX0, xs, IN, r0, TR, rows); load_tile_src(tO, PO, ds, OUT, r0, TR, rows); }
+      PT_STAMP(2) __syncthreads(); PT_STAMP(3)   // B1
+      if constexpr (PF) { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
       f32x16 acc[NB];
       h16x8 p[KS];
       chain_layer<NB, KS0>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); },
@@ -905,20 +983,20 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
         relu_pack_store<NB>(acc, p, nullptr, hf);
         write_packed_tile<NB>(b2, PH, srow, p, hf);
       }
-      __syncthreads();                                                   // B2
+      PT_STAMP(4) __syncthreads(); PT_STAMP(5)   // B2
       chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(WL, PW1, 32 * m, ks, lane); },
                            [&](int ks) { return *(const LDS_VEC(h16x8)*)(tO + srow * PO + 16 * ks + 8 * hf); });
-      bad |= mask_pack_lds<NB>(acc, p, ((NHID == 2) ? b2 : b1) + srow * PH, hf);
-      __syncthreads();                                                   // B3
+      mask_pack_lds<NB>(acc, p, ((NHID == 2) ? b2 : b1) + srow * PH, hf);
+      PT_STAMP(6) __syncthreads(); PT_STAMP(7)   // B3
       if constexpr (NHID == 2) {
         write_packed_tile<NB>(b2, PH, srow, p, hf);                      // dA2 over h2
-        __syncthreads();                                                 // B4
+        PT_STAMP(8) __syncthreads(); PT_STAMP(9)   // B4
         chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(W1, PW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
-        bad |= mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
-        __syncthreads();                                                 // B5
+        mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
+        PT_STAMP(10) __syncthreads(); PT_STAMP(11)   // B5
       }
       write_packed_tile<NB>(b2, PH, srow, p, hf);                        // dA1
-      __syncthreads();                                                   // B6
+      PT_STAMP(12) __syncthreads(); PT_STAMP(13)   // B6
       if (d_in) {
         const int row = r0 + srow;
         f32x16 o[IB];
@@ -931,44 +1009,50 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
               const int f = 32 * ib + 8 * q + 4 * hf;
               if (f < IN) {
                 h16x4 v;
-                InfTrack trk;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = (h16)o[ib][4 * q + r]; trk.see(o[ib][4 * q + r]); }
-                bad |= trk.bad();
+                for (int r = 0; r < 4; ++r) v[r] = (h16)o[ib][4 * q + r];
+                nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
                 *(h16x4*)(d_in + (size_t)row * IN + f) = v;
               }
             }
         }
       }
     }
-    if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
+    PT_FLUSH(0)
+    if (found_inf && __any(nan_bad(nanz)) && lane == 0) atomicOr(found_inf, 1);
   } else {
     MlpLayers L = mlp_layers(IN, HID, OUT, NHID);
     f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
     zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
+    PT_DECL
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int r0 = tile * TR;
-      __syncthreads();                                                   // B0
-      load_tile_src(tX0, PX0, xs, IN, r0, TR, rows);
-      load_tile_src(tO, PO, ds, OUT, r0, TR, rows);
-      __syncthreads();                                                   // B1
-      __syncthreads();                                                   // B2
+      PT_STAMP(0) __syncthreads(); PT_STAMP(1)   // B0
+      if constexpr (PF) stash();
+      else { load_tile_src(tX0, PX0, xs, IN, r0, TR, rows); load_tile_src(tO, PO, ds, OUT, r0, TR, rows); }
+      PT_STAMP(2) __syncthreads(); PT_STAMP(3)   // B1
+      if constexpr (PF) { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
+      PT_STAMP(4) __syncthreads(); PT_STAMP(5)   // B2
       dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, (NHID == 2) ? b2 : b1, PH, cw, lane);
-      __syncthreads();                                                   // B3
+      PT_STAMP(6) __syncthreads(); PT_STAMP(7)   // B3
       if constexpr (NHID == 2) {
-        __syncthreads();                                                 // B4
+        PT_STAMP(8) __syncthreads(); PT_STAMP(9)   // B4
         dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, cw, lane);
-        __syncthreads();                                                 // B5
+        PT_STAMP(10) __syncthreads(); PT_STAMP(11)   // B5
       }
-      __syncthreads();                                                   // B6
+      PT_STAMP(12) __syncthreads(); PT_STAMP(13)   // B6
       dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, b2, PH, tX0, PX0, cw, lane);
     }
+    PT_STAMP(0)
+    PT_FLUSH(1)
     if (dW) {
+      bool bad = false;
       auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, float* base) {
         const int i = 32 * ib + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          bad |= !(fabsf(a[r]) <= 3.0e38f);
           if (o < OUTL && i < INL && a[r] != 0.f) unsafeAtomicAdd(base + (size_t)o * INL + i, a[r]);
         }
       };
@@ -980,6 +1064,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
       }
 #pragma unroll
       for (int b = 0; b < NBLK_FIRST; ++b) { int blk = cw + 4 * b; if (blk < NB * IB) flush(dw_first[b], blk / IB, blk % IB, HID, IN, dW + L.w_off[0]); }
+      if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
     }
   }
 }
@@ -1000,9 +1085,16 @@ static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows
     hipLaunchKernelGGL((k_mlp_bwd_recomp<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wr, halves, xs, ds,
                        rows, rows_dev, (h16*)d_in, dW, found_inf);
   } else {
-    hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_mlp_bwd_recomp8<IN, HID, OUT, NHID>), dim3(g), dim3(512), lds, s, (const h16*)m->wr, halves, xs, ds,
-                       rows, rows_dev, (h16*)d_in, dW, found_inf);
+    static const bool no_pf = getenv("ALN_MLP_BWD_NOPREFETCH") != nullptr;
+    if (xs.mode == SRC_PLAIN && ds.mode == SRC_PLAIN && !no_pf) {
+      hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_mlp_bwd_recomp8<IN, HID, OUT, NHID, true>), dim3(g), dim3(512), lds, s, (const h16*)m->wr, halves, xs,
+                         ds, rows, rows_dev, (h16*)d_in, dW, found_inf);
+    } else {
+      hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_mlp_bwd_recomp8<IN, HID, OUT, NHID, false>), dim3(g), dim3(512), lds, s, (const h16*)m->wr, halves, xs,
+                         ds, rows, rows_dev, (h16*)d_in, dW, found_inf);
+    }
   }
   ALN_CHECK_LAUNCH("mlp_bwd_recomp");
   return 0;

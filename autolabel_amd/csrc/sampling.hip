@@ -12,6 +12,42 @@
 
 #define MAX_S 1024  // max samples per ray per pass
 
+// ------------------------------------------------------------------ near/far vs the [-bound, bound]^3 box
+// (torch-ngp raymarching.near_far_from_aabb; a miss gives near = far = min_near) -- oracle: OracleModel.near_far
+__device__ inline void ray_aabb(const float* o3, const float* d3, float bound, float min_near, float& near, float& far) {
+  float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float o = o3[k], d = d3[k];
+    float inv = __fdiv_rn(1.0f, d);
+    float t1 = __fmul_rn(__fsub_rn(-bound, o), inv), t2 = __fmul_rn(__fsub_rn(bound, o), inv);
+    tn = fmaxf(tn, fminf(t1, t2));
+    tf = fminf(tf, fmaxf(t1, t2));
+  }
+  bool miss = !(tn <= tf);
+  near = miss ? min_near : fmaxf(tn, min_near);
+  far = fmaxf(miss ? min_near : tf, near);
+}
+
+__global__ void k_ray_aabb(const float* __restrict__ ro, const float* __restrict__ rd, int N, float bound, float min_near,
+                           float* __restrict__ nears, float* __restrict__ fars) {
+  for (int ray = blockIdx.x * blockDim.x + threadIdx.x; ray < N; ray += gridDim.x * blockDim.x) {
+    float near, far;
+    ray_aabb(ro + 3 * (size_t)ray, rd + 3 * (size_t)ray, bound, min_near, near, far);
+    nears[ray] = near; fars[ray] = far;
+  }
+}
+
+extern "C" int aln_ray_aabb(const float* rays_o, const float* rays_d, int32_t N, float bound, float min_near, float* nears,
+                            float* fars, void* stream) {
+  ALN_REQUIRE(rays_o && rays_d && nears && fars, "ray_aabb: NULL pointer");
+  if (N <= 0) return 0;
+  hipLaunchKernelGGL(k_ray_aabb, dim3(aln_grid_for(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, N, bound,
+                     min_near, nears, fars);
+  ALN_CHECK_LAUNCH("ray_aabb");
+  return 0;
+}
+
 // ------------------------------------------------------------------ coarse
 __global__ void k_sample_coarse(const float* __restrict__ ro, const float* __restrict__ rd, int N, int S1, float bound,
                                 float min_near, int perturb, uint32_t key, const float* __restrict__ noise,
@@ -19,19 +55,8 @@ __global__ void k_sample_coarse(const float* __restrict__ ro, const float* __res
   size_t total = (size_t)N * S1;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     int ray = (int)(t / S1), i = (int)(t % S1);
-    float tn = -INFINITY, tf = INFINITY;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float o = ro[3 * (size_t)ray + k], d = rd[3 * (size_t)ray + k];
-      float inv = __fdiv_rn(1.0f, d);
-      float t1 = __fmul_rn(__fsub_rn(-bound, o), inv), t2 = __fmul_rn(__fsub_rn(bound, o), inv);
-      tn = fmaxf(tn, fminf(t1, t2));
-      tf = fminf(tf, fmaxf(t1, t2));
-    }
-    bool miss = !(tn <= tf);
-    float near = miss ? min_near : fmaxf(tn, min_near);
-    float far = miss ? min_near : tf;
-    far = fmaxf(far, near);
+    float near, far;
+    ray_aabb(ro + 3 * (size_t)ray, rd + 3 * (size_t)ray, bound, min_near, near, far);
     if (i == 0) { nears[ray] = near; fars[ray] = far; }
     float lin = __fdiv_rn((float)i, (float)(S1 > 1 ? S1 - 1 : 1));
     float span = __fsub_rn(far, near);

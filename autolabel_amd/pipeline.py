@@ -150,7 +150,17 @@ class HipPipeline:
         self.density_scale, self.min_near = float(density_scale), float(min_near)
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
         self.recompute = True  # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward)
-        self.kernel_events = None  # bench.py: list of (start, end) HIP events around the dominant kernel's launches
+        self.kernel_events = None  # bench.py: list of ((start, end) HIP events, kernel, tag) around the timed launches
+
+    def _k(self, name, *args, tag=None):
+        """H.call with optional HIP-event timing on the launch stream (bench.py sets kernel_events = [])."""
+        if self.kernel_events is None:
+            return H.call(name, *args)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        H.call(name, *args)
+        ev[1].record()
+        self.kernel_events.append((ev, name, tag))
 
     # ---- library-GEMM heads (MlpSpec.lib): y = relu(x W0^T) ... ; fp16 operands, fp32 accumulate (hipBLASLt)
     def _lib_fwd(self, k, x, save):
@@ -186,8 +196,8 @@ class HipPipeline:
         H.call('aln_encode_fwd', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows,
                stride, H.ptr(enc), H.stream())
         save = train and not self.recompute
-        H.call('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, H.ptr(h1) if save else None,
-               H.ptr(h2) if save else None, H.ptr(out), H.stream())
+        self._k('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, H.ptr(h1) if save else None,
+                H.ptr(h2) if save else None, H.ptr(out), H.stream(), tag=('sigma', rows))
         H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sigma), H.stream())
 
     def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
@@ -240,8 +250,8 @@ class HipPipeline:
         cout = c['color_out'] = g('color_out', (M, cs.out_pad), f16)
         H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G,
                cs.in_pad, H.ptr(cin), H.stream())
-        H.call('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if save else None,
-               H.ptr(ch2) if save else None, H.ptr(cout), H.stream())
+        self._k('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if save else None,
+                H.ptr(ch2) if save else None, H.ptr(cout), H.stream(), tag=('color', n_live))
         logits = feat = None
         if want_semantic:
             fs, os_ = nets['semf'], nets['semo']
@@ -249,8 +259,8 @@ class HipPipeline:
             if c['sem_fused']:  # inputs are built inside the kernels from sigma_out / f (no semf_in / semo_in tensors)
                 feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
                 logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
-                H.call('aln_sem_heads_fwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sout), M, L.D, L.G,
-                       H.ptr(feat), H.ptr(logits), H.stream())
+                self._k('aln_sem_heads_fwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sout), M, L.D, L.G,
+                        H.ptr(feat), H.ptr(logits), H.stream(), tag=('sem', M))
             else:
                 fin = c['semf_in'] = g('semf_in', (M, fs.in_pad), f16)
                 oin = c['semo_in'] = g('semo_in', (M, os_.in_pad), f16)
@@ -309,15 +319,15 @@ class HipPipeline:
         hp = (lambda t: None) if rc else H.ptr   # saved activations are not passed on the recompute path
         dA1, dA2 = (None, None) if rc else (g('dA1', (M, 128), f16), g('dA2', (M, 128), f16))
         d_cin = g('d_color_in', (M, cs.in_pad), f16)
-        H.call('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), hp(c['ch1']), hp(c['ch2']), H.ptr(d_cout),
-               M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream())
+        self._k('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), hp(c['ch1']), hp(c['ch2']), H.ptr(d_cout),
+                M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream(), tag=('color', c['n_live']))
         d_fin = d_oin = None
         if sem_fused:
             fs, os_ = nets['semf'], nets['semo']
             d_oin, d_fin = g('d_semo_in', (M, os_.in_pad), f16), g('d_semf_in', (M, fs.in_pad), f16)
-            H.call('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),
-                   H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_oin), H.ptr(d_fin),
-                   gp('semf'), gp('semo'), fi, H.stream())
+            self._k('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),
+                    H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_oin), H.ptr(d_fin),
+                    gp('semf'), gp('semo'), fi, H.stream(), tag=('sem', M))
         elif sem:
             fs, os_ = nets['semf'], nets['semo']
             if os_.lib:
@@ -337,14 +347,9 @@ class HipPipeline:
         H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), nets['semo'].in_pad, L.D,
                H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
         d_enc = g('d_enc', (M, e.enc_pad), f16)
-        H.call('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
-               H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream())
+        self._k('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
+                H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
         for (zz, rows, stride, de) in [(z, M1, S1, d_enc)] + ([(z[M1:], N * S2, S2, d_enc[M1:])] if S2 > 0 else []):
-            if self.kernel_events is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de), H.ptr(P.grad), H.stream())
-            if self.kernel_events is not None:
-                ev[1].record()
-                self.kernel_events.append((ev, rows))
+            self._k('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de), H.ptr(P.grad),
+                    H.stream(), tag=rows)

@@ -132,6 +132,7 @@ def main():
     sync()
     dt = time.time() - t0
     events, eng.pipe.kernel_events = eng.pipe.kernel_events, None
+    live_rows = float(eng.pipe.ws.get('n_live', (1,), torch.int32).item())   # color-head rows of the last step (w > 1e-4)
     if world > 1:
         t = torch.tensor([dt], device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -175,8 +176,9 @@ def main():
         # + the d_enc row (enc_pad x 2 B) + z (4 B).
         L = eng.L
         per_row = L.enc.grid.n_levels * 8 * 2 * 4 + L.enc.enc_pad * 2 + 4
-        durs = [e[0].elapsed_time(e[1]) * 1e-3 for e, _ in events]
-        rows = [r for _, r in events]
+        enc_ev = [(e, t) for e, n, t in events if n == 'aln_encode_bwd']
+        durs = [e[0].elapsed_time(e[1]) * 1e-3 for e, _ in enc_ev]
+        rows = [r for _, r in enc_ev]
         avg_s = sum(durs) / len(durs)
         achieved = per_row * (sum(rows) / len(rows)) / avg_s / 1e9
         traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
@@ -191,6 +193,27 @@ def main():
                            'note': 'scatter of 2x fp32 atomics per corner: bound by the atomic request rate (~21 G 64-byte '
                                    'requests/s measured, scripts/dev/probe_atomics3.hip), not by HBM bytes; traffic = '
                                    '(FETCH_SIZE + WRITE_SIZE) KB * 1024 from profiles/r01_pmc_summary.json'}
+        # second regime: the MLP heads against the dense fp16 MFMA peak.  Algorithmic FLOPs = 2 x MAC per
+        # evaluated sample forward, 4 x MAC backward (data + weight gradients), unpadded widths; the forward recompute
+        # inside the backward kernels is extra work, not counted.  Live rows of the color head are the device counter.
+        def macs(k):
+            m = L.nets[k]
+            return m.n_in * m.hidden + (m.n_hidden - 1) * m.hidden * m.hidden + m.hidden * m.n_out
+        mac = {'sigma': macs('sigma'), 'color': macs('color'), 'sem': macs('semf') + macs('semo')}
+        flops = t_mlp = 0.0
+        for e, n, t in events:
+            if n == 'aln_encode_bwd':
+                continue
+            head, r = t
+            if torch.is_tensor(r):
+                r = live_rows   # the device counter is reused every step; the last step's value stands for all
+            flops += (2.0 if n.endswith('_fwd') else 4.0) * mac[head] * r
+            t_mlp += e[0].elapsed_time(e[1]) * 1e-3
+        if t_mlp > 0:
+            res['roofline_mlp'] = {'kernels': 'k_mlp_fwd + k_mlp_bwd_recomp8 (all heads)', 'bound': 'mfma',
+                                   'achieved': flops / t_mlp / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                   'frac': flops / t_mlp / 1e12 / 2500.0, 'us_per_step': t_mlp * 1e6 / args.steps,
+                                   'algorithmic_gflop_per_step': flops / 1e9 / args.steps, 'live_color_rows': live_rows}
         if not args.no_cpu_baseline and world == 1:
             lo, hi = scene['min_bounds'], scene['max_bounds']
             v, sample = cpu_baseline(None, args.feature_dim, scene['n_classes'], float(((hi - lo) - (lo + hi) * 0.5).max()))

@@ -103,6 +103,9 @@ int aln_compute_direction(const float* R_WC, const int64_t* idx, int32_t n, int3
                           double cx, double cy, const float* jitter, float* dirs, float* norms, void* stream);
 
 /* ---- sampling: torch-ngp NeRFRenderer.run reached from autolabel/trainer.py:64-70 */
+/* near/far of each ray against [-bound,bound]^3 (raymarching.near_far_from_aabb; a miss gives near = far = min_near) */
+int aln_ray_aabb(const float* rays_o, const float* rays_d, int32_t N, float bound, float min_near, float* nears,
+                 float* fars, void* stream);
 int aln_sample_coarse(const float* rays_o, const float* rays_d, int32_t N, int32_t S1, float bound, float min_near,
                       int32_t perturb, uint32_t seed, uint32_t step, const float* noise /*[N,S1] or NULL*/,
                       float* nears, float* fars, float* z /*[N,S1]*/, void* stream);
@@ -148,6 +151,8 @@ int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void
 int aln_sigma_act(const void* sigma_out /*[rows,16] f16*/, int32_t rows, float* sigma, void* stream);
 int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx, int32_t* cidx_row,
                      void* stream);
+/* tcnn SphericalHarmonics(degree 4) of the remapped direction (autolabel/models.py:97-103,205-207): out[r, 0:16] f16 */
+int aln_sh4(const float* dirs /*[rows,3]*/, int32_t rows, int32_t out_pitch /*halves, >= 16*/, void* out, void* stream);
 int aln_build_color_in(const int32_t* live_idx, const int32_t* n_live, int32_t max_rows, const float* rays_d,
                        const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out, int32_t G, int32_t in_pad,
                        void* color_in, void* stream);

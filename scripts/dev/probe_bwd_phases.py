@@ -1,0 +1,58 @@
+"""Where do the cycles of k_mlp_bwd_recomp8 go?  Builds mlp.hip with -DALN_PHASE_TIMING (clock64 stamps around every
+barrier, block 0, chain wave 0 and dW wave 4) into scripts/dev/_build/ and prints cycles per phase and tile.
+
+  python scripts/dev/probe_bwd_phases.py build     # here (hipcc cross-compiles)
+  python scripts/dev/probe_bwd_phases.py [head]    # on the GPU box
+"""
+import sys, os, subprocess, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'scripts', 'dev', '_build', 'libaln_timing.so')
+if len(sys.argv) > 1 and sys.argv[1] == 'build':
+    from autolabel_amd import build as B
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES if os.path.exists(os.path.join(B.CSRC, s))]
+    subprocess.run(['hipcc'] + B.FLAGS + ['-DALN_PHASE_TIMING'] + srcs + ['-o', OUT], check=True)
+    sys.exit(0)
+import torch
+from autolabel_amd import hip as H
+H.LIB = OUT          # load the instrumented build instead of the product library
+from autolabel_amd.pipeline import ModelLayout, Params
+head = sys.argv[1] if len(sys.argv) > 1 else 'sigma'
+rows = 1 << 20
+L = ModelLayout('hg+freq', 15, 128, 128, 64, 7, bound=6.0)
+P = Params(L, 'cuda'); P.init_(0)
+m = L.nets[head]
+x = torch.randn(rows, m.in_pad, device='cuda').half()
+d_out = (torch.randn(rows, m.out_pad, device='cuda') * 0.01).half()
+d_in = torch.empty(rows, m.in_pad, device='cuda', dtype=torch.float16)
+flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+grad = torch.zeros_like(P.grad)
+gp = C.c_void_p(grad.data_ptr() + 4 * L.offsets[head])
+def run():
+    H.call('aln_mlp_bwd', C.byref(P.descs[head]), H.ptr(x), None, None, H.ptr(d_out), rows, None, None, None, H.ptr(d_in), gp,
+           H.ptr(flag), H.stream())
+lib = H.lib()
+lib.aln_debug_read_phases.argtypes = [C.c_void_p, C.c_int]
+for _ in range(3): run()
+torch.cuda.synchronize()
+lib.aln_debug_read_phases(None, 1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 5
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+buf = (C.c_longlong * 32)()
+lib.aln_debug_read_phases(buf, 0)
+us = e0.elapsed_time(e1) / reps * 1e3
+ntiles = rows // 128
+nblk = min(ntiles, torch.cuda.get_device_properties(0).multi_processor_count)
+iters = (ntiles + nblk - 1) // nblk * reps
+print(f'{head}: {us:.0f} us per launch, {iters // reps} tiles per block')
+names = ['tail(d_in/dW_first)', 'wait B0', 'load issue', 'wait B1', 'fwd recompute', 'wait B2', 'last layer', 'wait B3',
+         'write dA2', 'wait B4', 'mid layer', 'wait B5', 'write dA1', 'wait B6']
+for role, rn in [(0, 'chain wave 0'), (1, 'dW wave 4')]:
+    v = [buf[role * 16 + i] / iters for i in range(16)]
+    print(f'-- {rn}: {sum(v):.0f} clock ticks per tile')
+    for i, n in enumerate(names):
+        print(f'   {n:22s} {v[i]:8.0f}')

@@ -359,6 +359,31 @@ def test_sample_coarse_bit_exact(H):
     assert torch.equal(zz.cpu(), z + (u - 0.5) * ((far - near)[:, None] / np.float32(S1)))
 
 
+def test_ray_aabb_bit_exact(H):
+    N, bound = 300, 1.3
+    o, d = _rays(N, bound=bound)
+    m = O.OracleModel(O.ModelConfig(bound=bound, grid=O.GridSpec(n_levels=2)))
+    near, far = m.near_far(o, d)
+    od_, dd_ = o.cuda(), d.cuda()
+    nears, fars = torch.empty(N, device='cuda'), torch.empty(N, device='cuda')
+    H.call('aln_ray_aabb', H.ptr(od_), H.ptr(dd_), N, bound, 0.2, H.ptr(nears), H.ptr(fars), H.stream())
+    assert torch.equal(nears.cpu(), near) and torch.equal(fars.cpu(), far)
+    assert nears[0].item() == fars[0].item() == np.float32(0.2)   # the miss ray
+
+
+def test_sh4_matches_oracle(H):
+    g = torch.Generator().manual_seed(5)
+    d = torch.nn.functional.normalize(torch.randn(1000, 3, generator=g), dim=1)
+    want = O.sh4_encode((d + 1) / 2)
+    dd_ = d.cuda()
+    out = torch.zeros(1000, 32, dtype=torch.float16, device='cuda')
+    H.call('aln_sh4', H.ptr(dd_), 1000, 32, H.ptr(out), H.stream())
+    got = out.cpu().float()
+    assert torch.all(got[:, 16:] == 0)
+    # fp16 output of an fp32 polynomial: one half-ulp of rounding on top of a few fp32 ulps of evaluation-order freedom
+    assert (got[:, :16] - want).abs().max().item() <= 2.0 ** -11 * 3.0
+
+
 @pytest.mark.parametrize('perturb', [0, 1])
 def test_sample_fine_matches_sample_pdf(H, perturb):
     N, S1, S2 = 40, 128, 128
