@@ -17,6 +17,23 @@
 typedef __attribute__((address_space(3))) h16 lds_h16;   // LDS-typed element: ds_* with 32-bit addresses + immediate offsets
 #define LDS_VEC(T) __attribute__((address_space(3))) T
 
+// ---------------------------------------------------------------- LDS tile layouts
+// Measured (scripts/dev/probe_lds_banks.hip, probe_mfma_rate.hip; SQ_LDS_BANK_CONFLICT = 61 % of the LDS cycles with rows
+// padded to W + 8 halves): a ds_read_b64_tr_b16 fragment read ran 4-way bank-conflicted (its 32-lane group touches 4 rows x
+// 16 dwords and the rows started 4 banks apart), row-per-lane 8-byte accesses 2-way, and the ds_read2_b64 the compiler
+// forms from two adjacent 8-byte pieces costs 16 LDS cycles -- the MFMA phases were LDS-bound at 70-130 cycles per MFMA.
+// Row pitches of the hidden-width tiles and matrices are therefore chosen by exhaustive search over the bank model
+// (MI355X_MICROARCH.md, LDS): 148 halves for W = 128 and 68 for W = 64 make row-per-lane 8-byte reads and writes
+// conflict-free and leave the transpose reads 2-way -- half the LDS cycles, with plain base + immediate addressing (an
+// XOR/rotate swizzle reaches conflict-free transpose reads too but costs one address register per fragment: it spilled).
+__host__ __device__ constexpr int hid_pitch(int hid) { return hid == 128 ? 148 : hid + 4; }
+template <class TP>
+struct PlainV {   // [rows][pitch] row-major
+  TP p; int pitch;
+  __device__ inline TP at(int row, int col) const { return p + row * pitch + col; }
+};
+template <class TP> __device__ inline PlainV<TP> plainv(TP p, int pitch) { return PlainV<TP>{p, pitch}; }
+
 // ---------------------------------------------------------------- fragment bookkeeping
 struct MlpLayers {
   int n;          // number of weight matrices (n_hidden + 1)
@@ -52,16 +69,18 @@ extern "C" int64_t aln_mlp_frag_halves(int32_t in_pad, int32_t hidden, int32_t o
   return (int64_t)frags * 512;
 }
 
-// row-major fp16 copy W_l[out][in + 8] (pitch padded by 8 halves): read straight for forward fragments and through
-// ds_read_b64_tr_b16 for the transposed (backward) fragments -- one LDS image serves both directions.
+// row-major fp16 copy of the weights: read straight for forward fragments and through ds_read_b64_tr_b16 for the transposed
+// (backward) fragments -- one LDS image serves both directions.  W_0 is [out][in + 8] (pitch padded by 8 halves); the
+// matrices whose input is the hidden layer are [out][hid_pitch(hid)].
+__host__ __device__ inline int wrow_pitch(const MlpLayers& L, int l) { return l == 0 ? L.in_[0] + 8 : hid_pitch(L.in_[l]); }
 __host__ __device__ inline size_t wrow_off(const MlpLayers& L, int l) {
-  size_t o = 0; for (int i = 0; i < l; ++i) o += (size_t)L.out_[i] * (L.in_[i] + 8); return o;
+  size_t o = 0; for (int i = 0; i < l; ++i) o += (size_t)L.out_[i] * wrow_pitch(L, i); return o;
 }
 __global__ void k_mlp_rowmajor(const float* __restrict__ w, MlpLayers L, h16* __restrict__ wr) {
   size_t total = wrow_off(L, L.n);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     int l = 0; while (l + 1 < L.n && i >= wrow_off(L, l + 1)) ++l;
-    size_t e = i - wrow_off(L, l); int pitch = L.in_[l] + 8; int o = (int)(e / pitch), k = (int)(e % pitch);
+    size_t e = i - wrow_off(L, l); int pitch = wrow_pitch(L, l); int o = (int)(e / pitch), k = (int)(e % pitch);
     wr[i] = (h16)(k < L.in_[l] ? w[L.w_off[l] + (size_t)o * L.in_[l] + k] : 0.f);
   }
 }
@@ -468,16 +487,15 @@ __global__ __launch_bounds__(256) void k_dw_gemm(const h16* __restrict__ dA, int
 // once at the end: no per-layer dA round trip through HBM and no separate dW GEMM launches.
 typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4v* lds_s16x4_ptr;
-template <class TP>
-__device__ inline h16x8 tr_frag(TP tile, int pitch, int col0, int ks, int lane) {
+template <class TV>
+__device__ inline h16x8 tr_frag(TV t, int col0, int ks, int lane) {
   // operand fragment for mfma 32x32x16: lane (i = lane&31, hf = lane>>5) gets tile[16ks + 8hf + 0..7][col0 + i].
   // (the builtin lets the compiler count lgkmcnt itself, so several fragment reads stay in flight)
   const int hf = lane >> 5;
   const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
   const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  auto p0 = tile + row * pitch + col;
-  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
-  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 4 * pitch));
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row, col));
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row + 4, col));
   union { struct { s16x4v l, h; } s; h16x8 v; } u;
   u.s.l = lo; u.s.h = hi;
   return u.v;
@@ -495,8 +513,8 @@ __device__ inline void load_tile(h16* tile, int pitch, const h16* g, int ncols, 
 
 // dW accumulate over the block tile: wave owns C-blocks blk = wave + 4b (blk -> (ob, ib) = (blk / NIB, blk % NIB)).
 // When 4 % NIB == 0 the input block ib is the same for all owned blocks, so its fragment is fetched once per k-step.
-template <int NBLK, int NOB, int NIB, class TPA, class TPB>
-__device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], TPA tA, int pA, TPB tB, int pB, int wave, int lane) {
+template <int NBLK, int NOB, int NIB, class TVA, class TVB>
+__device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], TVA tA, TVB tB, int wave, int lane) {
   constexpr bool IB_CONST = (4 % NIB) == 0;
   constexpr int NBF = IB_CONST ? 1 : NBLK;
   h16x8 a[2][NBLK], bq[2][NBF];
@@ -505,11 +523,11 @@ __device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], TPA tA, int pA, TPB tB,
     for (int b = 0; b < NBLK; ++b) {
       const int blk = wave + 4 * b;
       if (blk < NOB * NIB) {
-        a[slot][b] = tr_frag(tA, pA, 32 * (blk / NIB), ks, lane);
-        if (!IB_CONST) bq[slot][b < NBF ? b : 0] = tr_frag(tB, pB, 32 * (blk % NIB), ks, lane);
+        a[slot][b] = tr_frag(tA, 32 * (blk / NIB), ks, lane);
+        if (!IB_CONST) bq[slot][b < NBF ? b : 0] = tr_frag(tB, 32 * (blk % NIB), ks, lane);
       }
     }
-    if (IB_CONST) bq[slot][0] = tr_frag(tB, pB, 32 * (wave % NIB), ks, lane);
+    if (IB_CONST) bq[slot][0] = tr_frag(tB, 32 * (wave % NIB), ks, lane);
   };
   fetch(0, 0);
 #pragma unroll
@@ -559,7 +577,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_fused(const h16* __restrict__ w
     load_tile(tX, PX, hl, HID, r0, TR, rows);
     __syncthreads();
     // ---- dW_last[o][i] += dOut^T . h_last
-    dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, tX, PX, wave, lane);
+    dw_accumulate<NBLK_LAST, OB, NB>(dw_last, plainv(tO, PO), plainv(tX, PX), wave, lane);
     // ---- chain: dA_last = relu'(h_last) * (W_last^T dOut)
     f32x16 acc[NB];
     zero_acc(acc);
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_fused(const h16* __restrict__ w
         }
       load_tile(tX, PX, h1, HID, r0, TR, rows);
       __syncthreads();
-      dw_accumulate<NBLK_MID, NB, NB>(dw_mid, tD, PD, tX, PX, wave, lane);
+      dw_accumulate<NBLK_MID, NB, NB>(dw_mid, plainv(tD, PD), plainv(tX, PX), wave, lane);
       zero_acc(acc);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -603,7 +621,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_fused(const h16* __restrict__ w
     load_tile(tX, PX, x, IN, r0, TR, rows);
     // columns IN..32*IB-1 of the last C-block read whatever follows in LDS: they only reach dW columns >= IN, which are never flushed
     __syncthreads();
-    dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, tD, PD, tX, PX, wave, lane);
+    dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, plainv(tD, PD), plainv(tX, PX), wave, lane);
     if (d_in) {
       const int row = r0 + srow;
 #pragma unroll
@@ -680,9 +698,13 @@ __device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
 #pragma unroll
       for (int m = 0; m < NB; ++m) a[(ks + 1) & 1][m] = frag(m, ks + 1);
     }
+    // pin the order: left alone, the machine scheduler turns this into NB dependent accumulator chains with one
+    // "ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma" round trip per MFMA (~80 cycles each instead of 32)
+    __builtin_amdgcn_sched_barrier(0);
     h16x8 b = bop(ks);
 #pragma unroll
     for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b, ks == 0 ? zero : acc[m]);   // C = 0 inline: no accumulator zeroing
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // relu'(h) mask read back from the LDS tile holding h (C-layout 8-byte chunks)
@@ -696,16 +718,21 @@ struct InfTrack {
 // The recompute kernels do not watch the intermediate fp16 gradients for overflow: an inf in dA either dies under the
 // ReLU mask (no effect, as in torch) or reaches dW / d_in as inf / NaN, and those endpoints are checked (GradScaler only
 // ever inspects parameter gradients: torch/amp/grad_scaler.py _unscale_grads_).
-template <int NB>
-__device__ inline void mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const lds_h16* act_row, int hf) {
+template <int NB, class TV>
+__device__ inline void mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], TV t, int srow, int hf) {
+  u32x2 a[NB][4];   // all activation reads go out first (one LDS latency for the layer, not one per 8 bytes)
+#pragma unroll
+  for (int m = 0; m < NB; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[m][q] = *(const LDS_VEC(u32x2)*)t.at(srow, 32 * m + 8 * q + 4 * hf);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int m = 0; m < NB; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const u32x2 a = *(const LDS_VEC(u32x2)*)(act_row + 32 * m + 8 * q + 4 * hf);
       uint32_t* w = (uint32_t*)&p[2 * m + (q >> 1)];
-      w[2 * (q & 1)] = mask2(acc[m][4 * q], acc[m][4 * q + 1], a.x);
-      w[2 * (q & 1) + 1] = mask2(acc[m][4 * q + 2], acc[m][4 * q + 3], a.y);
+      w[2 * (q & 1)] = mask2(acc[m][4 * q], acc[m][4 * q + 1], a[m][q].x);
+      w[2 * (q & 1) + 1] = mask2(acc[m][4 * q + 2], acc[m][4 * q + 3], a[m][q].y);
     }
 }
 
@@ -715,15 +742,14 @@ __device__ inline void mask_pack_lds(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], cons
 // 2*HID*NHID + IN + OUT halves read to IN + OUT (sigma head: 770 -> 224 B), which turns the kernel from latency/HBM bound
 // into MFMA bound.  Weights live in LDS ONCE, row-major: forward fragments are plain reads, transposed (backward)
 // fragments come from ds_read_b64_tr_b16.
-template <class TP>
-__device__ inline h16x8 tr_frag_chained(TP tile, int pitch, int col0, int ks, int lane) {
+template <class TV>
+__device__ inline h16x8 tr_frag_chained(TV t, int col0, int ks, int lane) {
   // as tr_frag, but the 8 rows follow the chained k-order of the register chain: base + 8*(j>>2) + 4*hf + (j&3)
   const int hf = lane >> 5;
   const int row = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * hf + ((lane & 15) >> 2);
   const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  auto p0 = tile + row * pitch + col;
-  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
-  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 8 * pitch));
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row, col));
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row + 8, col));
   union { struct { s16x4v l, h; } s; h16x8 v; } u;
   u.s.l = lo; u.s.h = hi;
   return u.v;
@@ -732,152 +758,29 @@ __device__ inline h16x8 tr_frag_chained(TP tile, int pitch, int col0, int ks, in
 __device__ inline h16x8 fwd_frag_natural(const lds_h16* W, int pitch, int mb, int ks, int lane) {
   return *(const LDS_VEC(h16x8)*)(W + (32 * mb + (lane & 31)) * pitch + 16 * ks + 8 * (lane >> 5));
 }
-__device__ inline h16x8 fwd_frag_chained(const lds_h16* W, int pitch, int mb, int ks, int lane) {
-  const lds_h16* p0 = W + (32 * mb + (lane & 31)) * pitch + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (lane >> 5);
-  h16x4 a = *(const LDS_VEC(h16x4)*)p0, b = *(const LDS_VEC(h16x4)*)(p0 + 8);
-  h16x8 r; r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
+// chained k-order: two 8-byte pieces 8 halves apart, read as two ds_read_b64 (never one ds_read2_b64: 8+ LDS cycles and
+// 32-bank conflicts against 2 x 2 conflict-free cycles)
+template <class TV>
+__device__ inline h16x8 fwd_frag_chained(TV W, int mb, int ks, int lane) {
+  const int row = 32 * mb + (lane & 31), col = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (lane >> 5);
+  union { struct { u32x2 a, b; } s; h16x8 v; } u;
+  auto p0 = W.at(row, col);
+  auto p1 = W.at(row, col + 8);
+  asm volatile("" : "+v"(p1));   // opaque: keeps the two reads from being fused into one ds_read2_b64
+  u.s.a = *(const LDS_VEC(u32x2)*)p0;
+  u.s.b = *(const LDS_VEC(u32x2)*)p1;
+  return u.v;
 }
-template <int NB>
-__device__ inline void write_packed_tile(lds_h16* tile, int pitch, int srow, const h16x8 (&p)[2 * NB], int hf) {
+template <int NB, class TV>
+__device__ inline void write_packed_tile(TV t, int srow, const h16x8 (&p)[2 * NB], int hf) {
 #pragma unroll
   for (int m = 0; m < NB; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
-      v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
-      *(LDS_VEC(h16x4)*)(tile + srow * pitch + 32 * m + 8 * q + 4 * hf) = v;
+      const uint32_t* w = (const uint32_t*)&p[2 * m + (q >> 1)];
+      *(LDS_VEC(u32x2)*)t.at(srow, 32 * m + 8 * q + 4 * hf) = (u32x2){w[2 * (q & 1)], w[2 * (q & 1) + 1]};
     }
 }
-// relu'(h) mask taken from the packed forward activations (registers) instead of a saved tensor
-template <int NB>
-__device__ inline bool mask_pack_regs(f32x16 (&acc)[NB], h16x8 (&p)[2 * NB], const h16x8 (&hact)[2 * NB]) {
-  bool bad = false;
-#pragma unroll
-  for (int m = 0; m < NB; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float g = ((float)hact[2 * m + (r >> 3)][r & 7] > 0.f) ? acc[m][r] : 0.f;
-      h16 gh = (h16)g;
-      bad |= !(fabsf((float)gh) <= 65504.f);
-      p[2 * m + (r >> 3)][r & 7] = gh;
-    }
-  return bad;
-}
-
-template <int IN, int HID, int OUT, int NHID>
-__global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ wr_g, size_t wr_halves, RowSrc xs, RowSrc ds,
-                                                       int rows, const int* __restrict__ rows_dev,
-                                                       h16* __restrict__ d_in, float* __restrict__ dW, int* __restrict__ found_inf) {
-  constexpr int NB = HID / 32, KS = HID / 16, KS0 = IN / 16, KSO = OUT / 16, IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
-  constexpr int PW0 = IN + 8, PW1 = HID + 8;                       // weight pitches
-  constexpr int PH = HID + 8, PX0 = IB * 32 + 8, PO = OB * 32 + 8;  // tile pitches
-  constexpr int TR = 128;
-  constexpr int NBLK_LAST = (OB * NB + 3) / 4, NBLK_MID = (NB * NB + 3) / 4, NBLK_FIRST = (NB * IB + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  lds_h16* wl = (lds_h16*)smem;
-  lds_h16* W0 = wl;                                    // [HID][IN+8]
-  lds_h16* W1 = W0 + HID * PW0;                        // [HID][HID+8]   (NHID == 2)
-  lds_h16* WL = (NHID == 2) ? W1 + HID * PW1 : W1;     // [OUT][HID+8]
-  lds_h16* tX0 = wl + (int)((wr_halves + 7) & ~(size_t)7);  // x tile        [TR][PX0]
-  lds_h16* b1 = tX0 + TR * PX0;                        // h1            [TR][PH]
-  lds_h16* b2 = b1 + TR * PH;                          // h2 / dA tiles [TR][PH]
-  lds_h16* tO = b2 + TR * PH;                          // dOut tile     [TR][PO]
-  copy_to_lds((h16*)smem, wr_g, wr_halves);
-  for (int i = threadIdx.x; i < TR * (PX0 + PO); i += 256) { if (i < TR * PX0) tX0[i] = (h16)0.f; else tO[i - TR * PX0] = (h16)0.f; }
-  const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: uniform branches in the dW block loops
-  if (rows_dev) rows = min(rows, *rows_dev);
-  MlpLayers L = mlp_layers(IN, HID, OUT, NHID);
-  f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
-  zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
-  bool bad = false;
-  h16x2 nanz = {0, 0};
-  const int ntiles = (rows + TR - 1) / TR;
-  const int srow = wave * 32 + c;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int r0 = tile * TR;
-    __syncthreads();
-    load_tile_src(tX0, PX0, xs, IN, r0, TR, rows);
-    load_tile_src(tO, PO, ds, OUT, r0, TR, rows);
-    __syncthreads();
-    // ---------------- forward recompute: h1 (and h2) go through registers into LDS tiles (dW operands + relu masks)
-    f32x16 acc[NB];
-    h16x8 p[KS];
-    chain_layer<NB, KS0>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); },
-                         [&](int ks) { return *(const LDS_VEC(h16x8)*)(tX0 + srow * PX0 + 16 * ks + 8 * hf); });
-    relu_pack_store<NB>(acc, p, nullptr, hf);
-    write_packed_tile<NB>(b1, PH, srow, p, hf);
-    if constexpr (NHID == 2) {
-      chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(W1, PW1, m, ks, lane); }, [&](int ks) { return p[ks]; });
-      relu_pack_store<NB>(acc, p, nullptr, hf);
-      write_packed_tile<NB>(b2, PH, srow, p, hf);
-    }
-    __syncthreads();
-    // ---------------- last layer: dW_last += dOut^T . h_last ; dA_last = relu'(h_last) * (W_last^T dOut)
-    dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, (NHID == 2) ? b2 : b1, PH, wave, lane);
-    chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(WL, PW1, 32 * m, ks, lane); },
-                         [&](int ks) { return *(const LDS_VEC(h16x8)*)(tO + srow * PO + 16 * ks + 8 * hf); });
-    if constexpr (NHID == 2) {
-      mask_pack_lds<NB>(acc, p, b2 + srow * PH, hf);
-      __syncthreads();                                   // dW_last readers are done with b2 (= h2)
-      write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA2
-      __syncthreads();
-      dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, wave, lane);
-      chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(W1, PW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
-      mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
-      __syncthreads();                                   // dW_mid readers are done with b2 / b1
-      write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1
-    } else {
-      mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
-      write_packed_tile<NB>(b2, PH, srow, p, hf);        // dA1 (b2 unused so far)
-    }
-    __syncthreads();
-    dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, b2, PH, tX0, PX0, wave, lane);
-    if (d_in) {
-      const int row = r0 + srow;
-      f32x16 o[IB];
-      chain_layer<IB, KS>(o, [&](int ib, int ks) { return tr_frag_chained(W0, PW0, 32 * ib, ks, lane); }, [&](int ks) { return p[ks]; });
-      if (row < rows) {
-#pragma unroll
-        for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f = 32 * ib + 8 * q + 4 * hf;
-            if (f < IN) {
-              h16x4 v;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (h16)o[ib][4 * q + r];
-              nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
-              *(h16x4*)(d_in + (size_t)row * IN + f) = v;
-            }
-          }
-      }
-    }
-  }
-  auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, float* base) {
-    const int i = 32 * ib + c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
-      bad |= !(fabsf(a[r]) <= 3.0e38f);
-      if (o < OUTL && i < INL && a[r] != 0.f) unsafeAtomicAdd(base + (size_t)o * INL + i, a[r]);
-    }
-  };
-  if (dW) {
-#pragma unroll
-    for (int b = 0; b < NBLK_LAST; ++b) { int blk = wave + 4 * b; if (blk < OB * NB) flush(dw_last[b], blk / NB, blk % NB, OUT, HID, dW + L.w_off[L.n - 1]); }
-    if (NHID == 2) {
-#pragma unroll
-      for (int b = 0; b < NBLK_MID; ++b) { int blk = wave + 4 * b; if (blk < NB * NB) flush(dw_mid[b], blk / NB, blk % NB, HID, HID, dW + L.w_off[1]); }
-    }
-#pragma unroll
-    for (int b = 0; b < NBLK_FIRST; ++b) { int blk = wave + 4 * b; if (blk < NB * IB) flush(dw_first[b], blk / IB, blk % IB, HID, IN, dW + L.w_off[0]); }
-  }
-  bad |= nan_bad(nanz);
-  if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
-}
-
 // ---------------------------------------------------------------- recompute backward, wave-specialised (8 waves)
 // Profiling the 4-wave kernel (rocprofv3 + ISA): ~6500 issued instructions per 128-row tile and wave, of which 152 are
 // MFMAs -- with 428 registers per wave the accumulators spill into the AGPR half (1900 v_accvgpr moves) and only ONE wave
@@ -888,14 +791,14 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_recomp(const h16* __restrict__ 
 // Dev-only phase timing (scripts/dev/probe_bwd_phases.py builds with -DALN_PHASE_TIMING): block 0 accumulates the shader
 // clock spent between consecutive stamps, per role (0 = chain wave 0, 1 = dW wave 4).
 #ifdef ALN_PHASE_TIMING
-__device__ long long g_phase_cycles[2][16];
+__device__ long long g_phase_cycles[2][32];
 extern "C" int aln_debug_read_phases(long long* host_out, int reset) {
-  if (reset) { long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)); }
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 32);
+  if (reset) { long long z[64] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 64);
 }
-#define PT_DECL long long pt_acc[16] = {0}; long long pt_last = clock64();
+#define PT_DECL long long pt_acc[32] = {0}; long long pt_last = clock64();
 #define PT_STAMP(i) { long long pt_now = clock64(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; }
-#define PT_FLUSH(role) if (blockIdx.x == 0 && cw == 0 && lane == 0) { for (int i = 0; i < 16; ++i) g_phase_cycles[role][i] += pt_acc[i]; }
+#define PT_FLUSH(role) if (blockIdx.x == 0 && cw == 0 && lane == 0) { for (int i = 0; i < 32; ++i) g_phase_cycles[role][i] += pt_acc[i]; }
 #else
 #define PT_DECL
 #define PT_STAMP(i)
@@ -909,8 +812,8 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
                                                         int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
                                                         float* __restrict__ dW, int* __restrict__ found_inf) {
   constexpr int NB = HID / 32, KS = HID / 16, KS0 = IN / 16, KSO = OUT / 16, IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
-  constexpr int PW0 = IN + 8, PW1 = HID + 8;
-  constexpr int PH = HID + 8, PX0 = IB * 32 + 8, PO = OB * 32 + 8;
+  constexpr int PW0 = IN + 8, PW1 = hid_pitch(HID);
+  constexpr int PH = hid_pitch(HID), PX0 = IB * 32 + 8, PO = OB * 32 + (OB == 1 ? 0 : 8);   // 32-wide dOut tile: transpose reads conflict-free unpadded
   constexpr int TR = 128;
   constexpr int NBLK_LAST = (OB * NB + 3) / 4, NBLK_MID = (NB * NB + 3) / 4, NBLK_FIRST = (NB * IB + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -922,6 +825,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
   lds_h16* b1 = tX0 + TR * PX0;
   lds_h16* b2 = b1 + TR * PH;
   lds_h16* tO = b2 + TR * PH;
+  const PlainV<lds_h16*> vW0{W0, PW0}, vW1{W1, PW1}, vWL{WL, PW1}, vX0{tX0, PX0}, vb1{b1, PH}, vb2{b2, PH}, vO{tO, PO};
   copy_to_lds((h16*)smem, wr_g, wr_halves);
   for (int i = threadIdx.x; i < TR * (PX0 + PO); i += 512) { if (i < TR * PX0) tX0[i] = (h16)0.f; else tO[i - TR * PX0] = (h16)0.f; }
   const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
@@ -976,31 +880,37 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
       h16x8 p[KS];
       chain_layer<NB, KS0>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); },
                            [&](int ks) { return *(const LDS_VEC(h16x8)*)(tX0 + srow * PX0 + 16 * ks + 8 * hf); });
+      PT_STAMP(16)
       relu_pack_store<NB>(acc, p, nullptr, hf);
-      write_packed_tile<NB>(b1, PH, srow, p, hf);
+      PT_STAMP(17)
+      write_packed_tile<NB>(vb1, srow, p, hf);
+      PT_STAMP(18)
       if constexpr (NHID == 2) {
-        chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(W1, PW1, m, ks, lane); }, [&](int ks) { return p[ks]; });
+        chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(vW1, m, ks, lane); }, [&](int ks) { return p[ks]; });
+        PT_STAMP(19)
         relu_pack_store<NB>(acc, p, nullptr, hf);
-        write_packed_tile<NB>(b2, PH, srow, p, hf);
+        PT_STAMP(20)
+        write_packed_tile<NB>(vb2, srow, p, hf);
       }
       PT_STAMP(4) __syncthreads(); PT_STAMP(5)   // B2
-      chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(WL, PW1, 32 * m, ks, lane); },
+      chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(vWL, 32 * m, ks, lane); },
                            [&](int ks) { return *(const LDS_VEC(h16x8)*)(tO + srow * PO + 16 * ks + 8 * hf); });
-      mask_pack_lds<NB>(acc, p, ((NHID == 2) ? b2 : b1) + srow * PH, hf);
+      if constexpr (NHID == 2) mask_pack_lds<NB>(acc, p, vb2, srow, hf); else mask_pack_lds<NB>(acc, p, vb1, srow, hf);
       PT_STAMP(6) __syncthreads(); PT_STAMP(7)   // B3
       if constexpr (NHID == 2) {
-        write_packed_tile<NB>(b2, PH, srow, p, hf);                      // dA2 over h2
+        write_packed_tile<NB>(vb2, srow, p, hf);                      // dA2 over h2
         PT_STAMP(8) __syncthreads(); PT_STAMP(9)   // B4
-        chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(W1, PW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
-        mask_pack_lds<NB>(acc, p, b1 + srow * PH, hf);
+        chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(vW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
+        PT_STAMP(21)
+        mask_pack_lds<NB>(acc, p, vb1, srow, hf);
         PT_STAMP(10) __syncthreads(); PT_STAMP(11)   // B5
       }
-      write_packed_tile<NB>(b2, PH, srow, p, hf);                        // dA1
+      write_packed_tile<NB>(vb2, srow, p, hf);                        // dA1
       PT_STAMP(12) __syncthreads(); PT_STAMP(13)   // B6
       if (d_in) {
         const int row = r0 + srow;
         f32x16 o[IB];
-        chain_layer<IB, KS>(o, [&](int ib, int ks) { return tr_frag_chained(W0, PW0, 32 * ib, ks, lane); }, [&](int ks) { return p[ks]; });
+        chain_layer<IB, KS>(o, [&](int ib, int ks) { return tr_frag_chained(vW0, 32 * ib, ks, lane); }, [&](int ks) { return p[ks]; });
         if (row < rows) {
 #pragma unroll
           for (int ib = 0; ib < IB; ++ib)
@@ -1033,15 +943,15 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
       PT_STAMP(2) __syncthreads(); PT_STAMP(3)   // B1
       if constexpr (PF) { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
       PT_STAMP(4) __syncthreads(); PT_STAMP(5)   // B2
-      dw_accumulate<NBLK_LAST, OB, NB>(dw_last, tO, PO, (NHID == 2) ? b2 : b1, PH, cw, lane);
+      if constexpr (NHID == 2) dw_accumulate<NBLK_LAST, OB, NB>(dw_last, vO, vb2, cw, lane); else dw_accumulate<NBLK_LAST, OB, NB>(dw_last, vO, vb1, cw, lane);
       PT_STAMP(6) __syncthreads(); PT_STAMP(7)   // B3
       if constexpr (NHID == 2) {
         PT_STAMP(8) __syncthreads(); PT_STAMP(9)   // B4
-        dw_accumulate<NBLK_MID, NB, NB>(dw_mid, b2, PH, b1, PH, cw, lane);
+        dw_accumulate<NBLK_MID, NB, NB>(dw_mid, vb2, vb1, cw, lane);
         PT_STAMP(10) __syncthreads(); PT_STAMP(11)   // B5
       }
       PT_STAMP(12) __syncthreads(); PT_STAMP(13)   // B6
-      dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, b2, PH, tX0, PX0, cw, lane);
+      dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, vb2, vX0, cw, lane);
     }
     PT_STAMP(0)
     PT_FLUSH(1)
@@ -1073,18 +983,13 @@ template <int IN, int HID, int OUT, int NHID>
 static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in,
                              float* dW, int* found_inf, hipStream_t s) {
   constexpr int IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
-  constexpr int PH = HID + 8, PX0 = IB * 32 + 8, PO = OB * 32 + 8;
+  constexpr int PH = hid_pitch(HID), PX0 = IB * 32 + 8, PO = OB * 32 + (OB == 1 ? 0 : 8);   // 32-wide dOut tile: transpose reads conflict-free unpadded
   size_t halves = (size_t)aln_mlp_rowmajor_halves(IN, HID, OUT, NHID);
   size_t lds = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(PX0 + 2 * PH + PO)) * 2;
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_recomp: LDS %zu B exceeds 160 KiB", lds);
   int tiles = (rows + 127) / 128;
   int g = tiles < 256 ? tiles : 256;
-  static const bool four = getenv("ALN_MLP_BWD_4WAVE") != nullptr;
-  if (four) {
-    hipFuncSetAttribute((const void*)k_mlp_bwd_recomp<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_mlp_bwd_recomp<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wr, halves, xs, ds,
-                       rows, rows_dev, (h16*)d_in, dW, found_inf);
-  } else {
+  {
     static const bool no_pf = getenv("ALN_MLP_BWD_NOPREFETCH") != nullptr;
     if (xs.mode == SRC_PLAIN && ds.mode == SRC_PLAIN && !no_pf) {
       hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

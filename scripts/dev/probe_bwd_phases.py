@@ -42,7 +42,7 @@ reps = 5
 e0.record()
 for _ in range(reps): run()
 e1.record(); torch.cuda.synchronize()
-buf = (C.c_longlong * 32)()
+buf = (C.c_longlong * 64)()
 lib.aln_debug_read_phases(buf, 0)
 us = e0.elapsed_time(e1) / reps * 1e3
 ntiles = rows // 128
@@ -52,7 +52,12 @@ print(f'{head}: {us:.0f} us per launch, {iters // reps} tiles per block')
 names = ['tail(d_in/dW_first)', 'wait B0', 'load issue', 'wait B1', 'fwd recompute', 'wait B2', 'last layer', 'wait B3',
          'write dA2', 'wait B4', 'mid layer', 'wait B5', 'write dA1', 'wait B6']
 for role, rn in [(0, 'chain wave 0'), (1, 'dW wave 4')]:
-    v = [buf[role * 16 + i] / iters for i in range(16)]
+    v = [buf[role * 32 + i] / iters for i in range(32)]
     print(f'-- {rn}: {sum(v):.0f} clock ticks per tile')
     for i, n in enumerate(names):
         print(f'   {n:22s} {v[i]:8.0f}')
+    sub = ['L0 mfma issue', 'relu_pack h1', 'write h1', 'L1 mfma issue', 'relu_pack h2', '(mid) mfma issue']
+    if role == 0:
+        print('   sub-stamps (the phase entry above = remainder after the last sub-stamp):')
+        for i, n in enumerate(sub):
+            print(f'     {n:20s} {v[16 + i]:8.0f}')
