@@ -258,6 +258,65 @@ __device__ inline void load_tile_src(lds_h16* tile, int pitch, const RowSrc& s, 
   }
 }
 
+// Two-stage form of load_chunk8 for software prefetch: raw_load only issues the global loads of one 8-feature chunk (no
+// dependent arithmetic, so nothing waits on them), raw_finish turns the registers into the fp16 chunk when the tile is
+// stashed into LDS one tile later.  MODE is a compile-time copy of RowSrc::mode so the unused fields fold away.
+struct RawChunk { h16x8 a, b; float w; float g[8]; };
+template <int MODE>
+__device__ inline void raw_load(RawChunk& r, const RowSrc& s, int row, int c0) {
+  if constexpr (MODE == SRC_PLAIN) {
+    r.a = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
+  } else if constexpr (MODE == SRC_SEMF_IN) {
+    const h16* p = s.a + (size_t)row * 16; r.a = *(const h16x8*)p; r.b = *(const h16x8*)(p + 8);
+  } else if constexpr (MODE == SRC_SEMO_IN) {
+    if (c0 >= s.D) { const h16* p = s.b + (size_t)row * 16; r.a = *(const h16x8*)p; r.b = *(const h16x8*)(p + 8); }
+    else r.a = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
+  } else {
+    const int ray = row < s.N * s.S1 ? row / s.S1 : (row - s.N * s.S1) / s.S2;
+    r.w = s.w_row[row];
+    const float* g = s.g + (size_t)ray * s.gw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.g[j] = (c0 + j < s.gw) ? g[c0 + j] : 0.f;
+    if constexpr (MODE == SRC_DSEMF_OUT) {
+      r.a = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
+      r.b = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);
+    }
+  }
+}
+__device__ inline h16x8 geo_from(const h16x8& lo, const h16x8& hi, int j0, int G) {   // geo_chunk on loaded registers
+  h16x8 o;
+  if (j0 == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h16 v = (j < 7) ? lo[j + 1] : hi[0]; o[j] = (j < G) ? v : (h16)1.0f; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h16 v = (j < 7) ? hi[j + 1] : (h16)1.0f; o[j] = (8 + j < G) ? v : (h16)1.0f; }
+  }
+  return o;
+}
+template <int MODE>
+__device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
+  if constexpr (MODE == SRC_PLAIN) return r.a;
+  else if constexpr (MODE == SRC_SEMF_IN) return geo_from(r.a, r.b, c0, s.G);
+  else if constexpr (MODE == SRC_SEMO_IN) {
+    if (c0 >= s.D) return geo_from(r.a, r.b, c0 - s.D, s.G);
+    h16x8 v = r.a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)v[j] > 0.f ? v[j] : (h16)0.f;
+    return v;
+  } else {
+    h16x8 o;
+    if constexpr (MODE == SRC_DLOGITS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (h16)((c0 + j < s.gw) ? r.w * r.g[j] : 0.f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (h16)(r.w * r.g[j] + ((float)r.a[j] > 0.f ? (float)r.b[j] : 0.f));
+    }
+    return o;
+  }
+}
+
 // ---------------------------------------------------------------- forward
 template <int HID, int NHID>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
@@ -805,9 +864,10 @@ extern "C" int aln_debug_read_phases(long long* host_out, int reset) {
 #define PT_FLUSH(role)
 #endif
 
-// PF (plain row sources only): the x / dOut chunks of the NEXT tile are requested right after B1 and sit in registers
-// through the whole tile, so the global-load latency (15 % of a tile when exposed) hides behind the MFMA phases.
-template <int IN, int HID, int OUT, int NHID, bool PF>
+// The x / dOut chunks of the NEXT tile are requested right after B1 (raw_load: XM / DM are the row-source modes) and sit in
+// registers through the whole tile, so the global-load latency (15 % of a tile when exposed; more for the on-the-fly
+// semantic-head sources) hides behind the MFMA phases; raw_finish + the LDS stores run at the top of the next tile.
+template <int IN, int HID, int OUT, int NHID, int XM, int DM>
 __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__ wr_g, size_t wr_halves, RowSrc xs, RowSrc ds,
                                                         int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
                                                         float* __restrict__ dW, int* __restrict__ found_inf) {
@@ -837,33 +897,33 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
   const int ntiles = (rows + TR - 1) / TR;
   constexpr int XCH = IN / 8, OCH = OUT / 8;                       // 8-half chunks per row
   constexpr int NXS = (TR * XCH + 511) / 512, NOS = (TR * OCH + 511) / 512;
-  h16x8 px[PF ? NXS : 1], po[PF ? NOS : 1];
+  RawChunk px[NXS], po[NOS];
   auto prefetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < NXS; ++q) {
+      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
+      if (i < TR * XCH && r0 + r < rows) raw_load<XM>(px[q], xs, r0 + r, 8 * k);
+    }
+#pragma unroll
+    for (int q = 0; q < NOS; ++q) {
+      const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
+      if (i < TR * OCH && r0 + r < rows) raw_load<DM>(po[q], ds, r0 + r, 8 * k);
+    }
+  };
+  auto stash = [&](int r0) {
     const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
       const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
-      px[q] = (i < TR * XCH && r0 + r < rows) ? *(const h16x8*)(xs.a + (size_t)(r0 + r) * xs.lda + 8 * k) : z;
+      if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX0 + r * PX0 + 8 * k) = (r0 + r < rows) ? raw_finish<XM>(px[q], xs, 8 * k) : z;
     }
 #pragma unroll
     for (int q = 0; q < NOS; ++q) {
       const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
-      po[q] = (i < TR * OCH && r0 + r < rows) ? *(const h16x8*)(ds.a + (size_t)(r0 + r) * ds.lda + 8 * k) : z;
+      if (i < TR * OCH) *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = (r0 + r < rows) ? raw_finish<DM>(po[q], ds, 8 * k) : z;
     }
   };
-  auto stash = [&]() {
-#pragma unroll
-    for (int q = 0; q < NXS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
-      if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX0 + r * PX0 + 8 * k) = px[q];
-    }
-#pragma unroll
-    for (int q = 0; q < NOS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
-      if (i < TR * OCH) *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = po[q];
-    }
-  };
-  if constexpr (PF) { if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x * TR); }
+  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x * TR);
   // The two roles run SEPARATE tile loops with the same barrier sequence (s_barrier only counts arrivals, and the role is
   // wave-uniform), so the register allocator never sees the chain state and the dW accumulators live at the same time.
   if (chain) {
@@ -872,10 +932,9 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int r0 = tile * TR;
       PT_STAMP(0) __syncthreads(); PT_STAMP(1)   // B0
-      if constexpr (PF) stash();
-      else { load_tile_src(tX0, PX0, xs, IN, r0, TR, rows); load_tile_src(tO, PO, ds, OUT, r0, TR, rows); }
+      stash(r0);
       PT_STAMP(2) __syncthreads(); PT_STAMP(3)   // B1
-      if constexpr (PF) { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
+      { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
       f32x16 acc[NB];
       h16x8 p[KS];
       chain_layer<NB, KS0>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); },
@@ -938,10 +997,9 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_recomp8(const h16* __restrict__
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int r0 = tile * TR;
       PT_STAMP(0) __syncthreads(); PT_STAMP(1)   // B0
-      if constexpr (PF) stash();
-      else { load_tile_src(tX0, PX0, xs, IN, r0, TR, rows); load_tile_src(tO, PO, ds, OUT, r0, TR, rows); }
+      stash(r0);
       PT_STAMP(2) __syncthreads(); PT_STAMP(3)   // B1
-      if constexpr (PF) { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
+      { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
       PT_STAMP(4) __syncthreads(); PT_STAMP(5)   // B2
       if constexpr (NHID == 2) dw_accumulate<NBLK_LAST, OB, NB>(dw_last, vO, vb2, cw, lane); else dw_accumulate<NBLK_LAST, OB, NB>(dw_last, vO, vb1, cw, lane);
       PT_STAMP(6) __syncthreads(); PT_STAMP(7)   // B3
@@ -989,18 +1047,25 @@ static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_recomp: LDS %zu B exceeds 160 KiB", lds);
   int tiles = (rows + 127) / 128;
   int g = tiles < 256 ? tiles : 256;
-  {
-    static const bool no_pf = getenv("ALN_MLP_BWD_NOPREFETCH") != nullptr;
-    if (xs.mode == SRC_PLAIN && ds.mode == SRC_PLAIN && !no_pf) {
-      hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_mlp_bwd_recomp8<IN, HID, OUT, NHID, true>), dim3(g), dim3(512), lds, s, (const h16*)m->wr, halves, xs,
-                         ds, rows, rows_dev, (h16*)d_in, dW, found_inf);
-    } else {
-      hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_mlp_bwd_recomp8<IN, HID, OUT, NHID, false>), dim3(g), dim3(512), lds, s, (const h16*)m->wr, halves, xs,
-                         ds, rows, rows_dev, (h16*)d_in, dW, found_inf);
-    }
+#define LAUNCH_SRC(XM, DM)                                                                                                  \
+  do {                                                                                                                     \
+    hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID, XM, DM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        (int)lds);                                                                                         \
+    hipLaunchKernelGGL((k_mlp_bwd_recomp8<IN, HID, OUT, NHID, XM, DM>), dim3(g), dim3(512), lds, s, (const h16*)m->wr, halves, \
+                       xs, ds, rows, rows_dev, (h16*)d_in, dW, found_inf);                                                 \
+  } while (0)
+  if (xs.mode == SRC_PLAIN && ds.mode == SRC_PLAIN) LAUNCH_SRC(SRC_PLAIN, SRC_PLAIN);
+  else if constexpr (IN == 16 && OUT == 64) {
+    ALN_REQUIRE(xs.mode == SRC_SEMF_IN && ds.mode == SRC_DSEMF_OUT, "mlp_bwd_recomp: unsupported row sources %d/%d", xs.mode, ds.mode);
+    LAUNCH_SRC(SRC_SEMF_IN, SRC_DSEMF_OUT);
+  } else if constexpr (IN == 80) {
+    ALN_REQUIRE(xs.mode == SRC_SEMO_IN && ds.mode == SRC_DLOGITS, "mlp_bwd_recomp: unsupported row sources %d/%d", xs.mode, ds.mode);
+    LAUNCH_SRC(SRC_SEMO_IN, SRC_DLOGITS);
+  } else {
+    aln_set_error("mlp_bwd_recomp: row sources %d/%d only exist for the semantic heads", xs.mode, ds.mode);
+    return -1;
   }
+#undef LAUNCH_SRC
   ALN_CHECK_LAUNCH("mlp_bwd_recomp");
   return 0;
 }
