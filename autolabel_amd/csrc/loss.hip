@@ -23,12 +23,15 @@ struct LossArgs {
   float* g_image; float* g_depth; float* g_sem; float* g_feat; float* terms;  // terms[5]: rgb, depth, feature, semantic, total
 };
 
-__global__ __launch_bounds__(64) void k_loss(LossArgs a) {
-  const int lane = threadIdx.x;
+// one wavefront per ray (4 per block): every ray is a short chain of dependent loads, so the kernel is latency-bound and
+// wants as many rays in flight as the chip holds; the block folds its four partial sums before the 5 same-address atomics
+__global__ __launch_bounds__(256) void k_loss(LossArgs a) {
+  __shared__ float part[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float scale = a.loss_scale ? *a.loss_scale : 1.f;
   const int nd = a.counts[0], ns = a.counts[1];
   float t_rgb = 0, t_depth = 0, t_feat = 0, t_sem = 0;
-  for (int ray = blockIdx.x; ray < a.N; ray += gridDim.x) {
+  for (int ray = blockIdx.x * 4 + wave; ray < a.N; ray += gridDim.x * 4) {
     if (lane < 3) {
       float diff = a.image[3 * (size_t)ray + lane] - a.gt_rgb[3 * (size_t)ray + lane];
       t_rgb += diff * diff;
@@ -76,7 +79,11 @@ __global__ __launch_bounds__(64) void k_loss(LossArgs a) {
     }
   }
   t_rgb = wave_sum(t_rgb); t_depth = wave_sum(t_depth); t_feat = wave_sum(t_feat); t_sem = wave_sum(t_sem);
-  if (lane == 0 && a.terms) {
+  if (lane == 0) { part[wave][0] = t_rgb; part[wave][1] = t_depth; part[wave][2] = t_feat; part[wave][3] = t_sem; }
+  __syncthreads();
+  if (threadIdx.x == 0 && a.terms) {
+    t_rgb = part[0][0] + part[1][0] + part[2][0] + part[3][0]; t_depth = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+    t_feat = part[0][2] + part[1][2] + part[2][2] + part[3][2]; t_sem = part[0][3] + part[1][3] + part[2][3] + part[3][3];
     float r = t_rgb / (3.f * a.N), d = nd ? t_depth / nd : 0.f, f = (a.gt_feat && a.Cf) ? t_feat / ((float)a.N * a.Cf) : 0.f,
           s = ns ? t_sem / ns : 0.f;
     atomicAdd(a.terms, r); atomicAdd(a.terms + 1, d); atomicAdd(a.terms + 2, f); atomicAdd(a.terms + 3, s);
@@ -100,7 +107,8 @@ extern "C" int aln_loss_fwd_bwd(const float* image, const float* depth, const fl
   ALN_CHECK_LAUNCH("loss_counts");
   LossArgs a{image, depth, semantic, features, gt_rgb, gt_depth, gt_sem, gt_feat, N, C, D, Cf, w_rgb, w_depth, w_sem, w_feat,
              counts, loss_scale, g_image, g_depth, g_sem, g_feat, terms};
-  hipLaunchKernelGGL(k_loss, dim3(N < 128 ? N : 128), dim3(64), 0, s, a);  // few blocks: the 5 loss-term atomics are same-address
+  int nb = (N + 3) / 4;
+  hipLaunchKernelGGL(k_loss, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, a);
   ALN_CHECK_LAUNCH("loss");
   return 0;
 }

@@ -342,37 +342,36 @@ __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
       float r = (1.f - p.wsum[ray]) * p.bg;
       p.image[3 * (size_t)ray] = c0 + r; p.image[3 * (size_t)ray + 1] = c1 + r; p.image[3 * (size_t)ray + 2] = c2 + r;
     }
-    // channel-parallel sums: lane = channel, samples in groups of 8 independent loads (coalesced row reads)
+    // channel sums: `lpr` lanes share a row (one 16-byte chunk each), so one wave instruction reads 64 / lpr whole rows;
+    // every lane keeps 8 channel sums over its rows and the row groups are folded with cross-lane adds at the end
     if (p.logits) {
-      for (int c = lane; c < p.C; c += 64) {
-        float acc = 0.f;
-        for (int k0 = 0; k0 < S; k0 += 8) {
-          float w8[8], v8[8];
+      const int nch_f = p.D / 8, nch_l = p.Cpad / 8;
+      int lpr = 1;
+      while (lpr < 64 && lpr < max(nch_f, nch_l)) lpr <<= 1;
+      const int cg = lane & (lpr - 1), rg = lane / lpr, rpi = 64 / lpr;
+      for (int pass = 0; pass < 2; ++pass) {
+        const h16* src = pass ? p.feat : p.logits;
+        const int ld = pass ? p.D : p.Cpad, nch = pass ? nch_f : nch_l, nout = pass ? p.D : p.C;
+        float* dst = (pass ? p.features : p.semantic) + (size_t)ray * nout;
+        for (int ch = cg; ch < nch; ch += lpr) {
+          float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+          for (int k = rg; k < S; k += rpi) {
+            const size_t row = row_of(ray, k, p.N, p.S1, p.S2);
+            const float w = p.w_row[row];
+            const h16x8 v = *(const h16x8*)(src + row * ld + 8 * ch);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            int k = k0 + j; bool ok = k < S;
-            size_t row = row_of(ray, ok ? k : 0, p.N, p.S1, p.S2);
-            w8[j] = ok ? p.w_row[row] : 0.f; v8[j] = (float)p.logits[row * p.Cpad + c];
+            for (int j = 0; j < 8; ++j) acc[j] += w * (float)v[j];
           }
+          for (int o = lpr; o < 64; o <<= 1) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc += w8[j] * v8[j];
-        }
-        p.semantic[(size_t)ray * p.C + c] = acc;
-      }
-      for (int d = lane; d < p.D; d += 64) {
-        float acc = 0.f;
-        for (int k0 = 0; k0 < S; k0 += 8) {
-          float w8[8], v8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            int k = k0 + j; bool ok = k < S;
-            size_t row = row_of(ray, ok ? k : 0, p.N, p.S1, p.S2);
-            w8[j] = ok ? p.w_row[row] : 0.f; v8[j] = (float)p.feat[row * p.D + d];
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o);
           }
+          if (rg == 0) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc += w8[j] * v8[j];
+            for (int j = 0; j < 8; ++j) if (8 * ch + j < nout) dst[8 * ch + j] = acc[j];
+          }
         }
-        p.features[(size_t)ray * p.D + d] = acc;
       }
     }
   }
@@ -384,6 +383,7 @@ extern "C" int aln_composite_out(const float* w_row, const int32_t* cidx_row, co
                                  void* stream) {
   ALN_REQUIRE(w_row && cidx_row && color_out && wsum && image, "composite_out: NULL pointer");
   ALN_REQUIRE(!logits || (feat && semantic && features), "composite_out: semantic buffers missing");
+  ALN_REQUIRE(!logits || (Cpad % 8 == 0 && D % 8 == 0), "composite_out: Cpad and D must be multiples of 8");
   if (N <= 0) return 0;
   CompOut p{w_row, cidx_row, (const h16*)color_out, (const h16*)logits, (const h16*)feat, wsum, N, S1, S2, C, Cpad, D, bg,
             image, semantic, features};
@@ -414,7 +414,15 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
   float* dws = R + S;     // sorted dw
   float* gs = dws + S;    // g_sem [C]
   float* gf = gs + p.Cpad;  // g_feat [D]
+  float* dsem = gf + p.D;   // d(loss)/dw from the semantic outputs, by sample id [S]
   bool bad = false;
+  // when d_logits / d_feat are not materialised (fused semantic heads) the <logits, g_sem> + <f, g_feat> dot products run
+  // row-major with `lpr` lanes per row (16-byte chunks, whole rows per instruction) instead of one strided row per lane
+  const bool rowmajor_dots = p.logits && !p.d_logits && !p.d_feat;
+  const int nch_f = p.D / 8, nch_l = p.Cpad / 8;
+  int lpr = 1;
+  while (lpr < 64 && lpr < max(nch_f, nch_l)) lpr <<= 1;
+  const int cg = lane & (lpr - 1), rg = lane / lpr, rpi = 64 / lpr;
   for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
     const float gi0 = p.g_image[3 * (size_t)ray], gi1 = p.g_image[3 * (size_t)ray + 1], gi2 = p.g_image[3 * (size_t)ray + 2];
     const float gd = p.g_depth[ray] / p.norms[ray];
@@ -423,11 +431,32 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
       for (int d = lane; d < p.D; d += 64) gf[d] = p.g_feat ? p.g_feat[(size_t)ray * p.D + d] : 0.f;
     }
     __syncthreads();
+    if (rowmajor_dots) {
+#pragma unroll 2
+      for (int k = rg; k < S; k += rpi) {   // S % rpi == 0 is not required: k only feeds loads and the final store
+        const size_t row = row_of(ray, k, p.N, p.S1, p.S2);
+        float acc = 0.f;
+        for (int ch = cg; ch < nch_l; ch += lpr) {
+          const h16x8 v = *(const h16x8*)(p.logits + row * p.Cpad + 8 * ch);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += (float)v[j] * gs[8 * ch + j];
+        }
+        for (int ch = cg; ch < nch_f; ch += lpr) {
+          const h16x8 v = *(const h16x8*)(p.feat + row * p.D + 8 * ch);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += (float)v[j] * gf[8 * ch + j];
+        }
+        for (int o = 1; o < lpr; o <<= 1) acc += __shfl_xor(acc, o);
+        if (cg == 0) dsem[k] = acc;
+      }
+      __syncthreads();
+    }
     for (int k = lane; k < S; k += 64) {
       int id = p.perm[(size_t)ray * S + k];
       size_t row = row_of(ray, id, p.N, p.S1, p.S2);
       float w = p.w_row[row];
       float dw = -p.bg * (gi0 + gi1 + gi2) + p.z[row] * gd;
+      if (rowmajor_dots) dw += dsem[id];
       int ci = p.cidx_row[row];
       if (ci >= 0) {
         h16x4 o = *(const h16x4*)(p.color_out + (size_t)ci * 16);
@@ -439,7 +468,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
         *(h16x8*)(p.d_color_out + (size_t)ci * 16) = lo;
         *(h16x8*)(p.d_color_out + (size_t)ci * 16 + 8) = hi;
       }
-      if (p.logits) {
+      if (p.logits && !rowmajor_dots) {
         const h16* lg = p.logits + row * p.Cpad; h16* dl = p.d_logits + row * p.Cpad;
         for (int c = 0; c < p.Cpad; c += 8) {
           h16x8 v = *(const h16x8*)(lg + c), o8;
@@ -492,7 +521,7 @@ extern "C" int aln_composite_bwd(const float* norms, const float* z, const float
             (const h16*)feat, (const h16*)sigma_out, g_image, g_depth, g_sem, g_feat, N, S1, S2, C, Cpad, D, D, bg,
             density_scale, d_h0, (h16*)d_color_out, (h16*)d_logits, (h16*)d_feat, found_inf};
   int S = S1 + S2;
-  size_t lds = (size_t)(3 * S + Cpad + D) * sizeof(float);
+  size_t lds = (size_t)(4 * S + Cpad + D) * sizeof(float);
   hipLaunchKernelGGL(k_composite_bwd, dim3(N < 65535 ? N : 65535), dim3(64), lds, (hipStream_t)stream, p);
   ALN_CHECK_LAUNCH("composite_bwd");
   return 0;
