@@ -275,3 +275,50 @@ def test_render_options_bg_color_and_chunking_consistency():
     for k in ['image', 'depth', 'semantic', 'semantic_features', 'weights_sum']:
         assert torch.allclose(a[k], b[k], atol=1e-6), k          # chunking does not change per-ray results
     assert torch.allclose(a['image'] - c['image'], (1 - a['weights_sum'])[:, None].expand(-1, 3), atol=1e-6)
+
+
+def test_open_vocabulary_queries_follow_the_reference_recipe():
+    """autolabel/evaluation.py:295-327 (pixels) and :400-445 (points): feature . text argmax, restated with plain loops."""
+    from autolabel_amd import queries as Q
+    model = make_model(D=64, C_=3, bound=1.5)
+    oracle, cfg = oracle_of(model)
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand(700, 3, generator=g) * 2 - 1) * 1.4
+    text = torch.nn.functional.normalize(torch.randn(5, 64, generator=g), dim=1)
+    # point features == semantic(density(x).geo_feat)[1] of the oracle
+    with torch.no_grad():
+        want_f = oracle.semantic(oracle.density(pts)['geo_feat'])[1]
+    got_f = Q.point_features(model, pts.cuda()).cpu()
+    assert got_f.shape == (700, 64)
+    assert (got_f - want_f).abs().max() < 2e-2 * max(1.0, want_f.abs().max().item())
+    # one evaluation (no jitter): the reference loop over prompts
+    got = Q.predict_semantic_points(model, pts.cuda(), text.cuda(), n_evals=1, batch_size=256).cpu()
+    fn = got_f / torch.norm(got_f, dim=-1, keepdim=True)
+    sims = torch.stack([(fn * text[i][None]).sum(dim=-1) for i in range(5)], dim=1)
+    top2 = sims.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3                       # ties within fp noise may flip
+    assert torch.equal(got[clear], sims.argmax(dim=1)[clear]) and clear.float().mean() > 0.9
+    # jittered averaging: weights 1 + (n - 1) x 1/n, label map applied
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    lab = torch.tensor([10, 11, 12, 13, 14], device='cuda')
+    out = Q.predict_semantic_points(model, pts.cuda(), text.cuda(), label_id_map=lab, n_evals=4, generator=gen)
+    assert out.shape == (700,) and int(out.min()) >= 10 and int(out.max()) <= 14
+    gen2 = torch.Generator(device='cuda').manual_seed(11)
+    f = Q.point_features(model, pts.cuda())
+    for _ in range(3):
+        f += Q.point_features(model, pts.cuda() + torch.randn(pts.shape, device='cuda', generator=gen2) * 0.02) * 0.25
+    assert torch.equal(out, lab[Q.similarity_argmax(f, text.cuda())])
+    # zero feature rows argmax to class 0 like the NaN rows of the reference
+    z = torch.zeros(3, 64, device='cuda'); z[1] = text[3].cuda()
+    assert Q.similarity_argmax(z, text.cuda()).tolist() == [0, 3, 0]
+    # pixels: staged render + argmax
+    H_, W_ = 6, 8
+    o = torch.zeros(H_, W_, 3); o[..., 2] = -1.2
+    d = torch.nn.functional.normalize(torch.stack(torch.meshgrid(torch.linspace(-.4, .4, H_), torch.linspace(-.4, .4, W_), indexing='ij') +
+                                                  (torch.ones(H_, W_),), dim=-1), dim=-1)
+    batch = {'rays_o': o.numpy(), 'rays_d': d.numpy(), 'direction_norms': np.ones((H_ * W_, 1), np.float32)}
+    img = Q.predict_semantic_image(model, batch, text.cuda(), num_steps=64, upsample_steps=32)
+    assert img.shape == (H_, W_)
+    feats = model.render(o.cuda(), d.cuda(), torch.ones(H_ * W_, 1, device='cuda'), staged=True, perturb=False, num_steps=64,
+                         upsample_steps=32)['semantic_features']
+    assert torch.equal(img, Q.similarity_argmax(feats, text.cuda()))
