@@ -318,7 +318,7 @@ __device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
 }
 
 // ---------------------------------------------------------------- forward
-template <int HID, int NHID>
+template <int HID, int NHID, int KS0>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
                                                 RowSrc xs, int rows, const int* __restrict__ rows_dev,
                                                 h16* __restrict__ h1, h16* __restrict__ h2, h16* __restrict__ out) {
@@ -330,21 +330,35 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, s
   const h16x8* frag = (const h16x8*)wl;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
   if (rows_dev) rows = min(rows, *rows_dev);
-  const int KS0 = in_pad / 16, OB = ceil32(out_pad);
+  const int OB = ceil32(out_pad);
   const size_t f1 = (size_t)NB * KS0;                       // layer-1 frags start
   const size_t fl = f1 + (NHID == 2 ? (size_t)NB * KS : 0); // last-layer frags start
   const int ntiles = (rows + 31) / 32;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  // The input chunks of a tile are all requested together, and the NEXT tile's chunks are requested into the same
+  // registers as soon as layer 0 has consumed them: their latency hides behind the remaining layers of this tile.
+  h16x8 xb[KS0];
+  auto load_x = [&](int t) {
+    const int r = t * 32 + c;
+#pragma unroll
+    for (int ks = 0; ks < KS0; ++ks) {
+      const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      xb[ks] = (r < rows) ? load_chunk8(xs, r, 16 * ks + 8 * hf) : z;
+    }
+  };
+  const int tstride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < ntiles) load_x(tile);
+  for (; tile < ntiles; tile += tstride) {
     const int row = tile * 32 + c;
     const bool valid = row < rows;
     f32x16 acc[NB];
     zero_acc(acc);
-    for (int ks = 0; ks < KS0; ++ks) {
-      h16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (valid) b = load_chunk8(xs, row, 16 * ks + 8 * hf);
 #pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KS0 + ks) * 64 + lane], b, acc[m]);
+    for (int ks = 0; ks < KS0; ++ks) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KS0 + ks) * 64 + lane], xb[ks], acc[m]);
     }
+    if (tile + tstride < ntiles) load_x(tile + tstride);
     h16x8 p[KS];
     relu_pack_store<NB>(acc, p, (valid && h1) ? h1 + (size_t)row * HID : nullptr, hf);
     if (NHID == 2) {
@@ -1081,17 +1095,28 @@ static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32
                        void* stream) {
   ALN_REQUIRE(m && xs.a && out && m->wf, "mlp_fwd: NULL pointer");
   ALN_REQUIRE(m->in_pad % 16 == 0 && m->out_pad % 16 == 0, "mlp_fwd: widths must be multiples of 16");
+  ALN_REQUIRE(m->in_pad <= 80, "mlp_fwd: in_pad %d exceeds the 80 input features the fused kernel holds in registers", m->in_pad);
   if (rows <= 0) return 0;
   size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 0);
   size_t lds = halves * 2;
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_fwd: weights (%zu B) exceed LDS", lds);
   dim3 g(mlp_grid(rows)), b(256);
   hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_K(H, N, K)                                                                                              \
+  do {                                                                                                                 \
+    hipFuncSetAttribute((const void*)k_mlp_fwd<H, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+    hipLaunchKernelGGL((k_mlp_fwd<H, N, K>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, xs,       \
+                       rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out);                                                 \
+  } while (0)
 #define LAUNCH(H, N)                                                                                                   \
   do {                                                                                                                 \
-    hipFuncSetAttribute((const void*)k_mlp_fwd<H, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-    hipLaunchKernelGGL((k_mlp_fwd<H, N>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, xs, \
-                       rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out);                                                 \
+    switch (m->in_pad / 16) {                                                                                          \
+      case 1: LAUNCH_K(H, N, 1); break;                                                                                \
+      case 2: LAUNCH_K(H, N, 2); break;                                                                                \
+      case 3: LAUNCH_K(H, N, 3); break;                                                                                \
+      case 4: LAUNCH_K(H, N, 4); break;                                                                                \
+      default: LAUNCH_K(H, N, 5); break;                                                                               \
+    }                                                                                                                  \
   } while (0)
   if (m->hidden == 128 && m->n_hidden == 2) LAUNCH(128, 2);
   else if (m->hidden == 128 && m->n_hidden == 1) LAUNCH(128, 1);
@@ -1099,6 +1124,7 @@ static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32
   else if (m->hidden == 64 && m->n_hidden == 1) LAUNCH(64, 1);
   else { aln_set_error("mlp_fwd: unsupported hidden=%d n_hidden=%d", m->hidden, m->n_hidden); return -1; }
 #undef LAUNCH
+#undef LAUNCH_K
   ALN_CHECK_LAUNCH("mlp_fwd");
   return 0;
 }
