@@ -20,6 +20,7 @@ struct EncParams {
   const uint32_t* table;  // fp16x2 per entry
   const float* rays_o; const float* rays_d; const float* z; const float* xyz;
   int rows, rays_stride;
+  int level_lo, level_hi;   // backward only: levels [level_lo, level_hi) of this launch
 };
 
 __device__ inline void row_position(const EncParams& p, int row, float* x) {
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void k_encode_bwd(EncParams p, const h16* __re
     float x[3] = {0, 0, 0}, xn[3];
     if (valid) row_position(p, row, x);
     normalize_pos(x, p.e.bound, true, xn);
-    for (int l = wave; l < p.e.grid.n_levels; l += 4) {
+    for (int l = p.level_lo + wave; l < p.level_hi; l += 4) {
       float g0 = 0.f, g1 = 0.f;
       if (valid) { h16x2 g = *(h16x2*)&tile[lane * pad + fdim + 2 * l]; g0 = (float)g[0]; g1 = (float)g[1]; }
       uint32_t idx[8]; float w[8];
@@ -221,6 +222,7 @@ static int fill_params(EncParams& p, const AlnEncDesc* e, const void* table, con
   ALN_REQUIRE(e->enc_dim == 6 * e->n_freq + (e->use_grid ? 2 * e->grid.n_levels : 0), "encode: enc_dim mismatch");
   p.e = *e; p.table = (const uint32_t*)table; p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.xyz = xyz;
   p.rows = rows; p.rays_stride = stride;
+  p.level_lo = 0; p.level_hi = e->use_grid ? (int)e->grid.n_levels : 0;
   return 0;
 }
 
@@ -239,18 +241,29 @@ extern "C" int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const 
   return 0;
 }
 
-extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
-                              const float* xyz, int32_t rows, int32_t rays_stride, const void* d_enc,
-                              float* grad_table, void* stream) {
+extern "C" int aln_encode_bwd_levels(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                                     const float* xyz, int32_t rows, int32_t rays_stride, const void* d_enc,
+                                     float* grad_table, int32_t level_lo, int32_t level_hi, void* stream) {
   EncParams p;
   if (int rc = fill_params(p, e, nullptr, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
   if (rows == 0 || !e->use_grid) return 0;
+  ALN_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= (int)e->grid.n_levels, "encode_bwd: level range [%d, %d)", level_lo,
+              level_hi);
+  if (level_lo == level_hi) return 0;
+  p.level_lo = level_lo; p.level_hi = level_hi;
   int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   size_t lds = (((size_t)ENC_TILE * e->enc_pad * sizeof(h16) + 15) & ~(size_t)15) + 4 * 64 * (16 * sizeof(float) + 8 * sizeof(uint32_t));
   hipLaunchKernelGGL(k_encode_bwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (const h16*)d_enc, grad_table);
   ALN_CHECK_LAUNCH("encode_bwd");
   return 0;
+}
+
+extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                              const float* xyz, int32_t rows, int32_t rays_stride, const void* d_enc,
+                              float* grad_table, void* stream) {
+  ALN_REQUIRE(e, "encode_bwd: NULL descriptor");
+  return aln_encode_bwd_levels(e, rays_o, rays_d, z, xyz, rows, rays_stride, d_enc, grad_table, 0, (int32_t)e->grid.n_levels, stream);
 }
 
 extern "C" int aln_grid_desc_init(AlnGridDesc* g) {

@@ -45,6 +45,10 @@ class TrainEngine:
         pipe.found_inf = self.state_i[2:3]
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # data parallel: the gradient all-reduce runs in buckets on a side stream while the hash-grid scatter is still
+        # working on the remaining levels (the scatter is the last and longest kernel of the backward pass)
+        self.overlap_comm = self.world > 1
+        self._comm = torch.cuda.Stream(device=dv) if self.world > 1 else None
         self._g = {}
 
     def _gbuf(self, name, shape):
@@ -67,14 +71,48 @@ class TrainEngine:
                H.ptr(out['semantic_features']), H.ptr(batch['pixels']), H.ptr(batch['depth']), H.ptr(batch['semantic']),
                H.ptr(gt_feat), N, L.C, L.D, Cf, w[0], w[1], w[2], w[3] if gt_feat is not None else 0.0, H.ptr(self.state_f),
                H.ptr(self.counts), H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem), H.ptr(g_feat), H.ptr(self.terms), H.stream())
-        pipe.backward(ctx, g_image, g_depth, g_sem, g_feat)
+        if self.world > 1 and self.overlap_comm:
+            self._reduced = True
+            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat, level_groups=self.level_groups(), on_grad_ready=self._bucket_ready)
+        else:
+            self._reduced = False
+            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat)
         return out
 
+    def level_groups(self):
+        """Hash-grid levels in scatter order: the fine (large, 4 MB each) levels first in groups of four -- one level per wave
+        of the scatter kernel -- and the small coarse levels last, so the only all-reduce nothing can hide is the smallest."""
+        n = int(self.L.enc.grid.n_levels) if self.L.n_grid else 0
+        groups, hi = [], n
+        while hi > 0:
+            lo = max(0, hi - 4)
+            groups.append((lo, hi))
+            hi = lo
+        return groups
+
+    def _bucket_ready(self, kind, a, b):
+        """P.grad[a:b] is final on the compute stream: average it over the ranks on the communication stream."""
+        from .parallel import allreduce_bucket
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(ev)
+            if kind == 'mlp':   # MLP block + the overflow flag in the tail element (every rank must skip the same steps)
+                allreduce_bucket(self.P.grad, a, b, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts)
+            else:
+                allreduce_bucket(self.P.grad, a, b, self.pg)
+
     def all_reduce_grads(self):
-        """One collective for every gradient (flat buffer) + the overflow flag riding in its tail."""
+        """Average every gradient over the ranks.  With overlap the buckets are already in flight on the communication
+        stream and this only makes the compute stream wait for them; otherwise ONE collective over the flat buffer with
+        the overflow flag riding in its tail."""
         if self.world > 1:
-            from .parallel import allreduce_gradients
-            allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg)
+            if self._reduced:
+                torch.cuda.current_stream().wait_stream(self._comm)
+            else:
+                from .parallel import allreduce_gradients
+                allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts)
 
     def optimizer_step(self):
         P, L, sc = self.P, self.L, self.scaler_cfg

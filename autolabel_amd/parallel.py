@@ -38,20 +38,53 @@ def rank_seed(base, rank):
     return (int(base) + 0x9E3779B1 * (rank + 1)) & 0x7FFFFFFF
 
 
-def allreduce_gradients(grad, n_total, found_inf, group=None):
+def _pack_tail(grad, tail, found_inf, counts):
+    grad[tail] = found_inf[0].to(grad.dtype)
+    if counts is not None:   # "this rank saw a labelled ray": torch DDP gives every rank a gradient for a parameter as soon
+        grad[tail + 1] = (counts[1] > 0).to(grad.dtype)   # as one rank has one, so the optimizer's skip rule must be global
+
+
+def _unpack_tail(grad, tail, found_inf, counts):
+    found_inf[0] = (grad[tail] > 0).to(found_inf.dtype)
+    if counts is not None:
+        counts[1] = torch.maximum(counts[1], (grad[tail + 1] > 0).to(counts.dtype))
+    grad[tail:tail + 2] = 0
+
+
+def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None):
     """Average `grad[:n_total]` over the group in place with a single collective; `found_inf` (int32[1]) becomes the
-    logical OR over ranks.  `grad` must have at least one spare element at index n_total."""
+    logical OR over ranks, and so does "some rank had labelled rays" (`counts[1] > 0`, which decides whether the semantic
+    heads take an optimizer step).  `grad` must have at least two spare elements at index n_total."""
     world = dist.get_world_size(group)
     if world == 1:
         return
-    grad[n_total] = found_inf[0].to(grad.dtype)
+    _pack_tail(grad, n_total, found_inf, counts)
     if dist.get_backend(group) == 'nccl':
         dist.all_reduce(grad, op=dist.ReduceOp.AVG, group=group)
     else:  # gloo has no AVG
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
         grad.mul_(1.0 / world)
-    found_inf[0] = (grad[n_total] > 0).to(found_inf.dtype)
-    grad[n_total] = 0
+    _unpack_tail(grad, n_total, found_inf, counts)
+
+
+def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=None):
+    """Average `grad[a:b]` over the group in place (one collective on the current stream).  With `found_inf` the bucket
+    must end at `tail` (= n_total): the flags travel in `grad[tail:tail + 2]` and come back as the OR over ranks."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    if found_inf is not None:
+        assert b == tail, 'the overflow flag rides right behind the bucket'
+        _pack_tail(grad, tail, found_inf, counts)
+        b = tail + 2
+    view = grad[a:b]
+    if dist.get_backend(group) == 'nccl':
+        dist.all_reduce(view, op=dist.ReduceOp.AVG, group=group)
+    else:  # gloo has no AVG
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        view.mul_(1.0 / world)
+    if found_inf is not None:
+        _unpack_tail(grad, tail, found_inf, counts)
 
 
 def broadcast_parameters(flat, group=None, src=0):

@@ -290,8 +290,13 @@ class HipPipeline:
                H.ptr(out.get('semantic_features')), H.stream())
         return out, c
 
-    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None):
-        """Accumulate d(loss)/d(params) into P.grad from per-ray output gradients (fp32, already loss-scaled)."""
+    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None):
+        """Accumulate d(loss)/d(params) into P.grad from per-ray output gradients (fp32, already loss-scaled).
+
+        Data-parallel callers pass ``level_groups`` = [(lo, hi), ...] and ``on_grad_ready``: the hash-grid scatter then runs
+        one group of levels at a time and the callback fires as soon as a part of P.grad is final -- ``('mlp', a, b)`` for
+        the MLP block (+ overflow flag) before the scatter starts, ``('grid', a, b)`` after each group (flat offsets) -- so
+        its all-reduce overlaps the remaining scatter."""
         L, P, ws = self.L, self.P, self.ws
         assert c['train'], 'backward needs a forward(train=True) context'
         N, S1, S2, M = c['N'], c['S1'], c['S2'], c['M']
@@ -350,6 +355,22 @@ class HipPipeline:
         self._k('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
                 H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
-        for (zz, rows, stride, de) in [(z, M1, S1, d_enc)] + ([(z[M1:], N * S2, S2, d_enc[M1:])] if S2 > 0 else []):
-            self._k('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de), H.ptr(P.grad),
-                    H.stream(), tag=rows)
+        passes = [(z, M1, S1, d_enc)] + ([(z[M1:], N * S2, S2, d_enc[M1:])] if S2 > 0 else [])
+        if on_grad_ready is not None:
+            on_grad_ready('mlp', L.n_grid, L.n_total)
+        if not e.use_grid:
+            return
+        if level_groups is None:
+            for (zz, rows, stride, de) in passes:
+                self._k('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de), H.ptr(P.grad),
+                        H.stream(), tag=(rows, int(e.grid.n_levels)))
+            return
+        F = int(e.grid.n_features)
+        for lo, hi in level_groups:
+            for (zz, rows, stride, de) in passes:
+                self._k('aln_encode_bwd_levels', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de),
+                        H.ptr(P.grad), lo, hi, H.stream(), tag=(rows, hi - lo))
+            if on_grad_ready is not None:
+                a = int(e.grid.offset[lo]) * F
+                b = int(e.grid.offset[hi]) * F if hi < int(e.grid.n_levels) else L.n_grid
+                on_grad_ready('grid', a, b)

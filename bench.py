@@ -176,11 +176,14 @@ def main():
         # + the d_enc row (enc_pad x 2 B) + z (4 B).
         L = eng.L
         per_row = L.enc.grid.n_levels * 8 * 2 * 4 + L.enc.enc_pad * 2 + 4
-        enc_ev = [(e, t) for e, n, t in events if n == 'aln_encode_bwd']
+        # (data-parallel runs launch the scatter in level groups: aln_encode_bwd_levels, tag = (rows, levels of the launch))
+        enc_ev = [(e, t) for e, n, t in events if n.startswith('aln_encode_bwd')]
         durs = [e[0].elapsed_time(e[1]) * 1e-3 for e, _ in enc_ev]
-        rows = [r for _, r in enc_ev]
+        nl = L.enc.grid.n_levels
+        per_launch = [r * (lv * 8 * 2 * 4 + (L.enc.enc_pad * 2 + 4) * lv / nl) for _, (r, lv) in enc_ev]
+        rows = [r * lv / nl for _, (r, lv) in enc_ev]
         avg_s = sum(durs) / len(durs)
-        achieved = per_row * (sum(rows) / len(rows)) / avg_s / 1e9
+        achieved = (sum(per_launch) / len(per_launch)) / avg_s / 1e9
         traffic = None  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
@@ -189,7 +192,7 @@ def main():
             pass
         res['roofline'] = {'kernel': 'k_encode_bwd', 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                            'frac': achieved / 8000.0, 'traffic': traffic, 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
-                           'algorithmic_bytes_per_launch': per_row * (sum(rows) / len(rows)),
+                           'algorithmic_bytes_per_launch': sum(per_launch) / len(per_launch),
                            'note': 'scatter of 2x fp32 atomics per corner: bound by the atomic request rate (~21 G 64-byte '
                                    'requests/s measured, scripts/dev/probe_atomics3.hip), not by HBM bytes; traffic = '
                                    '(FETCH_SIZE + WRITE_SIZE) KB * 1024 from profiles/r01_pmc_summary.json'}
@@ -202,7 +205,7 @@ def main():
         mac = {'sigma': macs('sigma'), 'color': macs('color'), 'sem': macs('semf') + macs('semo')}
         flops = t_mlp = 0.0
         for e, n, t in events:
-            if n == 'aln_encode_bwd':
+            if n.startswith('aln_encode_bwd'):
                 continue
             head, r = t
             if torch.is_tensor(r):

@@ -121,6 +121,11 @@ int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const float* rays
 int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
                    int32_t rows, int32_t rays_stride, const void* d_enc /*[rows,enc_pad] f16*/,
                    float* grad_table /*[n_entries*F] f32*/, void* stream);
+/* the same for levels [level_lo, level_hi) only: a data-parallel caller launches the levels in groups and all-reduces the
+ * finished part of the gradient table while the next group is still being scattered */
+int aln_encode_bwd_levels(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
+                          int32_t rows, int32_t rays_stride, const void* d_enc, float* grad_table, int32_t level_lo,
+                          int32_t level_hi, void* stream);
 
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,

@@ -1,0 +1,81 @@
+"""Data-parallel training step on the GPU with two ranks sharing one device (gloo carries the collectives: functional
+check of the bucketed, stream-overlapped gradient all-reduce -- RCCL itself needs one GPU per rank and is exercised by
+`bench.py --gpus N`)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo')
+    torch.cuda.set_device(0)
+    from autolabel_amd import parallel, synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    dev = torch.device('cuda', 0)
+    scene = synthetic.make_cube_scene(n_frames=8, size=32, seed=0, device=dev)
+    frames = DeviceFrames.from_scene(scene, dev)
+    layout = ModelLayout('hg+freq', 15, 128, 128, 64, scene['n_classes'], bound=3.0)
+    out = {}
+    for overlap in (True, False):
+        P = Params(layout, dev); P.init_(seed=0)
+        parallel.broadcast_parameters(P.flat)
+        P.refresh_shadows()
+        eng = TrainEngine(HipPipeline(layout, P), process_group=dist.group.WORLD, num_steps=32, upsample_steps=32)
+        eng.overlap_comm = overlap
+        buckets = []
+        if overlap:
+            inner = eng._bucket_ready
+            eng._bucket_ready = lambda kind, a, b: (buckets.append((kind, a, b)), inner(kind, a, b))[1]
+        lo, hi = parallel.frame_shard(8, rank, world)
+        batch = frames.alloc_batch(1024)
+        for i in range(3):
+            frames.next_train(batch, seed=parallel.rank_seed(5, rank), step=i, frame_range=(lo, hi))
+            eng.step(batch, seed=parallel.rank_seed(7, rank), step=i)
+        torch.cuda.synchronize()
+        flat = P.flat.detach().cpu()
+        both = [None] * world
+        dist.all_gather_object(both, flat)
+        out[overlap] = dict(same=bool(torch.equal(both[0], both[1])), finite=bool(torch.isfinite(flat).all()), flat=flat,
+                            steps=int(eng.state_i[0].item()), buckets=buckets, n_total=layout.n_total, n_grid=layout.n_grid)
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = out
+
+
+def test_two_ranks_on_one_gpu_stay_in_lockstep_with_bucketed_allreduce():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        res = dict(ret)
+    for rank in range(world):
+        for overlap in (True, False):
+            r = res[rank][overlap]
+            assert r['same'] and r['finite'] and r['steps'] == 3, (rank, overlap, r['same'], r['finite'], r['steps'])
+        # every step: the MLP bucket first, then the level groups; together they tile [0, n_total) exactly once
+        b = res[rank][True]['buckets']
+        per_step = len(b) // 3
+        step0 = b[:per_step]
+        assert step0[0][0] == 'mlp' and all(k == 'grid' for k, _, _ in step0[1:])
+        spans = sorted((a, e) for _, a, e in step0)
+        assert spans[0][0] == 0 and spans[-1][1] == res[rank][True]['n_total']
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        # the small coarse levels go last (the only all-reduce nothing overlaps)
+        assert step0[-1][1] == 0
+        # overlapped and single-collective runs agree up to the order of the float atomics in the scatter
+        f1, f0 = res[rank][True]['flat'], res[rank][False]['flat']
+        ng = res[rank][True]['n_grid']
+        assert (f1[ng:] - f0[ng:]).abs().max() < 5e-2 and ((f1[:ng] - f0[:ng]).abs() > 1e-2).float().mean() < 0.02
