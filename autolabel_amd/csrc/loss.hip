@@ -108,7 +108,8 @@ extern "C" int aln_loss_fwd_bwd(const float* image, const float* depth, const fl
   LossArgs a{image, depth, semantic, features, gt_rgb, gt_depth, gt_sem, gt_feat, N, C, D, Cf, w_rgb, w_depth, w_sem, w_feat,
              counts, loss_scale, g_image, g_depth, g_sem, g_feat, terms};
   int nb = (N + 3) / 4;
-  hipLaunchKernelGGL(k_loss, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, s, a);
+  // (the 5 loss-term atomics of every block hit one cache line and serialize in L2: 256 blocks, not one per 4 rays)
+  hipLaunchKernelGGL(k_loss, dim3(nb < 256 ? nb : 256), dim3(256), 0, s, a);
   ALN_CHECK_LAUNCH("loss");
   return 0;
 }
