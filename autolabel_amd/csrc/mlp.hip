@@ -76,37 +76,55 @@ __host__ __device__ inline int wrow_pitch(const MlpLayers& L, int l) { return l 
 __host__ __device__ inline size_t wrow_off(const MlpLayers& L, int l) {
   size_t o = 0; for (int i = 0; i < l; ++i) o += (size_t)L.out_[i] * wrow_pitch(L, i); return o;
 }
+// element i of the row-major image / element e of the fragment images of one head
+__device__ inline h16 rowmajor_elem(const float* __restrict__ w, const MlpLayers& L, size_t i) {
+  int l = 0; while (l + 1 < L.n && i >= wrow_off(L, l + 1)) ++l;
+  size_t e = i - wrow_off(L, l); int pitch = wrow_pitch(L, l); int o = (int)(e / pitch), k = (int)(e % pitch);
+  return (h16)(k < L.in_[l] ? w[L.w_off[l] + (size_t)o * L.in_[l] + k] : 0.f);
+}
+__device__ inline h16 frag_elem(const float* __restrict__ w, const MlpLayers& L, size_t e, bool bw) {
+  int j = e & 7, lane = (e >> 3) & 63; size_t frag = e >> 9;
+  int hf = lane >> 5, c = lane & 31;
+  int l = 0; size_t base = 0;
+  if (!bw) {
+    for (l = 0; l < L.n; ++l) { size_t cnt = (size_t)ceil32(L.out_[l]) * (L.in_[l] / 16); if (frag < base + cnt) break; base += cnt; }
+    int KS = L.in_[l] / 16; int mb = (frag - base) / KS, ks = (frag - base) % KS;
+    int o = 32 * mb + c, k = (l == 0) ? kmap_natural(ks, hf, j) : kmap_chained(ks, hf, j);
+    return (h16)((o < L.out_[l] && k < L.in_[l]) ? w[L.w_off[l] + (size_t)o * L.in_[l] + k] : 0.f);
+  }
+  for (l = L.n - 1; l >= 0; --l) { size_t cnt = (size_t)ceil32(L.in_[l]) * (L.out_[l] / 16); if (frag < base + cnt) break; base += cnt; }
+  int KS = L.out_[l] / 16; int mb = (frag - base) / KS, ks = (frag - base) % KS;
+  int ii = 32 * mb + c, o = (l == L.n - 1) ? kmap_natural(ks, hf, j) : kmap_chained(ks, hf, j);
+  return (h16)((ii < L.in_[l] && o < L.out_[l]) ? w[L.w_off[l] + (size_t)o * L.in_[l] + ii] : 0.f);
+}
+
 __global__ void k_mlp_rowmajor(const float* __restrict__ w, MlpLayers L, h16* __restrict__ wr) {
   size_t total = wrow_off(L, L.n);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    int l = 0; while (l + 1 < L.n && i >= wrow_off(L, l + 1)) ++l;
-    size_t e = i - wrow_off(L, l); int pitch = wrow_pitch(L, l); int o = (int)(e / pitch), k = (int)(e % pitch);
-    wr[i] = (h16)(k < L.in_[l] ? w[L.w_off[l] + (size_t)o * L.in_[l] + k] : 0.f);
-  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) wr[i] = rowmajor_elem(w, L, i);
 }
 
 __global__ void k_mlp_repack(const float* __restrict__ w, MlpLayers L, h16* __restrict__ wf, h16* __restrict__ wb) {
   // one thread per (frag, lane, j)
   size_t nf = fwd_frag_off(L, L.n) * 512, nb = bwd_frag_off(L, -1) * 512;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nf + nb; i += (size_t)gridDim.x * blockDim.x) {
-    bool bw = i >= nf;
-    size_t e = bw ? i - nf : i;
-    int j = e & 7, lane = (e >> 3) & 63; size_t frag = e >> 9;
-    int hf = lane >> 5, c = lane & 31;
-    int l = 0; size_t base = 0;
-    if (!bw) {
-      for (l = 0; l < L.n; ++l) { size_t cnt = (size_t)ceil32(L.out_[l]) * (L.in_[l] / 16); if (frag < base + cnt) break; base += cnt; }
-      int KS = L.in_[l] / 16; int mb = (frag - base) / KS, ks = (frag - base) % KS;
-      int o = 32 * mb + c, k = (l == 0) ? kmap_natural(ks, hf, j) : kmap_chained(ks, hf, j);
-      float v = (o < L.out_[l] && k < L.in_[l]) ? w[L.w_off[l] + (size_t)o * L.in_[l] + k] : 0.f;
-      wf[e] = (h16)v;
-    } else {
-      for (l = L.n - 1; l >= 0; --l) { size_t cnt = (size_t)ceil32(L.in_[l]) * (L.out_[l] / 16); if (frag < base + cnt) break; base += cnt; }
-      int KS = L.out_[l] / 16; int mb = (frag - base) / KS, ks = (frag - base) % KS;
-      int ii = 32 * mb + c, o = (l == L.n - 1) ? kmap_natural(ks, hf, j) : kmap_chained(ks, hf, j);
-      float v = (ii < L.in_[l] && o < L.out_[l]) ? w[L.w_off[l] + (size_t)o * L.in_[l] + ii] : 0.f;
-      wb[e] = (h16)v;
-    }
+    if (i < nf) wf[i] = frag_elem(w, L, i, false); else wb[i - nf] = frag_elem(w, L, i - nf, true);
+  }
+}
+
+// all heads of a model in ONE launch (the per-step shadow refresh after the optimizer: 8 launches -> 1)
+#define ALN_MAX_HEADS 8
+struct RepackHead { const float* w; MlpLayers L; h16* wf; h16* wb; h16* wr; size_t nf, nb, nr; };
+struct RepackAll { int n; RepackHead h[ALN_MAX_HEADS]; };
+__global__ void k_mlp_repack_all(RepackAll a) {
+  size_t total = 0;
+  for (int k = 0; k < a.n; ++k) total += a.h[k].nf + a.h[k].nb + a.h[k].nr;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t e = i; int k = 0;
+    while (e >= a.h[k].nf + a.h[k].nb + a.h[k].nr) { e -= a.h[k].nf + a.h[k].nb + a.h[k].nr; ++k; }
+    const RepackHead& h = a.h[k];
+    if (e < h.nf) h.wf[e] = frag_elem(h.w, h.L, e, false);
+    else if (e < h.nf + h.nb) h.wb[e - h.nf] = frag_elem(h.w, h.L, e - h.nf, true);
+    else h.wr[e - h.nf - h.nb] = rowmajor_elem(h.w, h.L, e - h.nf - h.nb);
   }
 }
 
@@ -127,6 +145,28 @@ extern "C" int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hid
     hipLaunchKernelGGL(k_mlp_rowmajor, dim3(32), dim3(256), 0, (hipStream_t)stream, w_master, L, (h16*)wr);
     ALN_CHECK_LAUNCH("mlp_rowmajor");
   }
+  return 0;
+}
+
+extern "C" int aln_mlp_repack_all(int32_t n_heads, const float* const* w_master, const AlnMlpDesc* const* descs, void* stream) {
+  ALN_REQUIRE(n_heads >= 0 && n_heads <= ALN_MAX_HEADS && (n_heads == 0 || (w_master && descs)), "mlp_repack_all: bad arguments");
+  if (n_heads == 0) return 0;
+  RepackAll a; a.n = n_heads;
+  size_t total = 0;
+  for (int k = 0; k < n_heads; ++k) {
+    const AlnMlpDesc* m = descs[k];
+    ALN_REQUIRE(m && w_master[k] && m->wf && m->wb, "mlp_repack_all: NULL pointer in head %d", k);
+    ALN_REQUIRE(m->in_pad % 16 == 0 && m->out_pad % 16 == 0 && (m->hidden == 64 || m->hidden == 128) &&
+                    (m->n_hidden == 1 || m->n_hidden == 2), "mlp_repack_all: unsupported shape in head %d", k);
+    RepackHead& h = a.h[k];
+    h.w = w_master[k]; h.L = mlp_layers(m->in_pad, m->hidden, m->out_pad, m->n_hidden);
+    h.wf = (h16*)m->wf; h.wb = (h16*)m->wb; h.wr = (h16*)m->wr;
+    h.nf = fwd_frag_off(h.L, h.L.n) * 512; h.nb = bwd_frag_off(h.L, -1) * 512; h.nr = m->wr ? wrow_off(h.L, h.L.n) : 0;
+    total += h.nf + h.nb + h.nr;
+  }
+  int g = (int)((total + 255) / 256); if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_mlp_repack_all, dim3(g), dim3(256), 0, (hipStream_t)stream, a);
+  ALN_CHECK_LAUNCH("mlp_repack_all");
   return 0;
 }
 

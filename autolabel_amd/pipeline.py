@@ -111,16 +111,20 @@ class Params:
         L = self.layout
         if grid and L.n_grid:
             H.call('aln_cast_f16', H.ptr(self.flat), H.ptr(self.table16), L.n_grid, H.stream())
+        fused = []
         for k, s in L.nets.items():
             if s.lib:
                 o = L.offsets[k]
                 for w in self.lib_w[k]:
                     w.copy_(self.flat[o:o + w.numel()].view_as(w))
                     o += w.numel()
-                continue
-            wf, wb, wr = self.frags[k]
-            H.call('aln_mlp_repack', C.c_void_p(self.flat.data_ptr() + 4 * L.offsets[k]), s.in_pad, s.hidden, s.out_pad,
-                   s.n_hidden, H.ptr(wf), H.ptr(wb), H.ptr(wr), H.stream())
+            else:
+                fused.append(k)
+        if fused:   # one launch for all fused heads
+            n = len(fused)
+            ws = (C.c_void_p * n)(*[self.flat.data_ptr() + 4 * L.offsets[k] for k in fused])
+            ds = (C.c_void_p * n)(*[C.addressof(self.descs[k]) for k in fused])
+            H.call('aln_mlp_repack_all', n, ws, ds, H.stream())
 
 
 class Workspace:

@@ -130,6 +130,9 @@ int aln_encode_bwd_levels(const AlnEncDesc* e, const float* rays_o, const float*
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
                    void* wf, void* wb, void* wr /*optional*/, void* stream);
+/* the same for n_heads descriptors (wf / wb / wr taken from each AlnMlpDesc) in ONE launch: the per-step refresh of the
+ * fp16 copies after the optimizer (scripts/train.py:50-63 keeps fp32 masters; tcnn re-casts them every step) */
+int aln_mlp_repack_all(int32_t n_heads, const float* const* w_master, const AlnMlpDesc* const* descs, void* stream);
 int64_t aln_mlp_frag_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden, int32_t backward);
 int64_t aln_mlp_rowmajor_halves(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden);
 /* h1/h2: [rows,hidden] f16 saved post-ReLU activations (NULL at inference).  rows_dev (optional, device int32)
