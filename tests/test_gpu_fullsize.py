@@ -1,0 +1,146 @@
+"""Size-independent properties of the hot path at BASELINE.json's full sizes (B = 8192 rays x 256 samples, hash grid
+L = 16, T = 2^19, 640x480 frames): the oracle needs minutes for these shapes, so here the kernels are checked against
+identities that hold for any input -- grid-vertex lookups, forward/backward adjointness, additivity over rays, ray
+independence, unit norms -- next to the oracle comparisons at small sizes in test_gpu_kernels.py / test_gpu_pipeline.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as O
+
+B_FULL, S_FULL = 8192, 256          # BASELINE configs[0] batch; 128 + 128 samples per ray
+
+
+@pytest.fixture(scope='module')
+def H():
+    from autolabel_amd import hip
+    hip.require_gpu()
+    hip.lib()
+    return hip
+
+
+def _rays(n, bound, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = (torch.rand(n, 3, generator=g) - 0.5) * bound
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    return o.cuda(), d.cuda()
+
+
+def test_grid_vertices_return_table_entries_bit_exact(H):
+    """At a vertex of level l the trilinear weights are (1, 0, ..., 0): the feature IS the table entry the index function
+    (dense stride or the xor-of-primes hash) selects -- 2^20 lookups per level against the oracle's index function."""
+    bound = 3.0
+    e = H.make_enc_desc('hg+freq', bound)
+    spec = O.GridSpec()
+    g = torch.Generator().manual_seed(0)
+    table = (torch.rand(spec.n_entries, 2, generator=g) - 0.5).half()
+    td = table.cuda()
+    n = 1 << 20
+    for lvl in (0, 2, 3, 9, 15):          # dense, last dense, first hashed, mid, finest
+        L = spec.levels()[lvl]
+        gi = torch.randint(0, int(L['res']) - 1, (n, 3), generator=g)
+        # pos = xn * scale + 0.5 must be the integer gi: xn = (gi - 0.5) / scale, kept where that round trip is exact in fp32
+        xn = (gi.float() - 0.5) / np.float32(L['scale'])
+        ok = ((xn * np.float32(L['scale']) + np.float32(0.5)) == gi.float()).all(dim=1) & (xn >= 0).all(dim=1)
+        x = (xn * np.float32(2 * bound) - np.float32(bound))
+        ok &= (((x + np.float32(bound)) / np.float32(2 * bound)) == xn).all(dim=1)
+        assert ok.float().mean() > 0.2, lvl
+        x, gi = x[ok].contiguous(), gi[ok]
+        out = torch.zeros(x.shape[0], e.enc_pad, dtype=torch.float16, device='cuda')
+        xd = x.cuda()
+        H.call('aln_encode_fwd', C.byref(e), H.ptr(td), None, None, None, H.ptr(xd), x.shape[0], 1, H.ptr(out), H.stream())
+        idx, wgt = O.grid_corner_indices(xn[ok].contiguous(), L)   # oracle index function; corner 0 of a vertex = the vertex
+        assert bool((wgt[:, 0] == 1).all()) and bool((wgt[:, 1:] == 0).all())
+        want = table[int(L['offset']) + idx[:, 0]]
+        got = out.cpu()[:, 12 + 2 * lvl:12 + 2 * lvl + 2]
+        assert torch.equal(got, want), f'level {lvl}: vertex lookups must be bit-exact'
+
+
+def test_encode_backward_is_the_adjoint_of_forward_at_full_size(H):
+    """<encode(T), D> == <T, encode_bwd(D)> for the grid part (the scatter is the transpose of the gather), B x S rows."""
+    bound = 3.0
+    e = H.make_enc_desc('hg+freq', bound)
+    spec = O.GridSpec()
+    N, S = B_FULL, S_FULL // 2            # one pass of the renderer: 8192 x 128 = 2^20 rows
+    rows = N * S
+    g = torch.Generator().manual_seed(1)
+    ro, rd = _rays(N, bound, 2)
+    z = (torch.rand(N, S, generator=g).sort(dim=1)[0] * 5 + 0.2).cuda().reshape(-1).contiguous()
+    table = ((torch.rand(spec.n_entries, 2, generator=g) - 0.5)).half().cuda()
+    enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(table), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(enc), H.stream())
+    d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+    d_enc[:, 12:44] = (torch.randn(rows, 32, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * 0.05).half()
+    grad = torch.zeros(spec.n_entries * 2, device='cuda')
+    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(d_enc), H.ptr(grad), H.stream())
+    lhs = (enc[:, 12:44].double() * d_enc[:, 12:44].double()).sum().item()
+    rhs = (table.double().reshape(-1) * grad.double()).sum().item()
+    scale = (enc[:, 12:44].double().abs() * d_enc[:, 12:44].double().abs()).sum().item()
+    # the forward rounds every feature to fp16 (2^-11 relative), the backward accumulates in fp32
+    assert abs(lhs - rhs) <= 2.0 ** -10 * scale * 0.05 + 1e-6 * scale, (lhs, rhs, scale)
+    # additivity over rays: scattering two halves of the batch separately gives the same table gradient
+    g2 = torch.zeros_like(grad)
+    h = N // 2
+    for a, b in ((0, h), (h, N)):
+        H.call('aln_encode_bwd', C.byref(e), H.ptr(ro[a:b]), H.ptr(rd[a:b]), H.ptr(z[a * S:b * S]), None, (b - a) * S, S,
+               H.ptr(d_enc[a * S:b * S]), H.ptr(g2), H.stream())
+    assert torch.equal(g2 != 0, grad != 0)
+    assert (g2 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
+    # level groups (the data-parallel launch order) tile the same scatter
+    g3 = torch.zeros_like(grad)
+    for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
+        H.call('aln_encode_bwd_levels', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(d_enc), H.ptr(g3), lo, hi,
+               H.stream())
+    assert torch.equal(g3 != 0, grad != 0) and (g3 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
+
+
+def test_render_is_ray_independent_and_bounded_at_full_batch():
+    """B = 8192 rays, 128 + 128 samples: permuting the rays permutes the outputs (no cross-ray coupling anywhere in the
+    launch sequence), the weights of a ray sum to at most one, and depth lies inside [near, far] / norm."""
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    layout = ModelLayout('hg+freq', 15, 128, 128, 64, 7, bound=3.0)
+    P = Params(layout, 'cuda'); P.init_(seed=0)
+    with torch.no_grad():
+        P.flat[:layout.n_grid].mul_(3e3)
+    P.refresh_shadows()
+    pipe = HipPipeline(layout, P)
+    N = B_FULL
+    ro, rd = _rays(N, 3.0, 5)
+    norms = (torch.rand(N, device='cuda') * 0.4 + 1.0)
+    out, c = pipe.forward(ro, rd, norms, 128, 128, False, train=False)
+    base = {k: v.clone() for k, v in out.items()}
+    near, far = c['nears'].clone(), c['fars'].clone()
+    assert torch.isfinite(torch.cat([v.reshape(-1) for v in base.values()])).all()
+    assert base['weights_sum'].max().item() <= 1.0 + 1e-5 and base['weights_sum'].min().item() >= 0.0
+    hit = base['weights_sum'] > 0.5
+    d = base['depth'] * norms
+    assert (d[hit] <= far[hit] + 1e-4).all() and (d[hit] >= near[hit] * base['weights_sum'][hit] - 1e-4).all()
+    perm = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(9))
+    out2, _ = pipe.forward(ro[perm].contiguous(), rd[perm].contiguous(), norms[perm].contiguous(), 128, 128, False, train=False)
+    for k in ('image', 'depth', 'semantic', 'semantic_features', 'weights_sum', 'coordinates_map', 'depth_variance'):
+        assert torch.equal(out2[k], base[k][perm]), f'{k}: a ray must not depend on its position in the batch'
+
+
+def test_full_frame_rays_are_unit_length_and_norms_follow_the_pinhole_formula(H):
+    """640x480 frame (307200 rays): |d| == 1 to one fp32 ulp, norm == ||((x+.5-cx)/fx, (y+.5-cy)/fy, 1)||, and the sum
+    of all directions equals R_WC applied to the sum of the normalised camera-frame rays (linearity of the rotation)."""
+    w, h, fx, fy, cx, cy = 640, 480, 320.0, 320.0, 319.5, 239.5
+    g = torch.Generator().manual_seed(4)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    R = q.float().contiguous()
+    idx = torch.arange(w * h, dtype=torch.int64)
+    dirs = torch.empty(w * h, 3, device='cuda'); norms = torch.empty(w * h, device='cuda')
+    Rd, idxd = R.cuda(), idx.cuda()
+    H.call('aln_compute_direction', H.ptr(Rd), H.ptr(idxd), w * h, w, fx, fy, cx, cy, None, H.ptr(dirs), H.ptr(norms), H.stream())
+    x = (idx % w).double() + 0.5; y = (idx // w).double() + 0.5
+    cam = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(x)], dim=1)
+    n64 = cam.norm(dim=1)
+    assert (norms.cpu().double() - n64).abs().max().item() <= 2e-7 * n64.max().item()
+    assert (dirs.cpu().double().norm(dim=1) - 1).abs().max().item() <= 3e-7
+    want_sum = (R.double() @ (cam / n64[:, None]).sum(dim=0))
+    assert (dirs.cpu().double().sum(dim=0) - want_sum).abs().max().item() <= 1e-2   # 307200 fp32 roundings
