@@ -113,6 +113,7 @@ extern "C" int aln_sh4(const float* dirs, int32_t rows, int32_t out_pitch, void*
 __global__ void k_build_color_in(const int* __restrict__ live_idx, const int* __restrict__ n_live, int max_rows,
                                  const float* __restrict__ rd, const float* __restrict__ dirs, int N, int S1, int S2,
                                  const h16* __restrict__ sigma_out, int G, int in_pad, h16* __restrict__ cin) {
+  // one thread per row, whole 16-byte chunks in and out (a row is 64 B for in_pad = 32)
   int n = live_idx ? min(*n_live, max_rows) : max_rows;
   for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n; ci += gridDim.x * blockDim.x) {
     int row = live_idx ? live_idx[ci] : ci;
@@ -121,17 +122,26 @@ __global__ void k_build_color_in(const int* __restrict__ live_idx, const int* __
     else { int ray = row < N * S1 ? row / S1 : (row - N * S1) / S2; d = rd + 3 * (size_t)ray; }
     float sh[16];
     sh4_of_dir(d, sh);
+    const h16x8 lo = *(const h16x8*)(sigma_out + (size_t)row * 16), hi = *(const h16x8*)(sigma_out + (size_t)row * 16 + 8);
+    h16x8 c0, c1, c2, c3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c0[j] = (h16)sh[j]; c1[j] = (h16)sh[8 + j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // geo_feat[g] = sigma_out[row][1 + g], ones from G on
+      h16 a = (j < 7) ? lo[j + 1] : hi[0], b = (j < 7) ? hi[j + 1] : (h16)1.0f;
+      c2[j] = (j < G) ? a : (h16)1.0f; c3[j] = (8 + j < G) ? b : (h16)1.0f;
+    }
     h16* o = cin + (size_t)ci * in_pad;
-    for (int j = 0; j < 16; ++j) o[j] = (h16)sh[j];
-    for (int g = 0; g < G; ++g) o[16 + g] = sigma_out[(size_t)row * 16 + 1 + g];
-    for (int j = 16 + G; j < in_pad; ++j) o[j] = (h16)1.0f;
+    *(h16x8*)o = c0; *(h16x8*)(o + 8) = c1; *(h16x8*)(o + 16) = c2;
+    if (in_pad >= 32) *(h16x8*)(o + 24) = c3;
+    for (int j = 32; j < in_pad; ++j) o[j] = (h16)1.0f;
   }
 }
 extern "C" int aln_build_color_in(const int32_t* live_idx, const int32_t* n_live, int32_t max_rows, const float* rays_d,
                                   const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out, int32_t G,
                                   int32_t in_pad, void* color_in, void* stream) {
   ALN_REQUIRE((rays_d || dirs) && sigma_out && color_in && (!live_idx || n_live), "build_color_in: NULL pointer");
-  ALN_REQUIRE(G + 1 <= 16 && 16 + G <= in_pad, "build_color_in: geo_feat_dim %d unsupported", G);
+  ALN_REQUIRE(G + 1 <= 16 && 16 + G <= in_pad && in_pad % 8 == 0 && (G <= 8 || in_pad >= 32), "build_color_in: geo_feat_dim %d unsupported", G);
   if (max_rows <= 0) return 0;
   hipLaunchKernelGGL(k_build_color_in, dim3(aln_grid_for(max_rows, 256)), dim3(256), 0, (hipStream_t)stream, live_idx, n_live,
                      max_rows, rays_d, dirs, N, S1, S2, (const h16*)sigma_out, G, in_pad, (h16*)color_in);
@@ -197,20 +207,32 @@ __global__ void k_assemble_dsigma_out(const float* __restrict__ d_h0, const h16*
                                       const h16* __restrict__ d_semo_in, int semo_in_pad, int D, const h16* __restrict__ d_color_in,
                                       int color_in_pad, const int* __restrict__ cidx_row, int rows, int G,
                                       h16* __restrict__ d_sigma_out, int* __restrict__ found_inf) {
-  size_t total = (size_t)rows * 16;
+  // one thread per row: the geo_feat gradients of the three consumers arrive as whole 16-byte chunks
   bool bad = false;
-  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    size_t r = t / 16; int j = (int)(t % 16);
-    float g = 0.f;
-    if (j == 0) g = d_h0[r];
-    else if (j <= G) {
-      int gi = j - 1;
-      if (d_semf_in) g += (float)d_semf_in[r * semf_in_pad + gi] + (float)d_semo_in[r * semo_in_pad + D + gi];
-      int ci = cidx_row ? cidx_row[r] : (int)r;
-      if (ci >= 0) g += (float)d_color_in[(size_t)ci * color_in_pad + 16 + gi];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    float g[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) g[j] = 0.f;
+    if (d_semf_in) {
+      const h16* pf = d_semf_in + (size_t)r * semf_in_pad; const h16* po = d_semo_in + (size_t)r * semo_in_pad + D;
+      const h16x8 f0 = *(const h16x8*)pf, f1 = *(const h16x8*)(pf + 8), o0 = *(const h16x8*)po, o1 = *(const h16x8*)(po + 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { g[j] = (float)f0[j] + (float)o0[j]; g[8 + j] = (float)f1[j] + (float)o1[j]; }
     }
-    h16 gh = (h16)g; bad |= !(fabsf((float)gh) <= 65504.f);
-    d_sigma_out[t] = gh;
+    const int ci = cidx_row ? cidx_row[r] : r;
+    if (ci >= 0) {
+      const h16* pc = d_color_in + (size_t)ci * color_in_pad + 16;
+      const h16x8 c0 = *(const h16x8*)pc, c1 = *(const h16x8*)(pc + 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { g[j] += (float)c0[j]; g[8 + j] += (float)c1[j]; }
+    }
+    h16x8 lo, hi;
+    lo[0] = (h16)d_h0[r];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) { h16 v = (j <= G) ? (h16)g[j - 1] : (h16)0.f; if (j < 8) lo[j] = v; else hi[j - 8] = v; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad |= !(fabsf((float)lo[j]) <= 65504.f) | !(fabsf((float)hi[j]) <= 65504.f);
+    *(h16x8*)(d_sigma_out + (size_t)r * 16) = lo; *(h16x8*)(d_sigma_out + (size_t)r * 16 + 8) = hi;
   }
   if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
 }
@@ -220,7 +242,9 @@ extern "C" int aln_assemble_grads(const float* d_h0, const void* d_semf_in, int3
                                   void* stream) {
   ALN_REQUIRE(d_h0 && d_color_in && d_sigma_out && (!d_semf_in || d_semo_in), "assemble_grads: NULL pointer");
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(k_assemble_dsigma_out, dim3(aln_grid_for((int64_t)rows * 16, 256)), dim3(256), 0, (hipStream_t)stream, d_h0,
+  ALN_REQUIRE(G <= 15 && color_in_pad >= 32 && color_in_pad % 8 == 0 && (!d_semf_in || (semf_in_pad == 16 && D % 8 == 0 && semo_in_pad >= D + 16)),
+              "assemble_grads: unsupported widths");
+  hipLaunchKernelGGL(k_assemble_dsigma_out, dim3(aln_grid_for((int64_t)rows, 256)), dim3(256), 0, (hipStream_t)stream, d_h0,
                      (const h16*)d_semf_in, semf_in_pad, (const h16*)d_semo_in, semo_in_pad, D, (const h16*)d_color_in,
                      color_in_pad, cidx_row, rows, G, (h16*)d_sigma_out, found_inf);
   ALN_CHECK_LAUNCH("assemble_dsigma_out");
