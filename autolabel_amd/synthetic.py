@@ -160,4 +160,6 @@ def subsample(scene, factor):
     out.update(images=scene['images'][:, idx].contiguous(), depths=scene['depths'][:, idx].contiguous(),
                semantics=scene['semantics'][:, idx].contiguous(), w=nw, h=nh,
                intrinsics=(fx * sx, fy * sy, cx * sx, cy * sy))
+    if scene.get('semantics_full') is not None:   # dense ground truth of the unlabelled frames (evaluation only)
+        out['semantics_full'] = scene['semantics_full'][:, idx].contiguous()
     return out
