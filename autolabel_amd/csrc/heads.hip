@@ -160,14 +160,21 @@ __global__ void k_build_semf_in(const h16* __restrict__ sigma_out, int rows, int
 // semo_in[row] = [relu(f) (D), geo_feat (G), 1...]
 __global__ void k_build_semo_in(const h16* __restrict__ f, const h16* __restrict__ sigma_out, int rows, int D, int G,
                                 int in_pad, h16* __restrict__ o) {
-  size_t total = (size_t)rows * in_pad;
+  // one 8-feature chunk per thread (D % 8 == 0, in_pad % 8 == 0): relu(f) chunks, then [geo_feat, 1...] chunks
+  const int nch = in_pad / 8;
+  size_t total = (size_t)rows * nch;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    size_t r = t / in_pad; int j = (int)(t % in_pad);
-    h16 v;
-    if (j < D) { v = f[r * D + j]; if ((float)v < 0.f) v = (h16)0.f; }
-    else if (j < D + G) v = sigma_out[r * 16 + 1 + (j - D)];
-    else v = (h16)1.0f;
-    o[t] = v;
+    size_t r = t / nch; int c0 = 8 * (int)(t % nch);
+    h16x8 v;
+    if (c0 < D) {
+      v = *(const h16x8*)(f + r * D + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if ((float)v[j] < 0.f) v[j] = (h16)0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { int g = c0 - D + j; v[j] = g < G ? sigma_out[r * 16 + 1 + g] : (h16)1.0f; }
+    }
+    *(h16x8*)(o + r * in_pad + c0) = v;
   }
 }
 extern "C" int aln_build_sem_in(const void* sigma_out, const void* f, int32_t rows, int32_t D, int32_t G, int32_t semf_in_pad,
@@ -181,7 +188,8 @@ extern "C" int aln_build_sem_in(const void* sigma_out, const void* f, int32_t ro
   }
   if (semo_in) {
     ALN_REQUIRE(f, "build_sem_in: f is NULL");
-    hipLaunchKernelGGL(k_build_semo_in, dim3(aln_grid_for((int64_t)rows * semo_in_pad, 256)), dim3(256), 0, (hipStream_t)stream,
+    ALN_REQUIRE(D % 8 == 0 && semo_in_pad % 8 == 0, "build_sem_in: D and semo_in_pad must be multiples of 8");
+    hipLaunchKernelGGL(k_build_semo_in, dim3(aln_grid_for((int64_t)rows * (semo_in_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                        (const h16*)f, (const h16*)sigma_out, rows, D, G, semo_in_pad, (h16*)semo_in);
     ALN_CHECK_LAUNCH("build_semo_in");
   }
@@ -191,16 +199,43 @@ extern "C" int aln_build_sem_in(const void* sigma_out, const void* f, int32_t ro
 // d_f_total[row][d] = d_feat[row][d] + (f > 0 ? d_semo_in[row][d] : 0)      (in place into d_feat)
 __global__ void k_assemble_dsemf_out(h16* __restrict__ d_feat, const h16* __restrict__ f, const h16* __restrict__ d_semo_in,
                                      int rows, int D, int semo_in_pad, int* __restrict__ found_inf) {
-  size_t total = (size_t)rows * D;
+  // d_feat += relu'(f) * d_semo_in[:, :D], 8 features per thread
+  const int nch = D / 8;
+  size_t total = (size_t)rows * nch;
   bool bad = false;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    size_t r = t / D; int d = (int)(t % D);
-    float g = (float)d_feat[t];
-    if ((float)f[t] > 0.f) g += (float)d_semo_in[r * semo_in_pad + d];
-    h16 gh = (h16)g; bad |= !(fabsf((float)gh) <= 65504.f);
-    d_feat[t] = gh;
+    size_t r = t / nch; int c0 = 8 * (int)(t % nch);
+    h16x8 g = *(const h16x8*)(d_feat + r * D + c0);
+    const h16x8 fv = *(const h16x8*)(f + r * D + c0), dv = *(const h16x8*)(d_semo_in + r * semo_in_pad + c0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = (float)g[j];
+      if ((float)fv[j] > 0.f) x += (float)dv[j];
+      g[j] = (h16)x; bad |= !(fabsf((float)g[j]) <= 65504.f);
+    }
+    *(h16x8*)(d_feat + r * D + c0) = g;
   }
   if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
+}
+// g *= (act > 0) in place + overflow watch: the ReLU backward of the library-GEMM heads, one pass instead of torch's three
+__global__ void k_relu_bwd(h16* __restrict__ g, const h16* __restrict__ act, size_t n8, int* __restrict__ found_inf) {
+  bool bad = false;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n8; t += (size_t)gridDim.x * blockDim.x) {
+    h16x8 gv = *(const h16x8*)(g + 8 * t);
+    const h16x8 av = *(const h16x8*)(act + 8 * t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (!((float)av[j] > 0.f)) gv[j] = (h16)0.f; bad |= !(fabsf((float)gv[j]) <= 65504.f); }
+    *(h16x8*)(g + 8 * t) = gv;
+  }
+  if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
+}
+extern "C" int aln_relu_bwd(void* g, const void* act, int64_t n, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(g && act && n % 8 == 0, "relu_bwd: NULL pointer or n %% 8 != 0");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_relu_bwd, dim3(aln_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (h16*)g, (const h16*)act,
+                     (size_t)(n / 8), found_inf);
+  ALN_CHECK_LAUNCH("relu_bwd");
+  return 0;
 }
 // d_sigma_out[row] = [d_h0, d_geo(semf_in) + d_geo(semo_in) + d_geo(color_in)] (16 wide)
 __global__ void k_assemble_dsigma_out(const float* __restrict__ d_h0, const h16* __restrict__ d_semf_in, int semf_in_pad,
@@ -254,7 +289,8 @@ extern "C" int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d
                                       int32_t semo_in_pad, int32_t* found_inf, void* stream) {
   ALN_REQUIRE(d_feat && f && d_semo_in, "assemble_dsemf_out: NULL pointer");
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(k_assemble_dsemf_out, dim3(aln_grid_for((int64_t)rows * D, 256)), dim3(256), 0, (hipStream_t)stream,
+  ALN_REQUIRE(D % 8 == 0 && semo_in_pad % 8 == 0, "assemble_dsemf_out: D and semo_in_pad must be multiples of 8");
+  hipLaunchKernelGGL(k_assemble_dsemf_out, dim3(aln_grid_for((int64_t)rows * (D / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                      (h16*)d_feat, (const h16*)f, (const h16*)d_semo_in, rows, D, semo_in_pad, found_inf);
   ALN_CHECK_LAUNCH("assemble_dsemf_out");
   return 0;

@@ -416,9 +416,9 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
   float* gf = gs + p.Cpad;  // g_feat [D]
   float* dsem = gf + p.D;   // d(loss)/dw from the semantic outputs, by sample id [S]
   bool bad = false;
-  // when d_logits / d_feat are not materialised (fused semantic heads) the <logits, g_sem> + <f, g_feat> dot products run
-  // row-major with `lpr` lanes per row (16-byte chunks, whole rows per instruction) instead of one strided row per lane
-  const bool rowmajor_dots = p.logits && !p.d_logits && !p.d_feat;
+  // the <logits, g_sem> + <f, g_feat> dot products (and, for the library-GEMM heads, the d_logits / d_feat rows = w * g)
+  // run row-major with `lpr` lanes per row (16-byte chunks, whole rows per instruction) instead of one strided row per lane
+  const bool rowmajor_dots = p.logits != nullptr;
   const int nch_f = p.D / 8, nch_l = p.Cpad / 8;
   int lpr = 1;
   while (lpr < 64 && lpr < max(nch_f, nch_l)) lpr <<= 1;
@@ -446,6 +446,21 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc += (float)v[j] * gf[8 * ch + j];
         }
+        if (p.d_logits || p.d_feat) {   // library-GEMM heads: d(logits) = w * g_sem, d(f) = w * g_feat as whole rows
+          const float w = p.w_row[row];
+          for (int ch = cg; ch < nch_l && p.d_logits; ch += lpr) {
+            h16x8 o8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o8[j] = (h16)(w * gs[8 * ch + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
+            *(h16x8*)(p.d_logits + row * p.Cpad + 8 * ch) = o8;
+          }
+          for (int ch = cg; ch < nch_f && p.d_feat; ch += lpr) {
+            h16x8 o8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o8[j] = (h16)(w * gf[8 * ch + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
+            *(h16x8*)(p.d_feat + row * p.D + 8 * ch) = o8;
+          }
+        }
         for (int o = 1; o < lpr; o <<= 1) acc += __shfl_xor(acc, o);
         if (cg == 0) dsem[k] = acc;
       }
@@ -467,22 +482,6 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
         bad |= !(fabsf((float)lo[0]) <= 65504.f) | !(fabsf((float)lo[1]) <= 65504.f) | !(fabsf((float)lo[2]) <= 65504.f);
         *(h16x8*)(p.d_color_out + (size_t)ci * 16) = lo;
         *(h16x8*)(p.d_color_out + (size_t)ci * 16 + 8) = hi;
-      }
-      if (p.logits && !rowmajor_dots) {
-        const h16* lg = p.logits + row * p.Cpad; h16* dl = p.d_logits + row * p.Cpad;
-        for (int c = 0; c < p.Cpad; c += 8) {
-          h16x8 v = *(const h16x8*)(lg + c), o8;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { dw += (float)v[j] * gs[c + j]; o8[j] = (h16)(w * gs[c + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
-          if (p.d_logits) *(h16x8*)(dl + c) = o8;
-        }
-        const h16* ft = p.feat + row * p.D; h16* df = p.d_feat + row * p.D;
-        for (int d = 0; d < p.D; d += 8) {
-          h16x8 v = *(const h16x8*)(ft + d), o8;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { dw += (float)v[j] * gf[d + j]; o8[j] = (h16)(w * gf[d + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
-          if (p.d_feat) *(h16x8*)(df + d) = o8;
-        }
       }
       dws[k] = dw; P[k] = dw * w;
     }

@@ -5,6 +5,7 @@ forward, GradScaler-scaled backward, per-optimizer step, scaler.update) with no 
 scale, the overflow flag, the optimizer step counter and the loss terms all live on the device.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -47,7 +48,7 @@ class TrainEngine:
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         # data parallel: the gradient all-reduce runs in buckets on a side stream while the hash-grid scatter is still
         # working on the remaining levels (the scatter is the last and longest kernel of the backward pass)
-        self.overlap_comm = self.world > 1
+        self.overlap_comm = self.world > 1 and os.environ.get('ALN_DP_OVERLAP', '1') != '0'   # ALN_DP_OVERLAP=0: one collective
         self._comm = torch.cuda.Stream(device=dv) if self.world > 1 else None
         self._g = {}
 

@@ -68,6 +68,7 @@ _SIGS = {
     'aln_build_color_in': (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp]),
     'aln_build_sem_in': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'aln_assemble_grads': (i32, [vp, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
+    'aln_relu_bwd': (i32, [vp, vp, i64, vp, vp]),
     'aln_assemble_dsemf_out': (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     'aln_composite_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),

@@ -177,6 +177,19 @@ class HipPipeline:
                     hs.append(h)
         return h, hs
 
+    def _lib_dw(self, g, a):
+        """dW = g^T a with fp32 accumulation, [rows, out] x [rows, in] -> [out, in].  The contraction runs over ~10^6 rows:
+        as one GEMM hipBLASLt gets a 512 x 512 output (4 tiles for 256 CUs); batched over row slabs it fills the chip, and
+        the fp32 slab results are summed afterwards (split-K by hand)."""
+        rows = g.shape[0]
+        slabs = 1
+        while slabs < 64 and rows % (slabs * 2) == 0 and rows // (slabs * 2) >= 4096:
+            slabs *= 2
+        if slabs == 1:
+            return torch.mm(g.t(), a, out_dtype=torch.float32)
+        gb = g.view(slabs, rows // slabs, g.shape[1]).transpose(1, 2)
+        return torch.bmm(gb, a.view(slabs, rows // slabs, a.shape[1]), out_dtype=torch.float32).sum(dim=0)
+
     def _lib_bwd(self, k, x, hs, d_out):
         """Accumulates dW into the flat gradient buffer (fp32 GEMM output) and returns dL/dx [rows, in_pad] fp16."""
         ws, L = self.P.lib_w[k], self.L
@@ -185,13 +198,14 @@ class HipPipeline:
         for w in ws:
             offs.append(o)
             o += w.numel()
+        fi = H.ptr(self.found_inf)
         for i in reversed(range(len(ws))):
-            dW = torch.mm(g.t(), acts[i], out_dtype=torch.float32)
+            dW = self._lib_dw(g, acts[i])
             self.P.grad[offs[i]:offs[i] + ws[i].numel()].add_(dW.view(-1))
             g = g @ ws[i]
-            if i > 0:
-                g.mul_(acts[i] > 0)
-        self.found_inf.bitwise_or_((~torch.isfinite(g).all()).to(torch.int32))
+            if i > 0:   # ReLU backward + overflow watch in one pass
+                H.call('aln_relu_bwd', H.ptr(g), H.ptr(acts[i]), g.numel(), fi, H.stream())
+        self.found_inf.bitwise_or_((~torch.isfinite(g).all()).to(torch.int32))   # the input gradient is an endpoint too
         return g
 
     # ---- point queries (models.py:175-188, 190-220, 248-256)

@@ -171,6 +171,9 @@ int aln_assemble_grads(const float* d_h0, const void* d_semf_in, int32_t semf_in
                        int32_t rows, int32_t G, void* d_sigma_out, int32_t* found_inf, void* stream);
 int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d_semo_in, int32_t rows, int32_t D, int32_t semo_in_pad,
                            int32_t* found_inf, void* stream);
+/* ReLU backward in place for the library-GEMM (wide) heads: g[i] = act[i] > 0 ? g[i] : 0, n halves (n % 8 == 0); found_inf
+ * is OR-ed when a non-finite gradient passes */
+int aln_relu_bwd(void* g, const void* act, int64_t n, int32_t* found_inf, void* stream);
 
 /* ---- compositing: alpha / cumprod weights and weighted sums of NeRFRenderer.run (fork), outputs image, depth
  * (metric z-depth = sum w t / direction_norm), semantic, semantic_features, depth_variance, coordinates_map;
