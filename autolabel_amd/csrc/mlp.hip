@@ -357,6 +357,29 @@ __device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
   }
 }
 
+// One layer of the register chain with software-pipelined A fragments: the NB fragments of k-step ks+1 are requested
+// before the NB MFMAs of k-step ks are issued (one wave per SIMD: nothing else hides the ~150-cycle LDS latency).
+template <int NB, int KSN, class FragFn, class BFn>
+__device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
+  h16x8 a[2][NB];
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < NB; ++m) a[0][m] = frag(m, 0);
+#pragma unroll
+  for (int ks = 0; ks < KSN; ++ks) {
+    if (ks + 1 < KSN) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) a[(ks + 1) & 1][m] = frag(m, ks + 1);
+    }
+    // pin the order: left alone, the machine scheduler turns this into NB dependent accumulator chains with one
+    // "ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma" round trip per MFMA (~80 cycles each instead of 32)
+    __builtin_amdgcn_sched_barrier(0);
+    h16x8 b = bop(ks);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b, ks == 0 ? zero : acc[m]);   // C = 0 inline: no accumulator zeroing
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 // ---------------------------------------------------------------- forward
 template <int HID, int NHID, int KS0>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, s
   copy_to_lds(wl, wf_g, wf_halves);
   __syncthreads();
   constexpr int NB = HID / 32, KS = HID / 16;
-  const h16x8* frag = (const h16x8*)wl;
+  const h16x8* frag0 = (const h16x8*)wl;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
   if (rows_dev) rows = min(rows, *rows_dev);
   const int OB = ceil32(out_pad);
@@ -391,22 +414,18 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, s
   for (; tile < ntiles; tile += tstride) {
     const int row = tile * 32 + c;
     const bool valid = row < rows;
+    // the weight fragments are re-read from LDS every tile: an offset the optimiser cannot see through keeps it from
+    // hoisting all of them into registers (306 VGPRs -> one wave per SIMD, nothing to overlap the pack/store phases with)
+    int fo = 0;
+    asm volatile("" : "+v"(fo));
+    const h16x8* frag = frag0 + fo;
     f32x16 acc[NB];
-    zero_acc(acc);
-#pragma unroll
-    for (int ks = 0; ks < KS0; ++ks) {
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KS0 + ks) * 64 + lane], xb[ks], acc[m]);
-    }
+    chain_layer<NB, KS0>(acc, [&](int m, int ks) { return frag[((size_t)m * KS0 + ks) * 64 + lane]; }, [&](int ks) { return xb[ks]; });
     if (tile + tstride < ntiles) load_x(tile + tstride);
     h16x8 p[KS];
     relu_pack_store<NB>(acc, p, (valid && h1) ? h1 + (size_t)row * HID : nullptr, hf);
     if (NHID == 2) {
-      zero_acc(acc);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[(f1 + (size_t)m * KS + ks) * 64 + lane], p[ks], acc[m]);
+      chain_layer<NB, KS>(acc, [&](int m, int ks) { return frag[(f1 + (size_t)m * KS + ks) * 64 + lane]; }, [&](int ks) { return p[ks]; });
       relu_pack_store<NB>(acc, p, (valid && h2) ? h2 + (size_t)row * HID : nullptr, hf);
     }
     for (int ob = 0; ob < OB; ++ob) {
@@ -797,29 +816,6 @@ static int launch_bwd_fused(const AlnMlpDesc* m, const void* x, const void* h1, 
   return 0;
 }
 
-// One layer of the register chain with software-pipelined A fragments: the NB fragments of k-step ks+1 are requested
-// before the NB MFMAs of k-step ks are issued (one wave per SIMD: nothing else hides the ~150-cycle LDS latency).
-template <int NB, int KSN, class FragFn, class BFn>
-__device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
-  h16x8 a[2][NB];
-  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int m = 0; m < NB; ++m) a[0][m] = frag(m, 0);
-#pragma unroll
-  for (int ks = 0; ks < KSN; ++ks) {
-    if (ks + 1 < KSN) {
-#pragma unroll
-      for (int m = 0; m < NB; ++m) a[(ks + 1) & 1][m] = frag(m, ks + 1);
-    }
-    // pin the order: left alone, the machine scheduler turns this into NB dependent accumulator chains with one
-    // "ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma" round trip per MFMA (~80 cycles each instead of 32)
-    __builtin_amdgcn_sched_barrier(0);
-    h16x8 b = bop(ks);
-#pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b, ks == 0 ? zero : acc[m]);   // C = 0 inline: no accumulator zeroing
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
 // relu'(h) mask read back from the LDS tile holding h (C-layout 8-byte chunks)
 // fp16 overflow detection without converting every value back: track max |g| (overflow <=> > 65504) and fold the values
 // into a NaN catcher (g * 0 is NaN for NaN / inf); two VALU ops per element instead of four.
