@@ -69,6 +69,26 @@ __device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn
   }
 }
 
+// trilinear weights + base cell only (forward: the indices are computed by the lanes that issue the loads)
+__device__ inline void grid_weights(const AlnGridDesc& g, int l, const float* xn, float* w, uint32_t* base) {
+  float scale = g.scale[l];
+  float fr[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float pos = __fadd_rn(__fmul_rn(xn[k], scale), 0.5f);
+    float fl = floorf(pos);
+    base[k] = (uint32_t)(int)fl;
+    fr[k] = __fsub_rn(pos, fl);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float ww = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ww = (c & (1 << k)) ? __fmul_rn(ww, fr[k]) : __fmul_rn(ww, __fsub_rn(1.0f, fr[k]));
+    w[c] = ww;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h16* tile = (h16*)smem;  // [ENC_TILE][enc_pad]
@@ -84,24 +104,41 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
     if (p.e.use_grid) {
       normalize_pos(x, p.e.bound, true, xn);
       for (int l = wave; l < p.e.grid.n_levels; l += 4) {
-        uint32_t idx[8]; float w[8]; uint32_t cell[3];
-        grid_corners(p.e.grid, l, xn, idx, w, cell);
+        float w[8]; uint32_t cell[3];
+        grid_weights(p.e.grid, l, xn, w, cell);
         const uint32_t* tab = p.table + p.e.grid.offset[l];
-        // run-dedupe of the gathers: consecutive samples in the same cell read the same 8 entries; only the first lane
-        // of a run loads them, the others take them over the cross-lane network (gathers are request-rate bound)
+        // run-dedupe of the gathers: consecutive samples in the same cell read the same 8 entries; only the first sample
+        // of a run (its head) loads them (gathers are request-rate bound)
         uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
         const bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
         const unsigned long long hm = __ballot(head);
         const int hl = 63 - __clzll(hm & ((2ull << lane) - 1ull));   // head lane of this lane's run
-        uint32_t v[8];
+        // A gather costs one request per distinct 64-byte chunk per wave instruction (scripts/dev/probe_gather_pairs.hip),
+        // and the two x-neighbour corners of a cell sit in one chunk 15 times out of 16 (x prime = 1, 16 fp16x2 entries per
+        // chunk).  So the loads are issued in PAIR layout -- lanes 2j and 2j+1 fetch the x = 0 / x = 1 corner of sample
+        // j (+32 in the second half) -- which halves the requests; the values then travel back to the owning lane.
+        const uint32_t res = p.e.grid.res[l], size = p.e.grid.size[l];
+        const bool dense = p.e.grid.dense[l] != 0;
+        uint32_t r[2][4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = (head && valid) ? tab[idx[c]] : 0u;
+        for (int h = 0; h < 2; ++h) {
+          const int s = (lane >> 1) + 32 * h;
+          const uint32_t cx = __shfl(cell[0], s) + (uint32_t)(lane & 1), cy = __shfl(cell[1], s), cz = __shfl(cell[2], s);
+          const bool act = ((hm >> s) & 1ull) && (t * ENC_TILE + s < p.rows);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = __shfl(v[c], hl);
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t gy = cy + (uint32_t)(i & 1), gz = cz + (uint32_t)(i >> 1);
+            const uint32_t ix = dense ? (cx + gy * res + gz * res * res) : (cx ^ (gy * PRIME_Y) ^ (gz * PRIME_Z));
+            r[h][i] = act ? tab[ix % size] : 0u;
+          }
+        }
+        const int src = 2 * (hl & 31);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          h16x2 hv = *(h16x2*)&v[c];
+        for (int c = 0; c < 8; ++c) {   // corner c = x | y << 1 | z << 2 ; accumulation order c = 0..7 as in the oracle
+          const uint32_t t0 = __shfl(r[0][c >> 1], src + (c & 1)), t1 = __shfl(r[1][c >> 1], src + (c & 1));
+          const uint32_t vv = (hl >> 5) ? t1 : t0;
+          h16x2 hv = *(const h16x2*)&vv;
           a0 = __fadd_rn(a0, __fmul_rn(w[c], (float)hv[0]));
           a1 = __fadd_rn(a1, __fmul_rn(w[c], (float)hv[1]));
         }
