@@ -89,6 +89,58 @@ __device__ inline void grid_weights(const AlnGridDesc& g, int l, const float* xn
   }
 }
 
+// tcnn Frequency: out[d * 2n + 2k + {0, 1}] = sin(2^k pi x_d + {0, pi/2})
+__device__ inline h16 freq_feature(int n_freq, const float* xr, int j) {
+  int d = j / (2 * n_freq), k = (j / 2) % n_freq;
+  float arg = __fmul_rn(__fmul_rn(xr[d], (float)(1 << k)), 3.14159265358979323846f);
+  if (j & 1) arg = __fadd_rn(arg, 1.57079632679489661923f);
+  return (h16)sinf(arg);
+}
+
+// Features of level l for the 64 samples of a wave (lane = sample, base_row = row of lane 0).
+__device__ inline h16x2 level_features(const EncParams& p, int l, const float* xn, int lane, int base_row) {
+  float w[8]; uint32_t cell[3];
+  grid_weights(p.e.grid, l, xn, w, cell);
+  const uint32_t* tab = p.table + p.e.grid.offset[l];
+  // run-dedupe of the gathers: consecutive samples in the same cell read the same 8 entries; only the first sample
+  // of a run (its head) loads them
+  uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
+  const bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
+  const unsigned long long hm = __ballot(head);
+  const int hl = 63 - __clzll(hm & ((2ull << lane) - 1ull));   // head lane of this lane's run
+  // A gather costs one request per distinct 64-byte chunk per wave instruction (scripts/dev/probe_gather_pairs.hip),
+  // and the two x-neighbour corners of a cell sit in one chunk 15 times out of 16 (x prime = 1, 16 fp16x2 entries per
+  // chunk).  So the loads are issued in PAIR layout -- lanes 2j and 2j+1 fetch the x = 0 / x = 1 corner of sample
+  // j (+32 in the second half) -- which halves the requests; the values then travel back to the owning lane.
+  const uint32_t res = p.e.grid.res[l], size = p.e.grid.size[l];
+  const bool dense = p.e.grid.dense[l] != 0;
+  uint32_t r[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int s = (lane >> 1) + 32 * h;
+    const uint32_t cx = __shfl(cell[0], s) + (uint32_t)(lane & 1), cy = __shfl(cell[1], s), cz = __shfl(cell[2], s);
+    const bool act = ((hm >> s) & 1ull) && (base_row + s < p.rows);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t gy = cy + (uint32_t)(i & 1), gz = cz + (uint32_t)(i >> 1);
+      const uint32_t ix = dense ? (cx + gy * res + gz * res * res) : (cx ^ (gy * PRIME_Y) ^ (gz * PRIME_Z));
+      r[h][i] = act ? tab[ix % size] : 0u;
+    }
+  }
+  const int src = 2 * (hl & 31);
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {   // corner c = x | y << 1 | z << 2 ; accumulation order c = 0..7 as in the oracle
+    const uint32_t t0 = __shfl(r[0][c >> 1], src + (c & 1)), t1 = __shfl(r[1][c >> 1], src + (c & 1));
+    const uint32_t vv = (hl >> 5) ? t1 : t0;
+    h16x2 hv = *(const h16x2*)&vv;
+    a0 = __fadd_rn(a0, __fmul_rn(w[c], (float)hv[0]));
+    a1 = __fadd_rn(a1, __fmul_rn(w[c], (float)hv[1]));
+  }
+  h16x2 o; o[0] = (h16)a0; o[1] = (h16)a1;
+  return o;
+}
+
 __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h16* tile = (h16*)smem;  // [ENC_TILE][enc_pad]
@@ -103,48 +155,8 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
     if (valid) row_position(p, row, x);
     if (p.e.use_grid) {
       normalize_pos(x, p.e.bound, true, xn);
-      for (int l = wave; l < p.e.grid.n_levels; l += 4) {
-        float w[8]; uint32_t cell[3];
-        grid_weights(p.e.grid, l, xn, w, cell);
-        const uint32_t* tab = p.table + p.e.grid.offset[l];
-        // run-dedupe of the gathers: consecutive samples in the same cell read the same 8 entries; only the first sample
-        // of a run (its head) loads them (gathers are request-rate bound)
-        uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
-        const bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
-        const unsigned long long hm = __ballot(head);
-        const int hl = 63 - __clzll(hm & ((2ull << lane) - 1ull));   // head lane of this lane's run
-        // A gather costs one request per distinct 64-byte chunk per wave instruction (scripts/dev/probe_gather_pairs.hip),
-        // and the two x-neighbour corners of a cell sit in one chunk 15 times out of 16 (x prime = 1, 16 fp16x2 entries per
-        // chunk).  So the loads are issued in PAIR layout -- lanes 2j and 2j+1 fetch the x = 0 / x = 1 corner of sample
-        // j (+32 in the second half) -- which halves the requests; the values then travel back to the owning lane.
-        const uint32_t res = p.e.grid.res[l], size = p.e.grid.size[l];
-        const bool dense = p.e.grid.dense[l] != 0;
-        uint32_t r[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int s = (lane >> 1) + 32 * h;
-          const uint32_t cx = __shfl(cell[0], s) + (uint32_t)(lane & 1), cy = __shfl(cell[1], s), cz = __shfl(cell[2], s);
-          const bool act = ((hm >> s) & 1ull) && (t * ENC_TILE + s < p.rows);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t gy = cy + (uint32_t)(i & 1), gz = cz + (uint32_t)(i >> 1);
-            const uint32_t ix = dense ? (cx + gy * res + gz * res * res) : (cx ^ (gy * PRIME_Y) ^ (gz * PRIME_Z));
-            r[h][i] = act ? tab[ix % size] : 0u;
-          }
-        }
-        const int src = 2 * (hl & 31);
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {   // corner c = x | y << 1 | z << 2 ; accumulation order c = 0..7 as in the oracle
-          const uint32_t t0 = __shfl(r[0][c >> 1], src + (c & 1)), t1 = __shfl(r[1][c >> 1], src + (c & 1));
-          const uint32_t vv = (hl >> 5) ? t1 : t0;
-          h16x2 hv = *(const h16x2*)&vv;
-          a0 = __fadd_rn(a0, __fmul_rn(w[c], (float)hv[0]));
-          a1 = __fadd_rn(a1, __fmul_rn(w[c], (float)hv[1]));
-        }
-        h16x2 o; o[0] = (h16)a0; o[1] = (h16)a1;
-        *(h16x2*)&tile[lane * pad + fdim + 2 * l] = o;
-      }
+      for (int l = p.level_lo + wave; l < p.level_hi; l += 4)
+        *(h16x2*)&tile[lane * pad + fdim + 2 * l] = level_features(p, l, xn, lane, t * ENC_TILE);
     }
     // frequency part + ones padding: (row, j) pairs spread over the block
     const int extra0 = p.e.enc_dim;  // padding starts here
@@ -156,10 +168,7 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
       float xr[3] = {0, 0, 0};
       if (rr < p.rows) row_position(p, rr, xr);
       if (p.e.freq_normalized) { float q[3]; normalize_pos(xr, p.e.bound, false, q); xr[0] = q[0]; xr[1] = q[1]; xr[2] = q[2]; }
-      int d = j / (2 * p.e.n_freq), k = (j / 2) % p.e.n_freq;
-      float arg = __fmul_rn(__fmul_rn(xr[d], (float)(1 << k)), 3.14159265358979323846f);
-      if (j & 1) arg = __fadd_rn(arg, 1.57079632679489661923f);
-      tile[r * pad + j] = (h16)sinf(arg);
+      tile[r * pad + j] = freq_feature(p.e.n_freq, xr, j);
     }
     __syncthreads();
     // coalesced write-out of the whole tile (rows are contiguous in memory)
@@ -170,6 +179,76 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
     for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------- level-phased forward
+// scripts/dev/probe_encode_fwd_levels.py: with all 16 levels in flight the gathers miss the 4 MB L2 of every XCD (28.5 MB of
+// tables) and the kernel runs at the rate the Infinity Cache delivers 64-byte lines: 21 us per level and 512 K samples.
+// One or two levels at a time stay L2-resident: 6 us per level.  So for large row counts the levels are processed in PHASES:
+// blocks are enumerated level-group-major (the dispatcher hands them out in order, so at any time the chip works on one or
+// two neighbouring groups of two levels = 4 MB of table), every wave writes its 64 samples' features of a level as one
+// coalesced 256-byte store into a per-level plane, and a second, streaming kernel assembles the row-major [rows, enc_pad]
+// operand (frequency features, planes, ones) the MLP reads.
+#define ENC_LG 2   // levels per phase
+__global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.x / nblk, b = blockIdx.x % nblk;
+  const int base_row = (b * 4 + wave) * 64;
+  if (base_row >= p.rows) return;
+  const int row = base_row + lane;
+  float x[3] = {0, 0, 0}, xn[3];
+  if (row < p.rows) row_position(p, row, x);
+  normalize_pos(x, p.e.bound, true, xn);
+#pragma unroll
+  for (int i = 0; i < ENC_LG; ++i) {
+    const int l = g * ENC_LG + i;
+    if (l < p.e.grid.n_levels) {
+      const h16x2 o = level_features(p, l, xn, lane, base_row);
+      if (row < p.rows) planes[(size_t)l * p.rows + row] = o;
+    }
+  }
+}
+__global__ void k_encode_assemble(EncParams p, const h16x2* __restrict__ planes, h16* __restrict__ out) {
+  const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq, gdim = 2 * p.e.grid.n_levels, nch = pad / 8;
+  const size_t total = (size_t)p.rows * nch;
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(t / nch), c0 = 8 * (int)(t % nch);
+    h16x8 v;
+    float xr[3] = {0, 0, 0};
+    if (c0 < fdim) {
+      row_position(p, row, xr);
+      if (p.e.freq_normalized) { float q[3]; normalize_pos(xr, p.e.bound, false, q); xr[0] = q[0]; xr[1] = q[1]; xr[2] = q[2]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      if (c < fdim) v[j] = freq_feature(p.e.n_freq, xr, c);
+      else if (c < fdim + gdim) { const h16x2 f = planes[(size_t)((c - fdim) >> 1) * p.rows + row]; v[j] = f[(c - fdim) & 1]; }
+      else v[j] = (h16)1.0f;
+    }
+    *(h16x8*)(out + (size_t)row * pad + c0) = v;
+  }
+}
+
+static int fill_params(EncParams& p, const AlnEncDesc* e, const void* table, const float* rays_o, const float* rays_d,
+                       const float* z, const float* xyz, int rows, int stride);
+extern "C" int64_t aln_encode_fwd_ws_bytes(const AlnEncDesc* e, int32_t rows) {
+  return (e && e->use_grid && rows > 0) ? (int64_t)e->grid.n_levels * rows * (int64_t)sizeof(h16x2) : 0;
+}
+extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
+                                     const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* planes_ws,
+                                     void* enc_out, void* stream) {
+  EncParams p;
+  if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
+  ALN_REQUIRE(e->use_grid && table_f16 && planes_ws && enc_out, "encode_fwd_phased: needs a grid encoding, its table and the plane workspace");
+  if (rows == 0) return 0;
+  const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + ENC_LG - 1) / ENC_LG;
+  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk);
+  ALN_CHECK_LAUNCH("encode_grid_phased");
+  hipLaunchKernelGGL(k_encode_assemble, dim3(aln_grid_for((int64_t)rows * (e->enc_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream, p,
+                     (const h16x2*)planes_ws, (h16*)enc_out);
+  ALN_CHECK_LAUNCH("encode_assemble");
+  return 0;
 }
 
 // Backward: scatter-add of w_c * dL/dfeat into the fp32 gradient table.
@@ -275,6 +354,22 @@ extern "C" int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const 
   size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);
   hipLaunchKernelGGL(k_encode_fwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (h16*)enc_out);
   ALN_CHECK_LAUNCH("encode_fwd");
+  return 0;
+}
+
+// dev probe (scripts/dev/probe_encode_fwd_levels.py): forward for levels [level_lo, level_hi) only (other columns stay unwritten)
+extern "C" int aln_dev_encode_fwd_levels(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
+                                         const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* enc_out,
+                                         int32_t level_lo, int32_t level_hi, void* stream) {
+  EncParams p;
+  if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
+  if (rows == 0) return 0;
+  p.level_lo = level_lo; p.level_hi = level_hi;
+  int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
+  int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);
+  hipLaunchKernelGGL(k_encode_fwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (h16*)enc_out);
+  ALN_CHECK_LAUNCH("encode_fwd_levels");
   return 0;
 }
 

@@ -153,6 +153,7 @@ class HipPipeline:
         self.ws = Workspace(params.device)
         self.density_scale, self.min_near = float(density_scale), float(min_near)
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
+        self.phased_min_rows = 1 << 16   # hash-grid forward: level-phased from this many sample rows on
         self.recompute = True  # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward)
         self.kernel_events = None  # bench.py: list of ((start, end) HIP events, kernel, tag) around the timed launches
 
@@ -211,8 +212,14 @@ class HipPipeline:
     # ---- point queries (models.py:175-188, 190-220, 248-256)
     def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train):
         e, s = self.L.enc, self.L.nets['sigma']
-        H.call('aln_encode_fwd', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows,
-               stride, H.ptr(enc), H.stream())
+        if e.use_grid and rows >= self.phased_min_rows:
+            # large batches: level-phased gathers (tables in flight stay L2-resident) + streaming row assembly
+            planes = self.ws.get('enc_planes', (int(e.grid.n_levels), rows, 2), f16)
+            H.call('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz),
+                   rows, stride, H.ptr(planes), H.ptr(enc), H.stream())
+        else:
+            H.call('aln_encode_fwd', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows,
+                   stride, H.ptr(enc), H.stream())
         save = train and not self.recompute
         self._k('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, H.ptr(h1) if save else None,
                 H.ptr(h2) if save else None, H.ptr(out), H.stream(), tag=('sigma', rows))

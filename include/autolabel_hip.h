@@ -118,6 +118,12 @@ int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const float* rays
                    const float* z /*[rows]*/, const float* xyz /*[rows,3] or NULL*/, int32_t rows,
                    int32_t rays_stride /*samples per ray for this pass*/, void* enc_out /*[rows,enc_pad] f16*/,
                    void* stream);
+/* the same result for large row counts, level-phased so that the tables in flight stay L2-resident (encode.hip); planes_ws is
+ * caller-owned scratch of aln_encode_fwd_ws_bytes(e, rows) bytes */
+int64_t aln_encode_fwd_ws_bytes(const AlnEncDesc* e, int32_t rows);
+int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
+                          const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* planes_ws, void* enc_out,
+                          void* stream);
 int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
                    int32_t rows, int32_t rays_stride, const void* d_enc /*[rows,enc_pad] f16*/,
                    float* grad_table /*[n_entries*F] f32*/, void* stream);

@@ -144,3 +144,26 @@ def test_full_frame_rays_are_unit_length_and_norms_follow_the_pinhole_formula(H)
     assert (dirs.cpu().double().norm(dim=1) - 1).abs().max().item() <= 3e-7
     want_sum = (R.double() @ (cam / n64[:, None]).sum(dim=0))
     assert (dirs.cpu().double().sum(dim=0) - want_sum).abs().max().item() <= 1e-2   # 307200 fp32 roundings
+
+
+@pytest.mark.parametrize('encoding', ['hg+freq', 'hg'])
+def test_level_phased_forward_encode_is_bit_identical_to_the_single_kernel(H, encoding):
+    """The level-phased forward (two kernels, per-level planes) must reproduce the tile kernel bit for bit, including a
+    ragged tail (rows not a multiple of 256) and point (xyz) input."""
+    bound = 3.0
+    e = H.make_enc_desc(encoding, bound)
+    spec = O.GridSpec()
+    g = torch.Generator().manual_seed(6)
+    table = ((torch.rand(spec.n_entries, 2, generator=g) - 0.5)).half().cuda()
+    for N, S, use_xyz in ((2048, 128, False), (777, 93, False), (70001, 1, True)):
+        rows = N * S
+        ro, rd = _rays(N, bound, 7)
+        z = (torch.rand(N, S, generator=g).sort(dim=1)[0] * 5 + 0.2).cuda().reshape(-1).contiguous()
+        xyz = ((torch.rand(rows, 3, generator=g) * 2 - 1) * bound * 1.05).cuda() if use_xyz else None
+        a = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+        b = torch.zeros_like(a)
+        ws = torch.empty(H.lib().aln_encode_fwd_ws_bytes(C.byref(e), rows), dtype=torch.uint8, device='cuda')
+        args = (H.ptr(table), None, None, None, H.ptr(xyz)) if use_xyz else (H.ptr(table), H.ptr(ro), H.ptr(rd), H.ptr(z), None)
+        H.call('aln_encode_fwd', C.byref(e), *args, rows, S, H.ptr(a), H.stream())
+        H.call('aln_encode_fwd_phased', C.byref(e), *args, rows, S, H.ptr(ws), H.ptr(b), H.stream())
+        assert torch.equal(a, b), (encoding, N, S)
