@@ -185,12 +185,12 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
 // scripts/dev/probe_encode_fwd_levels.py: with all 16 levels in flight the gathers miss the 4 MB L2 of every XCD (28.5 MB of
 // tables) and the kernel runs at the rate the Infinity Cache delivers 64-byte lines: 21 us per level and 512 K samples.
 // One or two levels at a time stay L2-resident: 6 us per level.  So for large row counts the levels are processed in PHASES:
-// blocks are enumerated level-group-major (the dispatcher hands them out in order, so at any time the chip works on one or
-// two neighbouring groups of two levels = 4 MB of table), every wave writes its 64 samples' features of a level as one
+// blocks are enumerated level-major (the dispatcher hands them out in order, so at any time the chip works on one or
+// two neighbouring levels = 4 MB of table), every wave writes its 64 samples' features of a level as one
 // coalesced 256-byte store into a per-level plane, and a second, streaming kernel assembles the row-major [rows, enc_pad]
 // operand (frequency features, planes, ones) the MLP reads.
-#define ENC_LG 2   // levels per phase
-__global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk) {
+#define ENC_LG 1   // levels per phase (measured: 1 -> 135 us, 2 -> 140 us, 4 -> 202 us per 512 K samples; ALN_ENC_LG overrides)
+__global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.x / nblk, b = blockIdx.x % nblk;
   const int base_row = (b * 4 + wave) * 64;
@@ -199,9 +199,8 @@ __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* 
   float x[3] = {0, 0, 0}, xn[3];
   if (row < p.rows) row_position(p, row, x);
   normalize_pos(x, p.e.bound, true, xn);
-#pragma unroll
-  for (int i = 0; i < ENC_LG; ++i) {
-    const int l = g * ENC_LG + i;
+  for (int i = 0; i < lg; ++i) {
+    const int l = g * lg + i;
     if (l < p.e.grid.n_levels) {
       const h16x2 o = level_features(p, l, xn, lane, base_row);
       if (row < p.rows) planes[(size_t)l * p.rows + row] = o;
@@ -209,24 +208,25 @@ __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* 
   }
 }
 __global__ void k_encode_assemble(EncParams p, const h16x2* __restrict__ planes, h16* __restrict__ out) {
+  // one thread per row: the plane reads of a wave are 256 contiguous bytes per level, the row goes out as 16-byte pieces
   const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq, gdim = 2 * p.e.grid.n_levels, nch = pad / 8;
-  const size_t total = (size_t)p.rows * nch;
-  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const int row = (int)(t / nch), c0 = 8 * (int)(t % nch);
-    h16x8 v;
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < p.rows; row += gridDim.x * blockDim.x) {
     float xr[3] = {0, 0, 0};
-    if (c0 < fdim) {
+    if (fdim) {
       row_position(p, row, xr);
       if (p.e.freq_normalized) { float q[3]; normalize_pos(xr, p.e.bound, false, q); xr[0] = q[0]; xr[1] = q[1]; xr[2] = q[2]; }
     }
+    for (int ch = 0; ch < nch; ++ch) {
+      h16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c0 + j;
-      if (c < fdim) v[j] = freq_feature(p.e.n_freq, xr, c);
-      else if (c < fdim + gdim) { const h16x2 f = planes[(size_t)((c - fdim) >> 1) * p.rows + row]; v[j] = f[(c - fdim) & 1]; }
-      else v[j] = (h16)1.0f;
+      for (int j = 0; j < 8; j += 2) {
+        const int c = 8 * ch + j;   // fdim and gdim are even: a pair never straddles two parts
+        if (c < fdim) { v[j] = freq_feature(p.e.n_freq, xr, c); v[j + 1] = freq_feature(p.e.n_freq, xr, c + 1); }
+        else if (c < fdim + gdim) { const h16x2 f = planes[(size_t)((c - fdim) >> 1) * p.rows + row]; v[j] = f[0]; v[j + 1] = f[1]; }
+        else { v[j] = (h16)1.0f; v[j + 1] = (h16)1.0f; }
+      }
+      *(h16x8*)(out + (size_t)row * pad + 8 * ch) = v;
     }
-    *(h16x8*)(out + (size_t)row * pad + c0) = v;
   }
 }
 
@@ -242,10 +242,11 @@ extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16,
   if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
   ALN_REQUIRE(e->use_grid && table_f16 && planes_ws && enc_out, "encode_fwd_phased: needs a grid encoding, its table and the plane workspace");
   if (rows == 0) return 0;
-  const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + ENC_LG - 1) / ENC_LG;
-  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk);
+  static const int lg = getenv("ALN_ENC_LG") ? atoi(getenv("ALN_ENC_LG")) : ENC_LG;
+  const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
+  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
   ALN_CHECK_LAUNCH("encode_grid_phased");
-  hipLaunchKernelGGL(k_encode_assemble, dim3(aln_grid_for((int64_t)rows * (e->enc_pad / 8), 256)), dim3(256), 0, (hipStream_t)stream, p,
+  hipLaunchKernelGGL(k_encode_assemble, dim3(aln_grid_for((int64_t)rows, 256)), dim3(256), 0, (hipStream_t)stream, p,
                      (const h16x2*)planes_ws, (h16*)enc_out);
   ALN_CHECK_LAUNCH("encode_assemble");
   return 0;
