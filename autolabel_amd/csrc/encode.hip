@@ -207,26 +207,39 @@ __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* 
     }
   }
 }
-__global__ void k_encode_assemble(EncParams p, const h16x2* __restrict__ planes, h16* __restrict__ out) {
-  // one thread per row: the plane reads of a wave are 256 contiguous bytes per level, the row goes out as 16-byte pieces
-  const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq, gdim = 2 * p.e.grid.n_levels, nch = pad / 8;
-  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < p.rows; row += gridDim.x * blockDim.x) {
-    float xr[3] = {0, 0, 0};
-    if (fdim) {
-      row_position(p, row, xr);
-      if (p.e.freq_normalized) { float q[3]; normalize_pos(xr, p.e.bound, false, q); xr[0] = q[0]; xr[1] = q[1]; xr[2] = q[2]; }
-    }
-    for (int ch = 0; ch < nch; ++ch) {
-      h16x8 v;
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        const int c = 8 * ch + j;   // fdim and gdim are even: a pair never straddles two parts
-        if (c < fdim) { v[j] = freq_feature(p.e.n_freq, xr, c); v[j + 1] = freq_feature(p.e.n_freq, xr, c + 1); }
-        else if (c < fdim + gdim) { const h16x2 f = planes[(size_t)((c - fdim) >> 1) * p.rows + row]; v[j] = f[0]; v[j + 1] = f[1]; }
-        else { v[j] = (h16)1.0f; v[j + 1] = (h16)1.0f; }
+__global__ __launch_bounds__(256) void k_encode_assemble(EncParams p, const h16x2* __restrict__ planes, h16* __restrict__ out) {
+  // one thread per row builds it in an LDS tile (plane reads of a wave: 256 contiguous bytes per level); the block then
+  // writes its 256 rows as one contiguous run of 16-byte pieces (row-per-lane 16-byte stores cost 2.5x the bytes in HBM
+  // write traffic: WRITE_SIZE)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* tile = (h16*)smem;   // [256][pad + 8]: the +8 halves keep the row-per-lane 16-byte LDS stores off a 4-way conflict
+  const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq, gdim = 2 * p.e.grid.n_levels, nch = pad / 8, tp = pad + 8;
+  const int nblk = (p.rows + 255) / 256;
+  for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int row = b * 256 + threadIdx.x;
+    if (row < p.rows) {
+      float xr[3] = {0, 0, 0};
+      if (fdim) {
+        row_position(p, row, xr);
+        if (p.e.freq_normalized) { float q[3]; normalize_pos(xr, p.e.bound, false, q); xr[0] = q[0]; xr[1] = q[1]; xr[2] = q[2]; }
       }
-      *(h16x8*)(out + (size_t)row * pad + 8 * ch) = v;
+      for (int ch = 0; ch < nch; ++ch) {
+        h16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const int c = 8 * ch + j;   // fdim and gdim are even: a pair never straddles two parts
+          if (c < fdim) { v[j] = freq_feature(p.e.n_freq, xr, c); v[j + 1] = freq_feature(p.e.n_freq, xr, c + 1); }
+          else if (c < fdim + gdim) { const h16x2 f = planes[(size_t)((c - fdim) >> 1) * p.rows + row]; v[j] = f[0]; v[j + 1] = f[1]; }
+          else { v[j] = (h16)1.0f; v[j + 1] = (h16)1.0f; }
+        }
+        *(h16x8*)(tile + threadIdx.x * tp + 8 * ch) = v;
+      }
     }
+    __syncthreads();
+    const int rows_here = min(256, p.rows - b * 256);
+    uint4* dst = (uint4*)(out + (size_t)b * 256 * pad);
+    for (int i = threadIdx.x; i < rows_here * nch; i += 256) dst[i] = *(const uint4*)(tile + (i / nch) * tp + 8 * (i % nch));
+    __syncthreads();
   }
 }
 
@@ -246,7 +259,7 @@ extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16,
   const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
   hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
   ALN_CHECK_LAUNCH("encode_grid_phased");
-  hipLaunchKernelGGL(k_encode_assemble, dim3(aln_grid_for((int64_t)rows, 256)), dim3(256), 0, (hipStream_t)stream, p,
+  hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
                      (const h16x2*)planes_ws, (h16*)enc_out);
   ALN_CHECK_LAUNCH("encode_assemble");
   return 0;
