@@ -55,16 +55,21 @@ __device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn
     fr[k] = __fsub_rn(pos, fl);
   }
   if (base) { base[0] = gi[0]; base[1] = gi[1]; base[2] = gi[2]; }
+  // index terms per axis: the +1 corner is one add away from the base corner (uint32 wrap-around keeps (g + 1) * P exact),
+  // and "% size" is a mask for the hashed levels (size = 2^k) and one conditional subtract for the dense ones
+  // (index <= res + res^2 + res^3 < 2 * size): 2 integer multiplies per level instead of 16 and no division
+  const uint32_t ty = dense ? res : PRIME_Y, tz = dense ? res * res : PRIME_Z;
+  const uint32_t ay[2] = {gi[1] * ty, gi[1] * ty + ty}, az[2] = {gi[2] * tz, gi[2] * tz + tz};
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    float ww = 1.0f; uint32_t cg[3];
+    float ww = 1.0f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (c & (1 << k)) { ww = __fmul_rn(ww, fr[k]); cg[k] = gi[k] + 1u; }
-      else { ww = __fmul_rn(ww, __fsub_rn(1.0f, fr[k])); cg[k] = gi[k]; }
-    }
-    uint32_t i = dense ? (cg[0] + cg[1] * res + cg[2] * res * res) : (cg[0] ^ (cg[1] * PRIME_Y) ^ (cg[2] * PRIME_Z));
-    idx[c] = i % size;
+    for (int k = 0; k < 3; ++k) ww = (c & (1 << k)) ? __fmul_rn(ww, fr[k]) : __fmul_rn(ww, __fsub_rn(1.0f, fr[k]));
+    const uint32_t gx = gi[0] + (uint32_t)(c & 1);
+    uint32_t i;
+    if (dense) { i = gx + ay[(c >> 1) & 1] + az[c >> 2]; i = i >= size ? i - size : i; }
+    else i = (gx ^ ay[(c >> 1) & 1] ^ az[c >> 2]) & (size - 1u);
+    idx[c] = i;
     w[c] = ww;
   }
 }
@@ -114,17 +119,20 @@ __device__ inline h16x2 level_features(const EncParams& p, int l, const float* x
   // j (+32 in the second half) -- which halves the requests; the values then travel back to the owning lane.
   const uint32_t res = p.e.grid.res[l], size = p.e.grid.size[l];
   const bool dense = p.e.grid.dense[l] != 0;
+  const uint32_t ty = dense ? res : PRIME_Y, tz = dense ? res * res : PRIME_Z;
   uint32_t r[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int s = (lane >> 1) + 32 * h;
     const uint32_t cx = __shfl(cell[0], s) + (uint32_t)(lane & 1), cy = __shfl(cell[1], s), cz = __shfl(cell[2], s);
     const bool act = ((hm >> s) & 1ull) && (base_row + s < p.rows);
+    const uint32_t ay[2] = {cy * ty, cy * ty + ty}, az[2] = {cz * tz, cz * tz + tz};   // see grid_corners
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const uint32_t gy = cy + (uint32_t)(i & 1), gz = cz + (uint32_t)(i >> 1);
-      const uint32_t ix = dense ? (cx + gy * res + gz * res * res) : (cx ^ (gy * PRIME_Y) ^ (gz * PRIME_Z));
-      r[h][i] = act ? tab[ix % size] : 0u;
+      uint32_t ix;
+      if (dense) { ix = cx + ay[i & 1] + az[i >> 1]; ix = ix >= size ? ix - size : ix; }
+      else ix = (cx ^ ay[i & 1] ^ az[i >> 1]) & (size - 1u);
+      r[h][i] = act ? tab[ix] : 0u;
     }
   }
   const int src = 2 * (hl & 31);
