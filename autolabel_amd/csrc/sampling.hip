@@ -432,7 +432,6 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
     }
     __syncthreads();
     if (rowmajor_dots) {
-#pragma unroll 2
       for (int k = rg; k < S; k += rpi) {   // S % rpi == 0 is not required: k only feeds loads and the final store
         const size_t row = row_of(ray, k, p.N, p.S1, p.S2);
         float acc = 0.f;
