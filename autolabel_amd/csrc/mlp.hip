@@ -192,6 +192,7 @@ __device__ inline void zero_acc(f32x16 (&acc)[NB]) {
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline uint32_t cvt_pk(float a, float b) {   // v_cvt_pk_f16_f32 (RNE)
   union { h16x2 h; uint32_t w; } u; u.h = __builtin_convertvector((f32x2){a, b}, h16x2);
   return u.w;
@@ -445,6 +446,105 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, s
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------- both semantic heads, forward, one kernel
+// semantic_features (G -> 64 -> 64 -> D = 64) and semantic_out (cat[relu(f), geo_feat] -> 64 -> C) of models.py:248-256 on the
+// same 32-row tile: f goes through a wave-private LDS tile, from which it is (a) written out as whole 128-byte rows and
+// (b) read back -- ReLU applied -- in the natural k-order of semantic_out's first layer, so both heads keep their ordinary
+// fragment images and f is never re-read from HBM (the two-launch path reads it back: 128 B/sample, 24 % of a render pass).
+template <int KSG>   // k-steps of the geo_feat input of both heads (in_pad of semantic_features / 16 = 1)
+__global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ wf_f, size_t halves_f, const h16* __restrict__ wf_o,
+                                                      size_t halves_o, const h16* __restrict__ sigma_out, int rows, int G,
+                                                      int out_pad_o, h16* __restrict__ feat, h16* __restrict__ logits) {
+  constexpr int HID = 64, D = 64, NB = 2, KS = 4, PT = D + 8;   // PT: pitch of the f tile (row-per-lane 16-byte reads conflict-free)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  h16* wl_f = (h16*)smem;
+  h16* wl_o = wl_f + ((halves_f + 7) & ~(size_t)7);
+  lds_h16* ftile = (lds_h16*)(wl_o + ((halves_o + 7) & ~(size_t)7)) + (threadIdx.x >> 6) * (32 * PT);
+  copy_to_lds(wl_f, wf_f, halves_f);
+  copy_to_lds(wl_o, wf_o, halves_o);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
+  const int OBO = ceil32(out_pad_o);
+  constexpr int KS0O = D / 16 + KSG;                        // semantic_out layer 0: relu(f) k-steps + the geo_feat k-step
+  const size_t f1 = (size_t)NB * KSG, fl = f1 + (size_t)NB * KS;   // semantic_features: layer 1 / last layer fragments
+  const size_t flo = (size_t)NB * KS0O;                             // semantic_out: last layer fragments
+  const int ntiles = (rows + 31) / 32, tstride = gridDim.x * 4;
+  h16x8 xb[KSG];
+  auto load_x = [&](int t) {
+    const int r = t * 32 + c;
+#pragma unroll
+    for (int ks = 0; ks < KSG; ++ks) {
+      const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      xb[ks] = (r < rows) ? geo_chunk(sigma_out, (size_t)r, 16 * ks + 8 * hf, G) : z;
+    }
+  };
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < ntiles) load_x(tile);
+  for (; tile < ntiles; tile += tstride) {
+    const int row0 = tile * 32, row = row0 + c;
+    const bool valid = row < rows;
+    int fo = 0;
+    asm volatile("" : "+v"(fo));                             // keep the fragments in LDS (see k_mlp_fwd)
+    const h16x8* ff = (const h16x8*)wl_f + fo;
+    const h16x8* fo_ = (const h16x8*)wl_o + fo;
+    f32x16 acc[NB];
+    h16x8 p[KS], geo[KSG];
+#pragma unroll
+    for (int ks = 0; ks < KSG; ++ks) geo[ks] = xb[ks];
+    chain_layer<NB, KSG>(acc, [&](int m, int ks) { return ff[((size_t)m * KSG + ks) * 64 + lane]; }, [&](int ks) { return geo[ks]; });
+    if (tile + tstride < ntiles) load_x(tile + tstride);
+    relu_pack_store<NB>(acc, p, nullptr, hf);
+    chain_layer<NB, KS>(acc, [&](int m, int ks) { return ff[(f1 + (size_t)m * KS + ks) * 64 + lane]; }, [&](int ks) { return p[ks]; });
+    relu_pack_store<NB>(acc, p, nullptr, hf);
+    // f = last layer of semantic_features (no activation) -> wave-private tile, row-major
+    chain_layer<NB, KS>(acc, [&](int m, int ks) { return ff[(fl + (size_t)m * KS + ks) * 64 + lane]; }, [&](int ks) { return p[ks]; });
+#pragma unroll
+    for (int m = 0; m < NB; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(LDS_VEC(u32x2)*)(ftile + c * PT + 32 * m + 8 * q + 4 * hf) =
+            (u32x2){cvt_pk(acc[m][4 * q], acc[m][4 * q + 1]), cvt_pk(acc[m][4 * q + 2], acc[m][4 * q + 3])};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (a) the 32 rows of f leave as contiguous 16-byte pieces
+    const int rows_here = min(32, rows - row0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = lane + 64 * i, r = pc >> 3, ch = pc & 7;
+      if (r < rows_here) *(u32x4*)(feat + (size_t)(row0 + r) * D + 8 * ch) = *(const LDS_VEC(u32x4)*)(ftile + r * PT + 8 * ch);
+    }
+    // (b) semantic_out layer 0: relu(f) in natural k-order from the tile, then the geo_feat chunk
+    chain_layer<NB, KS0O>(acc, [&](int m, int ks) { return fo_[((size_t)m * KS0O + ks) * 64 + lane]; },
+                          [&](int ks) {
+                            if (ks >= D / 16) return geo[ks - D / 16];
+                            union { u32x4 u; s16x2 i[4]; h16x8 v; } b;
+                            b.u = *(const LDS_VEC(u32x4)*)(ftile + c * PT + 16 * ks + 8 * hf);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) b.i[j] = __builtin_elementwise_max(b.i[j], (s16x2){0, 0});
+                            return b.v;
+                          });
+    relu_pack_store<NB>(acc, p, nullptr, hf);
+    for (int ob = 0; ob < OBO; ++ob) {
+      f32x16 o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) o = mfma16(fo_[(flo + (size_t)ob * KS + ks) * 64 + lane], p[ks], o);
+      if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int f = 32 * ob + 8 * q + 4 * hf;
+          if (f < out_pad_o) {
+            h16x4 v; v[0] = (h16)o[4 * q]; v[1] = (h16)o[4 * q + 1]; v[2] = (h16)o[4 * q + 2]; v[3] = (h16)o[4 * q + 3];
+            *(h16x4*)(logits + (size_t)row * out_pad_o + f) = v;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next iteration's f
   }
 }
 
@@ -1254,6 +1354,17 @@ extern "C" int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
                                  int32_t G, void* feat, void* logits, void* stream) {
   ALN_REQUIRE(semf && semo && sigma_out && feat && logits, "sem_heads_fwd: NULL pointer");
   ALN_REQUIRE(semf->out_pad == D && semo->in_pad >= D + G + 1 && D % 8 == 0, "sem_heads_fwd: shape mismatch");
+  if (semf->in_pad == 16 && semf->hidden == 64 && semf->n_hidden == 2 && semf->out_pad == 64 && D == 64 && semo->in_pad == 80 &&
+      semo->hidden == 64 && semo->n_hidden == 1 && semo->out_pad <= 64 && semf->wf && semo->wf && !getenv("ALN_SEM_FWD_UNFUSED")) {
+    if (rows <= 0) return 0;
+    size_t hf_ = (size_t)aln_mlp_frag_halves(16, 64, 64, 2, 0), ho_ = (size_t)aln_mlp_frag_halves(80, 64, semo->out_pad, 1, 0);
+    size_t lds = (((hf_ + 7) & ~(size_t)7) + ((ho_ + 7) & ~(size_t)7) + 4 * 32 * (64 + 8)) * 2;
+    hipFuncSetAttribute((const void*)k_sem_fwd_fused<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_sem_fwd_fused<1>), dim3(mlp_grid(rows)), dim3(256), lds, (hipStream_t)stream, (const h16*)semf->wf, hf_,
+                       (const h16*)semo->wf, ho_, (const h16*)sigma_out, rows, G, semo->out_pad, (h16*)feat, (h16*)logits);
+    ALN_CHECK_LAUNCH("sem_fwd_fused");
+    return 0;
+  }
   RowSrc a{}; a.mode = SRC_SEMF_IN; a.a = (const h16*)sigma_out; a.lda = 16; a.G = G; a.D = D;
   if (int rc = mlp_fwd_src(semf, a, rows, nullptr, nullptr, nullptr, feat, stream)) return rc;
   RowSrc b{}; b.mode = SRC_SEMO_IN; b.a = (const h16*)feat; b.lda = D; b.b = (const h16*)sigma_out; b.ldb = 16; b.G = G; b.D = D;

@@ -406,3 +406,26 @@ def test_sample_fine_matches_sample_pdf(H, perturb):
     assert (got[:, 1:] >= got[:, :-1]).all()
     # parallel scans re-associate the cumprod / cumsum: 1e-4 of the ray span (cdf steps can be steep)
     assert (got - want).abs().max() <= 2e-4 * far.max().item()
+
+
+def test_fused_semantic_heads_forward_is_bit_identical_to_two_launches(H):
+    """k_sem_fwd_fused keeps f in a wave-private LDS tile; same fragments, same k-order -> same bits as the two-kernel path."""
+    _, dF, keepF = _mlp_setup(H, 16, 64, 64, 2, seed=3)
+    _, dO, keepO = _mlp_setup(H, 80, 64, 16, 1, seed=4)
+    rows = 5000 + 17                       # ragged: not a multiple of 32
+    g = torch.Generator().manual_seed(5)
+    sigma_out = (torch.randn(rows, 16, generator=g)).half().cuda()
+    outs = []
+    for unfused in (False, True):
+        if unfused:
+            os.environ['ALN_SEM_FWD_UNFUSED'] = '1'
+        try:
+            feat = torch.zeros(rows, 64, dtype=torch.float16, device='cuda')
+            logits = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
+            H.call('aln_sem_heads_fwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, 15, H.ptr(feat), H.ptr(logits), H.stream())
+            torch.cuda.synchronize()
+            outs.append((feat.cpu(), logits.cpu()))
+        finally:
+            os.environ.pop('ALN_SEM_FWD_UNFUSED', None)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].abs().max() > 0 and outs[0][1].abs().max() > 0
