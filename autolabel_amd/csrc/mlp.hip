@@ -362,22 +362,23 @@ __device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
 // before the NB MFMAs of k-step ks are issued (one wave per SIMD: nothing else hides the ~150-cycle LDS latency).
 template <int NB, int KSN, class FragFn, class BFn>
 __device__ inline void chain_layer(f32x16 (&acc)[NB], FragFn frag, BFn bop) {
-  h16x8 a[2][NB];
+  h16x8 a[2][NB], b[2];
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int m = 0; m < NB; ++m) a[0][m] = frag(m, 0);
+  b[0] = bop(0);
 #pragma unroll
   for (int ks = 0; ks < KSN; ++ks) {
-    if (ks + 1 < KSN) {
+    if (ks + 1 < KSN) {   // next k-step's A fragments AND B operand (an LDS tile read for the first / last layer) in flight
 #pragma unroll
       for (int m = 0; m < NB; ++m) a[(ks + 1) & 1][m] = frag(m, ks + 1);
+      b[(ks + 1) & 1] = bop(ks + 1);
     }
     // pin the order: left alone, the machine scheduler turns this into NB dependent accumulator chains with one
     // "ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma" round trip per MFMA (~80 cycles each instead of 32)
     __builtin_amdgcn_sched_barrier(0);
-    h16x8 b = bop(ks);
 #pragma unroll
-    for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b, ks == 0 ? zero : acc[m]);   // C = 0 inline: no accumulator zeroing
+    for (int m = 0; m < NB; ++m) acc[m] = mfma16(a[ks & 1][m], b[ks & 1], ks == 0 ? zero : acc[m]);   // C = 0 inline: no accumulator zeroing
     __builtin_amdgcn_sched_barrier(0);
   }
 }
