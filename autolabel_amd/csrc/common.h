@@ -75,3 +75,26 @@ static inline int aln_grid_for(int64_t work, int block, int max_blocks = 256 * 8
   if (g > max_blocks) g = max_blocks;
   return (int)g;
 }
+
+// tcnn SphericalHarmonics degree 4 on d01 in [0,1] (models.py:205-207) -- oracle: sh4_encode
+__device__ inline void sh4(float x, float y, float z, float* o) {
+  float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y; o[2] = 0.48860251190291987f * z; o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy; o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f; o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2); o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2); o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2); o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// the remap of models.py:205 ((d+1)/2, which tcnn maps back with 2x-1) followed by SH deg 4
+__device__ inline void sh4_of_dir(const float* d, float* sh) {
+  float v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { float d01 = (d[k] + 1.0f) / 2.0f; v[k] = d01 * 2.0f - 1.0f; }
+  sh4(v[0], v[1], v[2], sh);
+}
+

@@ -234,14 +234,15 @@ __device__ inline bool nan_bad(h16x2 acc) { return !((float)acc[0] == 0.f) || !(
 // The heads' inputs / output gradients are cheap functions of tensors that already exist (models.py:248-256 plumbing);
 // instead of materialising them ([rows,80] + [rows,64] + [rows,16] fp16 round trips through HBM) the MLP kernels build
 // each 8-feature chunk on the fly.
-enum { SRC_PLAIN = 0, SRC_SEMF_IN = 1, SRC_SEMO_IN = 2, SRC_DLOGITS = 3, SRC_DSEMF_OUT = 4 };
+enum { SRC_PLAIN = 0, SRC_SEMF_IN = 1, SRC_SEMO_IN = 2, SRC_DLOGITS = 3, SRC_DSEMF_OUT = 4, SRC_COLOR_IN = 5 };
 struct RowSrc {
   int mode;
   const h16* a; int lda;      // PLAIN: x ; SEMF_IN: sigma_out (ld 16) ; SEMO_IN / DSEMF_OUT: f (ld D)
   const h16* b; int ldb;      // SEMO_IN: sigma_out ; DSEMF_OUT: d_semo_in
   const float* w_row; const float* g;   // DLOGITS / DSEMF_OUT: per-row weight, per-ray output gradient [N, gw]
   int N, S1, S2, D, G, gw;
-};
+  const int* idx;             // COLOR_IN: live_idx (compact row -> sample row) or NULL; b = sigma_out, g = directions
+};                            //           (gw = 0: one per ray [N,3], gw = 1: one per sample row [rows,3])
 __device__ inline h16x8 geo_chunk(const h16* sigma_out, size_t row, int j0, int G) {
   // [geo_feat (G), 1, 1, ...] features j0..j0+7 ; geo_feat[g] = sigma_out[row][1 + g].  j0 is 0 or 8: both cases use
   // compile-time element indices (a runtime-indexed local array would live in scratch memory)
@@ -280,6 +281,22 @@ __device__ inline h16x8 load_chunk8(const RowSrc& s, int row, int c0) {
         h16x8 d = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (h16)(w * g[c0 + j] + ((float)f[j] > 0.f ? (float)d[j] : 0.f));
+      }
+      return o;
+    }
+    case SRC_COLOR_IN: {   // color_net input [SH16(dir), geo_feat, 1...] of models.py:205-212, built on the fly (inference)
+      const int r = s.idx ? s.idx[row] : row;
+      if (c0 >= 16) return geo_chunk(s.b, (size_t)r, c0 - 16, s.G);
+      const float* d = s.g + 3 * (size_t)(s.gw ? r : (r < s.N * s.S1 ? r / s.S1 : (r - s.N * s.S1) / s.S2));
+      float sh[16];
+      sh4_of_dir(d, sh);
+      h16x8 o;
+      if (c0 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (h16)sh[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (h16)sh[8 + j];
       }
       return o;
     }
@@ -1230,7 +1247,7 @@ static int mlp_grid(int rows) {
 
 static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32_t* rows_dev, void* h1, void* h2, void* out,
                        void* stream) {
-  ALN_REQUIRE(m && xs.a && out && m->wf, "mlp_fwd: NULL pointer");
+  ALN_REQUIRE(m && (xs.a || xs.mode == SRC_COLOR_IN) && out && m->wf, "mlp_fwd: NULL pointer");
   ALN_REQUIRE(m->in_pad % 16 == 0 && m->out_pad % 16 == 0, "mlp_fwd: widths must be multiples of 16");
   ALN_REQUIRE(m->in_pad <= 80, "mlp_fwd: in_pad %d exceeds the 80 input features the fused kernel holds in registers", m->in_pad);
   if (rows <= 0) return 0;
@@ -1347,6 +1364,17 @@ extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, c
     }
   }
   return 0;
+}
+
+// color_net on the live samples with its input rows built inside the kernel (inference: nothing to keep for a backward)
+extern "C" int aln_color_fwd(const AlnMlpDesc* color, const int32_t* live_idx, const int32_t* n_live, int32_t max_rows,
+                             const float* rays_d, const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out,
+                             int32_t G, void* color_out, void* stream) {
+  ALN_REQUIRE(color && (rays_d || dirs) && sigma_out && color_out && (!live_idx || n_live), "color_fwd: NULL pointer");
+  ALN_REQUIRE(color->in_pad == 32 && G + 1 <= 16, "color_fwd: needs in_pad 32 (SH16 + geo_feat <= 15), got in_pad %d G %d", color->in_pad, G);
+  RowSrc x{}; x.mode = SRC_COLOR_IN; x.b = (const h16*)sigma_out; x.ldb = 16; x.G = G; x.idx = live_idx;
+  x.g = dirs ? dirs : rays_d; x.gw = dirs ? 1 : 0; x.N = N; x.S1 = S1; x.S2 = S2 > 0 ? S2 : 1;
+  return mlp_fwd_src(color, x, max_rows, live_idx ? n_live : nullptr, nullptr, nullptr, color_out, stream);
 }
 
 // ---------------------------------------------------------------- semantic heads with on-the-fly inputs / gradients

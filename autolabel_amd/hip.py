@@ -67,6 +67,7 @@ _SIGS = {
     'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 6),
     'aln_sigma_act': (i32, [vp, i32, vp, vp]),
     'aln_compact_live': (i32, [vp, i32, f32, vp, vp, vp, vp]),
+    'aln_color_fwd': (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
     'aln_build_color_in': (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp]),
     'aln_build_sem_in': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'aln_assemble_grads': (i32, [vp, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp]),

@@ -273,10 +273,14 @@ class HipPipeline:
         ch1 = c['ch1'] = g('ch1', (M if save else 1, cs.hidden), f16)
         ch2 = c['ch2'] = g('ch2', (M if save else 1, cs.hidden), f16)
         cout = c['color_out'] = g('color_out', (M, cs.out_pad), f16)
-        H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G,
-               cs.in_pad, H.ptr(cin), H.stream())
-        self._k('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if save else None,
-                H.ptr(ch2) if save else None, H.ptr(cout), H.stream(), tag=('color', n_live))
+        if train or cs.in_pad != 32:
+            H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G,
+                   cs.in_pad, H.ptr(cin), H.stream())
+            self._k('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if save else None,
+                    H.ptr(ch2) if save else None, H.ptr(cout), H.stream(), tag=('color', n_live))
+        else:   # inference: the input rows are built inside the kernel (no color_in round trip through HBM)
+            H.call('aln_color_fwd', C.byref(P.descs['color']), H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2,
+                   H.ptr(sout), L.G, H.ptr(cout), H.stream())
         logits = feat = None
         if want_semantic:
             fs, os_ = nets['semf'], nets['semo']

@@ -167,6 +167,11 @@ int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_
                      void* stream);
 /* tcnn SphericalHarmonics(degree 4) of the remapped direction (autolabel/models.py:97-103,205-207): out[r, 0:16] f16 */
 int aln_sh4(const float* dirs /*[rows,3]*/, int32_t rows, int32_t out_pitch /*halves, >= 16*/, void* out, void* stream);
+/* color_net forward with its input rows built inside the kernel from live_idx / directions / sigma_out (inference path:
+ * no color_in tensor; dirs = one direction per row [rows,3], else rays_d [N,3] indexed through the row's ray) */
+int aln_color_fwd(const AlnMlpDesc* color, const int32_t* live_idx, const int32_t* n_live, int32_t max_rows,
+                  const float* rays_d, const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out, int32_t G,
+                  void* color_out, void* stream);
 int aln_build_color_in(const int32_t* live_idx, const int32_t* n_live, int32_t max_rows, const float* rays_d,
                        const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out, int32_t G, int32_t in_pad,
                        void* color_in, void* stream);

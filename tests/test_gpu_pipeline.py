@@ -298,3 +298,15 @@ def test_adam_step_matches_torch_adam_and_skips_on_inf():
     step()
     assert torch.equal(p[n_grid:], before[n_grid:]) and not torch.equal(p[:n_grid], before[:n_grid])
     assert si[4].item() == 5 and si[5].item() == 4
+
+
+def test_inference_and_training_forward_agree_bitwise():
+    """train=False skips the color_in tensor (inputs built inside the color kernel) and nothing else: same outputs."""
+    _, pipe, _ = build_pair(C_=5)
+    o, d, norms = make_rays(600, seed=4)
+    od, dd, nd = o.cuda(), d.cuda(), norms.reshape(-1).cuda()
+    a, _ = pipe.forward(od, dd, nd, 64, 32, False, train=True)
+    a = {k: v.clone() for k, v in a.items()}
+    b, _ = pipe.forward(od, dd, nd, 64, 32, False, train=False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
