@@ -124,6 +124,10 @@ int64_t aln_encode_fwd_ws_bytes(const AlnEncDesc* e, int32_t rows);
 int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
                           const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* planes_ws, void* enc_out,
                           void* stream);
+/* development probe (scripts/dev/probe_encode_fwd_levels.py): the tile kernel for levels [level_lo, level_hi) only */
+int aln_dev_encode_fwd_levels(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
+                              const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* enc_out,
+                              int32_t level_lo, int32_t level_hi, void* stream);
 int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
                    int32_t rows, int32_t rays_stride, const void* d_enc /*[rows,enc_pad] f16*/,
                    float* grad_table /*[n_entries*F] f32*/, void* stream);

@@ -14,13 +14,9 @@ ro = ((torch.rand(N, 3, generator=g) - 0.5) * 4).cuda()
 rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()
 z = (torch.rand(N, S, generator=g).sort(dim=1)[0] * 5 + 0.2).cuda().reshape(-1).contiguous()
 enc = torch.empty(rows, 48, device='cuda', dtype=torch.float16)
-lib = H.lib()
-fn = lib.aln_dev_encode_fwd_levels
-fn.restype = C.c_int32
-fn.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 def run(lo, hi):
-    rc = fn(C.cast(C.byref(L.enc), C.c_void_p), H.ptr(P.table16), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(enc), lo, hi, H.stream())
-    assert rc == 0
+    H.call('aln_dev_encode_fwd_levels', C.byref(L.enc), H.ptr(P.table16), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(enc), lo, hi,
+           H.stream())
 def timeit(f, reps=5):
     for _ in range(2): f()
     torch.cuda.synchronize()
