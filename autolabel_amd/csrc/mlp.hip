@@ -1009,7 +1009,7 @@ __device__ inline void write_packed_tile(TV t, int srow, const h16x8 (&p)[2 * NB
     }
 }
 // ---------------------------------------------------------------- recompute backward, wave-specialised (8 waves)
-// Profiling the 4-wave kernel (rocprofv3 + ISA): ~6500 issued instructions per 128-row tile and wave, of which 152 are
+// Profiling the first version (4 waves, every wave chain + dW; rocprofv3 + ISA): ~6500 issued instructions per 128-row tile and wave, of which 152 are
 // MFMAs -- with 428 registers per wave the accumulators spill into the AGPR half (1900 v_accvgpr moves) and only ONE wave
 // per SIMD is resident, so nothing hides the dependent-issue latency.  Here the two jobs get their own waves: waves 0-3 run
 // the register chain (forward recompute + backward data path, ~170 VGPRs), waves 4-7 only accumulate the weight gradients
