@@ -140,6 +140,13 @@ class Workspace:
             self.bufs[name] = (key, torch.empty(shape, dtype=dtype, device=self.device))
         return self.bufs[name][1]
 
+    def scratch(self, name, nbytes):
+        """Byte scratch that only ever grows (callers with varying sizes share one allocation)."""
+        t = self.bufs.get(name)
+        if t is None or t[1].numel() < nbytes:
+            self.bufs[name] = (('scratch', name), torch.empty(int(nbytes), dtype=torch.uint8, device=self.device))
+        return self.bufs[name][1]
+
 
 f16, f32_, i32_ = torch.float16, torch.float32, torch.int32
 
@@ -214,7 +221,7 @@ class HipPipeline:
         e, s = self.L.enc, self.L.nets['sigma']
         if e.use_grid and rows >= self.phased_min_rows:
             # large batches: level-phased gathers (tables in flight stay L2-resident) + streaming row assembly
-            planes = self.ws.get('enc_planes', (int(e.grid.n_levels), rows, 2), f16)
+            planes = self.ws.scratch('enc_planes', int(e.grid.n_levels) * rows * 4)
             H.call('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz),
                    rows, stride, H.ptr(planes), H.ptr(enc), H.stream())
         else:
