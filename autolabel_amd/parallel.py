@@ -91,3 +91,33 @@ def broadcast_parameters(flat, group=None, src=0):
     """Replicate the master parameters of rank `src` (model replicas must start identical)."""
     if dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+
+
+def ray_shard(n_rays, rank, world):
+    """Contiguous slice [lo, hi) of a frame's rays for this rank (rendering shards over rays with no collective in the
+    data path, SURVEY 8e: "rendering a single frame can split rows across GPUs")."""
+    per, rem = divmod(n_rays, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+@torch.no_grad()
+def render_sharded(model, rays_o, rays_d, direction_norms, group=None, **render_kwargs):
+    """Every rank renders its slice of the rays with `model.render(staged=True)`; the slices are concatenated on every
+    rank with one all_gather per output at the end (outputs only: nothing is exchanged while rendering).  Shapes follow
+    `model.render`: the ray prefix of `rays_o` is restored."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    prefix = rays_o.shape[:-1]
+    ro, rd, dn = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), direction_norms.reshape(-1)
+    lo, hi = ray_shard(ro.shape[0], rank, world)
+    out = model.render(ro[lo:hi].contiguous(), rd[lo:hi].contiguous(), dn[lo:hi].contiguous(), staged=True, **render_kwargs)
+    if world > 1:
+        sizes = [ray_shard(ro.shape[0], r, world) for r in range(world)]
+        full = {}
+        for k, v in out.items():
+            parts = [torch.empty((b - a,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for a, b in sizes]
+            dist.all_gather(parts, v.contiguous(), group=group)
+            full[k] = torch.cat(parts, 0)
+        out = full
+    return {k: (v.reshape(*prefix, *v.shape[1:]) if v.dim() > 1 else v.reshape(*prefix)) for k, v in out.items()}

@@ -48,6 +48,17 @@ def _worker(rank, world, port, ret):
         flat = P.flat.detach().cpu()
         both = [None] * world
         dist.all_gather_object(both, flat)
+        if overlap:   # sharded rendering of one frame: every rank ends up with the full, identical image
+            from autolabel_amd.models import ALNetwork
+            from autolabel_amd.parallel import render_sharded
+            torch.manual_seed(0)
+            net = ALNetwork(encoding='hg+freq', num_layers=2, hidden_dim=128, geo_feat_dim=15, num_layers_color=2, hidden_dim_color=128,
+                            hidden_dim_semantic=64, semantic_classes=scene['n_classes'], bound=3.0, cuda_ray=False, density_scale=1).cuda()
+            t = frames.get_test(1)
+            whole = net.render(t['rays_o'], t['rays_d'], t['direction_norms'], staged=True, perturb=False, num_steps=32, upsample_steps=16)
+            shard = render_sharded(net, t['rays_o'], t['rays_d'], t['direction_norms'], perturb=False, num_steps=32, upsample_steps=16)
+            out['render'] = {k: float((whole[k].float() - shard[k].float()).abs().max()) for k in whole}
+            out['render_shape'] = tuple(shard['image'].shape) == tuple(whole['image'].shape)
         out[overlap] = dict(same=bool(torch.equal(both[0], both[1])), finite=bool(torch.isfinite(flat).all()), flat=flat,
                             steps=int(eng.state_i[0].item()), buckets=buckets, n_total=layout.n_total, n_grid=layout.n_grid)
     dist.barrier()
@@ -62,6 +73,8 @@ def test_two_ranks_on_one_gpu_stay_in_lockstep_with_bucketed_allreduce():
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         res = dict(ret)
     for rank in range(world):
+        # sharded render of a frame == the single-process render, bit for bit
+        assert res[rank]['render_shape'] and max(res[rank]['render'].values()) == 0.0, res[rank]['render']
         for overlap in (True, False):
             r = res[rank][overlap]
             assert r['same'] and r['finite'] and r['steps'] == 3, (rank, overlap, r['same'], r['finite'], r['steps'])

@@ -65,3 +65,15 @@ def test_frame_shards_partition_all_frames():
                 lo, hi = frame_shard(n, r, world)
                 covered += list(range(lo, hi))
             assert covered == list(range(n))
+
+
+def test_ray_shards_partition_a_frame():
+    from autolabel_amd.parallel import ray_shard
+    for n in [1, 307200, 76801]:
+        for world in [1, 2, 3, 8]:
+            covered = []
+            for r in range(world):
+                lo, hi = ray_shard(n, r, world)
+                assert hi - lo in (n // world, n // world + 1)
+                covered.append((lo, hi))
+            assert covered[0][0] == 0 and covered[-1][1] == n and all(covered[i][1] == covered[i + 1][0] for i in range(world - 1))
