@@ -1296,7 +1296,7 @@ static int mlp_bwd_recomp_src(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int row
 #define TRYR(I, H, O, N)                                                                                  \
   if (m->in_pad == I && m->hidden == H && m->out_pad == O && m->n_hidden == N)                            \
     return launch_bwd_recomp<I, H, O, N>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
-  TRYR(48, 128, 16, 2) TRYR(32, 128, 16, 2) TRYR(64, 128, 16, 2) TRYR(16, 64, 64, 2) TRYR(80, 64, 16, 1) TRYR(80, 64, 32, 1)
+  TRYR(48, 128, 16, 2) TRYR(32, 128, 16, 2) TRYR(64, 128, 16, 2) TRYR(16, 64, 64, 2) TRYR(80, 64, 16, 1) TRYR(80, 64, 32, 1) TRYR(80, 64, 48, 1) TRYR(80, 64, 64, 1)
 #undef TRYR
   aln_set_error("mlp_bwd: no recompute kernel for in=%d hid=%d out=%d nh=%d (pass saved activations)", m->in_pad, m->hidden,
                 m->out_pad, m->n_hidden);

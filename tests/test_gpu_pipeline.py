@@ -128,12 +128,13 @@ def test_loss_kernel_matches_trainer_formula():
     assert gs.abs().max().item() == 0 and gd.abs().max().item() == 0 and torch.isfinite(t).all()
 
 
-def test_train_step_gradients_match_oracle_autograd():
-    """Backward parity.  The oracle is evaluated at the HIP path's own importance samples (z_fine_override):
+@pytest.mark.parametrize('n_classes', [3, 20, 40, 64])
+def test_train_step_gradients_match_oracle_autograd(n_classes):
+    """Backward parity (class counts 3 / 20 / 40 / 64 = logits padded to 16 / 32 / 48 / 64 columns).  The oracle is evaluated at the HIP path's own importance samples (z_fine_override):
     the finest hash-grid cells are 4e-6 wide, so a 1e-6 difference in z (re-associated cumsum in the sampler,
     tested on its own above) moves a sample's gradient to other table entries."""
-    oracle, pipe, cfg = build_pair(L=16, D=64, C_=3)
-    N, S1, S2, C_, D, Cf = 64, 64, 64, 3, 64, 48
+    oracle, pipe, cfg = build_pair(L=16, D=64, C_=n_classes)
+    N, S1, S2, C_, D, Cf = 64, 64, 64, n_classes, 64, 48
     o, d, norms = make_rays(N, seed=2)
     g = torch.Generator().manual_seed(11)
     noise, u = torch.rand(N, S1, generator=g), torch.rand(N, S2, generator=g)
