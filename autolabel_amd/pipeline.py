@@ -43,8 +43,8 @@ class ModelLayout:
                  num_layers=2, num_layers_color=2, bound=1.0, grid=None):
         self.enc = H.make_enc_desc(encoding, float(bound), grid)
         self.G, self.D, self.C = geo_feat_dim, hidden_dim_semantic, semantic_classes
-        if geo_feat_dim != 15:
-            raise NotImplementedError('geo_feat_dim != 15 is not supported by the HIP heads (sigma output is 16 wide)')
+        if not 1 <= geo_feat_dim <= 15:
+            raise NotImplementedError('geo_feat_dim must be in 1..15 for the HIP heads (density + geo_feat share one 16-wide row)')
         self.n_grid = int(self.enc.grid.n_entries) * 2 if self.enc.use_grid else 0
         self.nets = {
             'sigma': MlpSpec('sigma', self.enc.enc_dim, hidden_dim, 1 + geo_feat_dim, num_layers),
