@@ -1289,6 +1289,15 @@ extern "C" int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, con
   return mlp_fwd_src(m, plain_src(x, m->in_pad), rows, rows_dev, h1, h2, out, stream);
 }
 
+// shapes the recompute backward is instantiated for (the list of TRYR below)
+extern "C" int aln_mlp_has_recompute(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden) {
+  static const int shapes[][4] = {{48, 128, 16, 2}, {32, 128, 16, 2}, {64, 128, 16, 2}, {16, 64, 64, 2},
+                                  {80, 64, 16, 1},  {80, 64, 32, 1},  {80, 64, 48, 1},  {80, 64, 64, 1}};
+  for (auto& q : shapes)
+    if (q[0] == in_pad && q[1] == hidden && q[2] == out_pad && q[3] == n_hidden) return 1;
+  return 0;
+}
+
 static int mlp_bwd_recomp_src(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in, float* dW,
                               int* found_inf, hipStream_t s) {
   ALN_REQUIRE(m && m->wr && xs.a && (ds.a || ds.g), "mlp_bwd: recompute path needs x, dL/dout and the row-major weight copy (wr)");

@@ -61,6 +61,7 @@ _SIGS = {
     'aln_mlp_repack': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),
     'aln_mlp_repack_all': (i32, [i32, vp, vp, vp]),
+    'aln_mlp_has_recompute': (i32, [i32, i32, i32, i32]),
     'aln_mlp_frag_halves': (i64, [i32, i32, i32, i32, i32]),
     'aln_mlp_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),

@@ -161,7 +161,10 @@ class HipPipeline:
         self.density_scale, self.min_near = float(density_scale), float(min_near)
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
         self.phased_min_rows = 1 << 16   # hash-grid forward: level-phased from this many sample rows on
-        self.recompute = True  # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward)
+        # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
+        # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
+        self.recompute = all(s.lib or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
+                             for s in layout.nets.values())
         self.kernel_events = None  # bench.py: list of ((start, end) HIP events, kernel, tag) around the timed launches
 
     def _k(self, name, *args, tag=None):

@@ -152,6 +152,8 @@ int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t*
 /* h1 == NULL selects the recompute backward: hidden activations are rebuilt from x inside the kernel (needs m->wr).
  * d_in (optional) [rows,in_pad] f16; dW (optional) += weight gradients in the fp32 master layout; dA1/dA2 are scratch
  * [rows,hidden] f16 (only touched by the unfused fallback); found_inf is OR-ed when an fp16 gradient overflows. */
+/* 1 if the recompute backward exists for this shape (otherwise pass saved activations to aln_mlp_bwd) */
+int aln_mlp_has_recompute(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden);
 int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
                 const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW, int32_t* found_inf, void* stream);
 

@@ -10,17 +10,17 @@ pytestmark = pytest.mark.gpu
 from oracle import nerf_oracle as O
 
 
-def build_pair(encoding='hg+freq', L=16, D=64, C_=3, bound=1.0, seed=0, grid_scale=1e4, log2_T=19, G=15):
+def build_pair(encoding='hg+freq', L=16, D=64, C_=3, bound=1.0, seed=0, grid_scale=1e4, log2_T=19, G=15, hidden=128, hidden_color=128):
     """Same parameters in the oracle (named tensors) and in the HIP flat buffer."""
     from autolabel_amd import hip as H
     from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
-    cfg = O.ModelConfig(encoding=encoding, feature_dim=D, n_classes=C_, bound=bound, geo_feat_dim=G,
+    cfg = O.ModelConfig(encoding=encoding, feature_dim=D, n_classes=C_, bound=bound, geo_feat_dim=G, hidden_dim=hidden, hidden_dim_color=hidden_color,
                         grid=O.GridSpec(n_levels=L, log2_hashmap_size=log2_T))
     p = O.init_params(cfg, seed)
     if 'grid' in p:
         p['grid'] = (p['grid'] * grid_scale).half().float()  # non-trivial density; exactly representable in the fp16 table
     oracle = O.OracleModel(cfg, params=p, half_sim=True)
-    layout = ModelLayout(encoding, G, 128, 128, D, C_, bound=bound, grid=H.make_grid_desc(n_levels=L, log2_hashmap_size=log2_T))
+    layout = ModelLayout(encoding, G, hidden, hidden_color, D, C_, bound=bound, grid=H.make_grid_desc(n_levels=L, log2_hashmap_size=log2_T))
     P = Params(layout, 'cuda')
     parts = [p['grid'].reshape(-1)] if 'grid' in p else []
     for name in ['sigma', 'color', 'semf', 'semo']:
@@ -129,12 +129,13 @@ def test_loss_kernel_matches_trainer_formula():
     assert gs.abs().max().item() == 0 and gd.abs().max().item() == 0 and torch.isfinite(t).all()
 
 
-@pytest.mark.parametrize('n_classes,G', [(3, 15), (20, 15), (40, 15), (64, 15), (3, 7), (5, 1)])
-def test_train_step_gradients_match_oracle_autograd(n_classes, G):
+@pytest.mark.parametrize('n_classes,G,hidden', [(3, 15, 128), (20, 15, 128), (40, 15, 128), (64, 15, 128), (3, 7, 128), (5, 1, 128), (3, 15, 64)])
+def test_train_step_gradients_match_oracle_autograd(n_classes, G, hidden):
     """Backward parity (class counts 3 / 20 / 40 / 64 = logits padded to 16 / 32 / 48 / 64 columns).  The oracle is evaluated at the HIP path's own importance samples (z_fine_override):
     the finest hash-grid cells are 4e-6 wide, so a 1e-6 difference in z (re-associated cumsum in the sampler,
     tested on its own above) moves a sample's gradient to other table entries."""
-    oracle, pipe, cfg = build_pair(L=16, D=64, C_=n_classes, G=G)
+    oracle, pipe, cfg = build_pair(L=16, D=64, C_=n_classes, G=G, hidden=hidden, hidden_color=hidden)
+    assert pipe.recompute == (hidden == 128)   # 64-wide density / color nets: saved activations + generic backward kernels
     N, S1, S2, C_, D, Cf = 64, 64, 64, n_classes, 64, 48
     o, d, norms = make_rays(N, seed=2)
     g = torch.Generator().manual_seed(11)
