@@ -420,6 +420,293 @@ extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const fl
   return aln_encode_bwd_levels(e, rays_o, rays_d, z, xyz, rows, rays_stride, d_enc, grad_table, 0, (int32_t)e->grid.n_levels, stream);
 }
 
+// ---------------------------------------------------------------- binned backward (no global atomics)
+// The atomic scatter above is bound by the L2 atomic units (~21 G 64-byte requests/s, profiles/r02_probe_atomics.txt): every
+// (sample, level) costs ~4 requests although each 64-byte chunk of a 4 MB level table is hit ~64 times per step.  The binned
+// backward turns the scatter into two streaming passes:
+//   phase 1 (k_encode_bwd_bin): a block owns a tile of 512 consecutive sample rows.  Per level it computes the run-deduped
+//     (index, w * dL/dfeat) records exactly as the atomic kernel does, counting-sorts them in LDS by table SLICE (8192 entries =
+//     64 KB of fp32 accumulators) and writes the sorted records as ONE contiguous run into the tile's fixed chunk of the record
+//     pool, plus one (start, count) descriptor per slice.  Records are 8 bytes: slot within the slice | fp16x2 value.
+//   phase 2 (k_encode_bwd_accum): a block owns one (level, slice); it streams that slice's runs of every tile, accumulates
+//     them with LDS atomics in fp32 and adds the slice to the gradient table with plain coalesced stores.
+// HBM traffic: 8 B written + 8 B read per record (<= 8 x 16 records per sample) instead of 4 atomic requests per (sample, level).
+#define BIN_TILE 512            // sample rows per phase-1 block (= threads: lane = sample, so runs along a ray dedupe in-wave)
+#define BIN_SLICE_LOG2 13       // table entries per slice (x 2 features x 4 B = 64 KB LDS in phase 2)
+#define BIN_SLICE (1 << BIN_SLICE_LOG2)
+#define BIN_MAX_SLICES 64       // 2^19 entries / 8192
+#define BIN_CHUNK (BIN_TILE * 8)   // records per (tile, level) chunk of the pool
+#define BIN_MAX_SHIFT 12        // largest per-tile up-scaling of the fp16 record values (2^12)
+
+struct BinParams {
+  EncParams p;
+  const h16* d_enc;
+  uint2* pool;        // [n_levels][ntiles][BIN_CHUNK] records
+  uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  start | count << 13 | shift << 26
+  int ntiles;
+  int rows1, stride2; // rows [0, rows1) use p.rays_stride samples per ray, the rest stride2 (coarse + fine pass in one launch)
+};
+
+__device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
+  const EncParams& p = b.p;
+  if (p.xyz) { x[0] = p.xyz[3 * (size_t)row]; x[1] = p.xyz[3 * (size_t)row + 1]; x[2] = p.xyz[3 * (size_t)row + 2]; return; }
+  const int ray = row < b.rows1 ? row / p.rays_stride : (row - b.rows1) / b.stride2;
+  aln_sample_xyz(p.rays_o + 3 * (size_t)ray, p.rays_d + 3 * (size_t)ray, p.z[row], p.e.bound, x);
+}
+
+__global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
+  __shared__ uint2 sorted[BIN_CHUNK];                        // 32 KB
+  __shared__ uint32_t gtile[ALN_MAX_LEVELS * (BIN_TILE + 1)]; // level-major d_enc grid part, 32 KB
+  __shared__ uint32_t cnt[2][BIN_MAX_SLICES], base[BIN_MAX_SLICES], total_s, vmax_s[2], shift_s;
+  const EncParams& p = b.p;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tile = blockIdx.x;
+  const int row0 = tile * BIN_TILE;
+  const int rows_here = min(BIN_TILE, p.rows - row0);
+  const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq, nl = p.e.grid.n_levels;
+  // d_enc grid columns of the tile -> LDS, level-major (reads below: lane = sample, conflict-free)
+  for (int i = tid; i < rows_here * nl; i += BIN_TILE) {
+    const int r = i / nl, l = i - r * nl;
+    gtile[l * (BIN_TILE + 1) + r] = *(const uint32_t*)(b.d_enc + (size_t)(row0 + r) * pad + fdim + 2 * l);
+  }
+  if (tid < 2 * BIN_MAX_SLICES) cnt[0][tid] = 0;
+  if (tid < 2) vmax_s[tid] = 0u;
+  const int row = row0 + tid;
+  const bool valid = row < p.rows;
+  float x[3] = {0, 0, 0}, xn[3];
+  if (valid) bin_row_position(b, row, x);
+  normalize_pos(x, p.e.bound, true, xn);
+  __syncthreads();
+  for (int l = p.level_lo; l < p.level_hi; ++l) {
+    const int par = l & 1;
+    float g0 = 0.f, g1 = 0.f;
+    if (valid) { const uint32_t gw = gtile[l * (BIN_TILE + 1) + tid]; const h16x2 g = *(const h16x2*)&gw; g0 = (float)g[0]; g1 = (float)g[1]; }
+    uint32_t idx[8]; float w[8]; uint32_t cell[3];
+    grid_corners(p.e.grid, l, xn, idx, w, cell);
+    // run-dedupe along the ray (as in k_encode_bwd): adjacent lanes in the same cell are summed into the run head
+    uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
+    const bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
+    const unsigned long long hm = __ballot(head);
+    const int rid = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { v[2 * c] = w[c] * g0; v[2 * c + 1] = w[c] * g1; }
+    if (__popcll(hm) < 64) {
+      // runs are contiguous: once no lane finds a run mate at distance `off`, none exists further away (most fine levels
+      // leave after one step; the full ladder is 6 x 16 shuffles)
+      for (int off = 1; off < 64; off <<= 1) {
+        const int r2 = __shfl_down(rid, off);
+        const bool take = (lane + off < 64) && (r2 == rid);
+        if (!__any(take)) break;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float o = __shfl_down(v[k], off); v[k] += take ? o : 0.f; }
+      }
+    }
+    // records of this lane (run heads only).  Values travel as fp16x2 scaled by 2^e, e = per (tile, level) exponent chosen so
+    // that the largest |value| of the tile lands in [2^14, 2^15) (0 <= e <= BIN_MAX_SHIFT; never scaled down): tiny products
+    // w * g keep their bits instead of flushing at the fp16 denormal step.  An overflow shows up as inf -> found_inf.
+    float vmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
+    const bool emit = head && vmax > 0.f;     // NaN compares false: a NaN run is dropped here but d_enc's own watch has fired
+    uint32_t rk[8];
+    if (emit) {
+      atomicMax(&vmax_s[par], __float_as_uint(vmax));   // non-negative floats order like their bit patterns
+#pragma unroll
+      for (int c = 0; c < 8; ++c) rk[c] = atomicAdd(&cnt[par][idx[c] >> BIN_SLICE_LOG2], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive prefix over the slice counters; descriptors; reset the counters for level l + 2
+      const uint32_t n = cnt[par][lane];
+      uint32_t inc = n;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+      base[lane] = inc - n;
+      cnt[par][lane] = 0;
+      const int ex = (int)((vmax_s[par] >> 23) & 0xFFu) - 127;          // floor(log2(max)); inf / huge -> large -> shift 0
+      const int sh = min(max(14 - ex, 0), BIN_MAX_SHIFT);
+      if (lane == 63) { total_s = inc; shift_s = sh; }
+      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - n) | (n << 13) | ((uint32_t)sh << 26);
+    }
+    __syncthreads();
+    if (tid == 0) vmax_s[par] = 0u;    // next use: level l + 2, two barriers away from any reader
+    if (emit) {
+      const float sc = __uint_as_float((uint32_t)(127 + shift_s) << 23);   // 2^shift
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        h16x2 hv; hv[0] = (h16)(v[2 * c] * sc); hv[1] = (h16)(v[2 * c + 1] * sc);
+        const uint32_t s = idx[c] >> BIN_SLICE_LOG2;
+        sorted[base[s] + rk[c]] = make_uint2(idx[c] & (BIN_SLICE - 1u), *(const uint32_t*)&hv);
+      }
+    }
+    __syncthreads();
+    const uint32_t total = total_s;
+    uint4* dst = (uint4*)(b.pool + ((size_t)l * b.ntiles + tile) * BIN_CHUNK);
+    const uint4* src = (const uint4*)sorted;
+    for (uint32_t i = tid; i < (total + 1) / 2; i += BIN_TILE) dst[i] = src[i];
+    // (no barrier: the next level's writes to `sorted` come after two more barriers)
+  }
+}
+
+struct AccParams {
+  const uint2* pool; const uint32_t* desc; float* grad; int32_t* found_inf;
+  int ntiles, level_lo, n_levels_here;
+  uint32_t blk_start[ALN_MAX_LEVELS + 1];   // first block of each launched level (levels enumerated from level_lo)
+  uint32_t split[ALN_MAX_LEVELS];           // blocks per slice: coarse levels have few slices, their tiles are split over blocks
+  uint32_t size[ALN_MAX_LEVELS], offset[ALN_MAX_LEVELS];
+};
+
+// fp16 record value -> exact 64-bit fixed point in units of 2^-24 (the smallest fp16 denormal): every fp16 is an integer
+// < 2^40 in that unit, so 2^23 records can be summed without overflow and the sum is EXACT and order-independent.
+// (ds_add_f32 runs at 0.33 lanes/clk/CU on gfx950, ds_add_u64 at 4.6: profiles/r02_probe_lds_atomics.txt.)
+// Records scaled up by 2^e (e <= BIN_MAX_SHIFT, phase 1) are shifted left by BIN_MAX_SHIFT - e: the accumulator unit is 2^-36,
+// |value| < 2^16 * 2^36 = 2^52 per record, so 2^11 records of the largest fp16 magnitude still fit.
+__device__ inline long long fx_from_half(h16 h) {
+  const float a = (float)h * 16777216.0f;              // exact: 11-bit significand, |a| < 2^40
+  const float hi = truncf(a * (1.0f / 1048576.0f));    // |hi| < 2^20
+  const float lo = a - hi * 1048576.0f;                // exact, same sign, |lo| < 2^20
+  return ((long long)(int)hi << 20) + (long long)(int)lo;
+}
+#define FX_UNIT (1.0 / 68719476736.0)   // 2^-36
+
+#define ACC_THREADS 1024
+__global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
+  long long* acc = (long long*)acc_smem;   // [BIN_SLICE][2] = 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = ACC_THREADS / 64;
+  int li = 0;
+  while (li + 1 < a.n_levels_here && blockIdx.x >= a.blk_start[li + 1]) ++li;
+  const int l = a.level_lo + li;
+  const uint32_t nsl = (a.size[l] + BIN_SLICE - 1) >> BIN_SLICE_LOG2, K = a.split[li];
+  const uint32_t bl = blockIdx.x - a.blk_start[li];
+  const int s = bl % nsl, part = bl / nsl;
+  for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ll;
+  __syncthreads();
+  const uint32_t* d = a.desc + ((size_t)l * BIN_MAX_SLICES + s) * a.ntiles;
+  const uint2* pool = a.pool + (size_t)l * a.ntiles * BIN_CHUNK;
+  bool bad = false;   // a non-finite record (inf / nan upstream, or an fp16 overflow of a run sum)
+  auto add = [&](uint2 r, uint32_t up) {   // up = BIN_MAX_SHIFT - shift of the run's tile
+    const h16x2 hv = *(const h16x2*)&r.y;
+    bad |= (r.y & 0x7C00u) == 0x7C00u || (r.y & 0x7C000000u) == 0x7C000000u;
+    atomicAdd((unsigned long long*)&acc[2 * r.x], (unsigned long long)(fx_from_half(hv[0]) << up));
+    atomicAdd((unsigned long long*)&acc[2 * r.x + 1], (unsigned long long)(fx_from_half(hv[1]) << up));
+  };
+  if (K > 1) {
+    // coarse levels (few slices, long runs of hundreds of records per tile): one tile per wave at a time, four loads per lane
+    // in flight; the tiles of the slice are dealt out over the K blocks
+    for (int t = part * nw + wave; t < a.ntiles; t += K * nw) {
+      const uint32_t q = d[t];
+      const uint32_t st0 = q & 0x1FFFu, n0 = (q >> 13) & 0x1FFFu, up0 = BIN_MAX_SHIFT - (q >> 26);
+      const uint2* src = pool + (size_t)t * BIN_CHUNK + st0;
+      for (uint32_t k = lane; k < n0; k += 256) {
+        uint2 rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rr[u] = (k + 64 * u < n0) ? src[k + 64 * u] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (k + 64 * u < n0) add(rr[u], up0);
+      }
+    }
+  } else
+  for (int t0 = (part * nw + wave) * 64; t0 < a.ntiles; t0 += K * nw * 64) {
+    const uint32_t dd = (t0 + lane < a.ntiles) ? d[t0 + lane] : 0u;
+    const int nt = min(64, a.ntiles - t0);
+    // batches of 4 runs, the first 128 records of each run in two loads per lane; the next batch is requested before the
+    // current one is consumed (16 loads in flight per wave)
+    uint2 r[2][8]; uint32_t st[2][4], n[2][4], up[2][4];
+    auto request = [&](int buf, int j0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t q = __builtin_amdgcn_readlane(dd, (j0 + u) & 63);
+        st[buf][u] = q & 0x1FFFu; n[buf][u] = (j0 + u < nt) ? ((q >> 13) & 0x1FFFu) : 0u; up[buf][u] = BIN_MAX_SHIFT - (q >> 26);
+        const uint2* src = pool + (size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u];
+        r[buf][2 * u] = r[buf][2 * u + 1] = make_uint2(0u, 0u);
+        if ((uint32_t)lane < n[buf][u]) r[buf][2 * u] = src[lane];
+        if ((uint32_t)lane + 64u < n[buf][u]) r[buf][2 * u + 1] = src[lane + 64];
+      }
+    };
+    auto consume = [&](int buf, int j0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if ((uint32_t)lane < n[buf][u]) add(r[buf][2 * u], up[buf][u]);
+        if ((uint32_t)lane + 64u < n[buf][u]) add(r[buf][2 * u + 1], up[buf][u]);
+        for (uint32_t k = 128 + lane; k < n[buf][u]; k += 64)   // long runs
+          add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], up[buf][u]);
+      }
+    };
+    request(0, 0);
+    for (int j0 = 0; j0 < nt; j0 += 8) {
+      request(1, j0 + 4);
+      consume(0, j0);
+      request(0, j0 + 8);
+      consume(1, j0 + 4);
+    }
+  }
+  __syncthreads();
+  const uint32_t e0 = (uint32_t)s << BIN_SLICE_LOG2;
+  const uint32_t ne = min((uint32_t)BIN_SLICE, a.size[l] - e0);
+  float* g = a.grad + 2 * ((size_t)a.offset[l] + e0);
+  for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) {
+    const long long q = acc[i];
+    if (q != 0ll) {
+      const float v = (float)((double)q * FX_UNIT);    // one rounding of the exact sum
+      if (K > 1) unsafeAtomicAdd(&g[i], v); else g[i] += v;   // adjacent lanes, adjacent floats: 16 lanes per request
+    }
+  }
+  if (bad) {   // poison the slice (torch's GradScaler looks at the gradient tensor itself) and raise the engine's flag
+    g[0] = __builtin_nanf("");
+    if (a.found_inf) *a.found_inf = 1;
+  }
+}
+
+extern "C" int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows) {
+  if (!e || !e->use_grid || rows <= 0) return 0;
+  const int64_t ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
+  return nl * ntiles * BIN_CHUNK * (int64_t)sizeof(uint2) + nl * BIN_MAX_SLICES * ntiles * (int64_t)sizeof(uint32_t);
+}
+
+extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                                     const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
+                                     const void* d_enc, float* grad_table, void* ws, int32_t level_lo, int32_t level_hi,
+                                     int32_t* found_inf, void* stream) {
+  BinParams b;
+  if (int rc = fill_params(b.p, e, nullptr, rays_o, rays_d, z, xyz, rows, stride1)) return rc;
+  if (rows == 0 || !e->use_grid) return 0;
+  ALN_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= (int)e->grid.n_levels, "encode_bwd_binned: level range [%d, %d)",
+              level_lo, level_hi);
+  ALN_REQUIRE(d_enc && grad_table && ws, "encode_bwd_binned: NULL pointer");
+  ALN_REQUIRE(0 <= rows_pass1 && rows_pass1 <= rows && (rows_pass1 == rows || stride2 > 0), "encode_bwd_binned: bad pass split");
+  ALN_REQUIRE(e->grid.log2_hashmap_size <= BIN_SLICE_LOG2 + 6, "encode_bwd_binned: tables above 2^19 entries are not supported");
+  if (level_lo == level_hi) return 0;
+  const int ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
+  b.p.level_lo = level_lo; b.p.level_hi = level_hi;
+  b.d_enc = (const h16*)d_enc; b.ntiles = ntiles; b.rows1 = rows_pass1; b.stride2 = stride2 > 0 ? stride2 : 1;
+  b.pool = (uint2*)ws;
+  b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * BIN_CHUNK * sizeof(uint2));
+  hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
+  ALN_CHECK_LAUNCH("encode_bwd_bin");
+  AccParams a;
+  a.pool = b.pool; a.desc = b.desc; a.grad = grad_table; a.found_inf = found_inf; a.ntiles = ntiles;
+  a.level_lo = level_lo; a.n_levels_here = level_hi - level_lo;
+  uint32_t nblk = 0;
+  for (int l = level_lo; l < level_hi; ++l) {
+    const uint32_t nsl = (e->grid.size[l] + BIN_SLICE - 1) >> BIN_SLICE_LOG2;
+    uint32_t K = nsl >= 32 ? 1 : (BIN_MAX_SLICES + nsl - 1) / nsl;     // coarse levels: at least 64 blocks per level
+    const uint32_t kmax = (uint32_t)(ntiles + 15) / 16;   // a block of 16 waves needs at least 16 tiles
+    if (K > kmax) K = kmax;
+    if (K < 1) K = 1;
+    a.blk_start[l - level_lo] = nblk; a.split[l - level_lo] = K;
+    nblk += nsl * K;
+  }
+  a.blk_start[level_hi - level_lo] = nblk;
+  for (int l = 0; l < nl; ++l) { a.size[l] = e->grid.size[l]; a.offset[l] = e->grid.offset[l]; }
+  static const bool lds_ok = hipFuncSetAttribute((const void*)k_encode_bwd_accum, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 2 * BIN_SLICE * (int)sizeof(long long)) == hipSuccess;
+  ALN_REQUIRE(lds_ok, "encode_bwd_binned: cannot reserve 128 KB of LDS");
+  hipLaunchKernelGGL(k_encode_bwd_accum, dim3(nblk), dim3(ACC_THREADS), 2 * BIN_SLICE * sizeof(long long), (hipStream_t)stream, a);
+  ALN_CHECK_LAUNCH("encode_bwd_accum");
+  return 0;
+}
+
 extern "C" int aln_grid_desc_init(AlnGridDesc* g) {
   ALN_REQUIRE(g && g->n_levels > 0 && g->n_levels <= ALN_MAX_LEVELS, "grid_desc: n_levels out of range");
   uint32_t offset = 0;

@@ -10,6 +10,7 @@ table (what the gather kernel reads) and fp16 MFMA-fragment copies of the MLP we
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -165,6 +166,8 @@ class HipPipeline:
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
         self.recompute = all(s.lib or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
                              for s in layout.nets.values())
+        # hash-grid backward: binned two-pass scatter by default; ALN_ENC_BWD=atomic selects the fp32-atomic kernel
+        self.binned_bwd = os.environ.get('ALN_ENC_BWD', 'binned') != 'atomic'
         self.kernel_events = None  # bench.py: list of ((start, end) HIP events, kernel, tag) around the timed launches
 
     def _k(self, name, *args, tag=None):
@@ -398,6 +401,19 @@ class HipPipeline:
         if on_grad_ready is not None:
             on_grad_ready('mlp', L.n_grid, L.n_total)
         if not e.use_grid:
+            return
+        if self.binned_bwd:
+            # binned scatter (encode.hip): both passes in one launch pair per level group, no global atomics
+            nl = int(e.grid.n_levels)
+            bins = self.ws.scratch('enc_bwd_bins', H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M))
+            F = int(e.grid.n_features)
+            for lo, hi in (level_groups or [(0, nl)]):
+                self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1), H.ptr(d_enc),
+                        H.ptr(P.grad), H.ptr(bins), lo, hi, fi, H.stream(), tag=(M, hi - lo))
+                if on_grad_ready is not None and level_groups is not None:
+                    a = int(e.grid.offset[lo]) * F
+                    b = int(e.grid.offset[hi]) * F if hi < nl else L.n_grid
+                    on_grad_ready('grid', a, b)
             return
         if level_groups is None:
             for (zz, rows, stride, de) in passes:

@@ -137,6 +137,16 @@ int aln_encode_bwd_levels(const AlnEncDesc* e, const float* rays_o, const float*
                           int32_t rows, int32_t rays_stride, const void* d_enc, float* grad_table, int32_t level_lo,
                           int32_t level_hi, void* stream);
 
+/* the same gradient WITHOUT global atomics (encode.hip, "binned backward"): phase 1 counting-sorts the run-deduped
+ * (index, value) records of every 512-row tile by 64 KB table slice and streams them to `ws`; phase 2 accumulates each slice in
+ * LDS and adds it to grad_table.  Rows [0, rows_pass1) are rays_stride1 samples per ray, the rest rays_stride2 (the coarse and
+ * the importance pass of autolabel/trainer.py:64-70 in one launch).  ws = aln_encode_bwd_binned_ws_bytes(e, rows) bytes of
+ * caller-owned scratch.  *found_inf is set when a gradient entry is not finite (record values travel as fp16). */
+int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows);
+int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
+                          int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2, const void* d_enc,
+                          float* grad_table, void* ws, int32_t level_lo, int32_t level_hi, int32_t* found_inf, void* stream);
+
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
                    void* wf, void* wb, void* wr /*optional*/, void* stream);

@@ -99,6 +99,58 @@ def test_encode_backward_is_the_adjoint_of_forward_at_full_size(H):
     assert torch.equal(g3 != 0, grad != 0) and (g3 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
 
 
+def test_binned_scatter_is_the_adjoint_of_the_gather_at_full_size(H):
+    """The same identities for the atomic-free scatter (aln_encode_bwd_binned), both renderer passes in one launch:
+    8192 rays x (128 + 128) samples = 2^21 rows.  Record values are fp16 (2^-11 each), accumulation is fp32."""
+    bound = 3.0
+    e = H.make_enc_desc('hg+freq', bound)
+    spec = O.GridSpec()
+    N, S1, S2 = B_FULL, S_FULL // 2, S_FULL // 2
+    M1, M = N * S1, N * (S1 + S2)
+    g = torch.Generator().manual_seed(7)
+    ro, rd = _rays(N, bound, 4)
+    z = torch.cat([(torch.rand(N, S1, generator=g).sort(dim=1)[0] * 5 + 0.2).reshape(-1),
+                   (torch.rand(N, S2, generator=g).sort(dim=1)[0] * 5 + 0.2).reshape(-1)]).cuda().contiguous()
+    table = ((torch.rand(spec.n_entries, 2, generator=g) - 0.5)).half().cuda()
+    enc = torch.zeros(M, e.enc_pad, dtype=torch.float16, device='cuda')
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(table), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M1, S1, H.ptr(enc), H.stream())
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(table), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, M - M1, S2, H.ptr(enc[M1:]), H.stream())
+    d_enc = torch.zeros(M, e.enc_pad, dtype=torch.float16, device='cuda')
+    d_enc[:, 12:44] = (torch.randn(M, 32, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * 0.05).half()
+    ws = torch.empty(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M)), dtype=torch.uint8, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def binned(grad, a=0, b=N, lo=0, hi=16):
+        # rays [a, b): their coarse rows followed by their fine rows, as one launch
+        zz = torch.cat([z[a * S1:b * S1], z[M1 + a * S2:M1 + b * S2]]).contiguous()
+        de = torch.cat([d_enc[a * S1:b * S1], d_enc[M1 + a * S2:M1 + b * S2]]).contiguous()
+        n = b - a
+        H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro[a:b]), H.ptr(rd[a:b]), H.ptr(zz), None, n * (S1 + S2), n * S1, S1, S2,
+               H.ptr(de), H.ptr(grad), H.ptr(ws), lo, hi, H.ptr(flag), H.stream())
+
+    grad = torch.zeros(spec.n_entries * 2, device='cuda')
+    binned(grad)
+    lhs = (enc[:, 12:44].double() * d_enc[:, 12:44].double()).sum().item()
+    rhs = (table.double().reshape(-1) * grad.double()).sum().item()
+    scale = (enc[:, 12:44].double().abs() * d_enc[:, 12:44].double().abs()).sum().item()
+    assert abs(lhs - rhs) <= 2.0 ** -10 * scale * 0.05 + 1e-6 * scale, (lhs, rhs, scale)
+    assert flag.item() == 0
+    # against the fp32-atomic kernel on the same rows
+    ref = torch.zeros_like(grad)
+    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M1, S1, H.ptr(d_enc), H.ptr(ref), H.stream())
+    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, M - M1, S2, H.ptr(d_enc[M1:]), H.ptr(ref), H.stream())
+    assert (grad - ref).norm().item() <= 5e-4 * ref.norm().item()
+    # additivity over rays
+    g2 = torch.zeros_like(grad)
+    binned(g2, 0, N // 2); binned(g2, N // 2, N)
+    assert (g2 - grad).abs().max().item() <= 1e-4 * max(1.0, grad.abs().max().item())
+    # level groups tile the scatter
+    g3 = torch.zeros_like(grad)
+    for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
+        binned(g3, lo=lo, hi=hi)
+    assert (g3 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
+
+
 def test_render_is_ray_independent_and_bounded_at_full_batch():
     """B = 8192 rays, 128 + 128 samples: permuting the rays permutes the outputs (no cross-ray coupling anywhere in the
     launch sequence), the weights of a ray sum to at most one, and depth lies inside [near, far] / norm."""

@@ -243,6 +243,87 @@ def test_encode_from_rays_and_backward(H):
     assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
 
 
+def _binned_bwd(H, e, ro, rd, z, rows, rows1, s1, s2, d_enc, grad, lo=0, hi=None, flag=None):
+    ws = torch.empty(max(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), 16), dtype=torch.uint8, device='cuda')
+    H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows1, s1, s2, H.ptr(d_enc), H.ptr(grad),
+           H.ptr(ws), lo, int(e.grid.n_levels) if hi is None else hi, H.ptr(flag), H.stream())
+
+
+@pytest.mark.parametrize('N,S', [(37, 24), (1, 5), (300, 13), (64, 128)])
+def test_binned_encode_backward_matches_oracle(H, N, S):
+    """The atomic-free scatter (phase 1 bins fp16x2 records by table slice, phase 2 accumulates in LDS) against fp32 autograd
+    of the oracle's encoder: same touched entries (indexing bit-exact), values to fp16 record rounding (2^-11 per record)."""
+    bound = 1.0
+    e = H.make_enc_desc('hg+freq', bound)
+    cfg = O.ModelConfig(bound=bound)
+    g = torch.Generator().manual_seed(5 + N)
+    ro = (torch.rand(N, 3, generator=g) - 0.5)
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1)
+    z = torch.rand(N, S, generator=g).sort(dim=1)[0] * 2
+    x = torch.clamp(ro[:, None] + rd[:, None] * z[..., None], -bound, bound).reshape(-1, 3)
+    table = ((torch.rand(cfg.grid.n_entries, 2, generator=g) - 0.5)).half()
+    model = O.OracleModel(cfg, params={'grid': table.float()}, half_sim=True)
+    enc_o = model.encode(x)
+    rows = N * S
+    d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16)
+    d_enc[:, :44] = (torch.randn(rows, 44, generator=g) * 0.1).half()
+    (enc_o * d_enc[:, :44].float()).sum().backward()
+    want = model.params['grid'].grad
+    grad = torch.zeros(cfg.grid.n_entries * 2, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    _binned_bwd(H, e, ro.cuda(), rd.cuda(), z.cuda().reshape(-1), rows, rows, S, S, d_enc.cuda(), grad, flag=flag)
+    got = grad.cpu().view(-1, 2)
+    assert flag.item() == 0
+    assert not ((got != 0) & (want == 0)).any(), 'an entry the oracle never touches received a gradient'
+    # per-entry error: each record is rounded to fp16 once (rel 2^-11, products below 3e-8 are dropped, two nearly opposite
+    # records may cancel exactly); the sum of the records itself is exact (64-bit fixed point)
+    assert ((got - want).abs() <= 2.0 ** -10 * want.abs().max()).all()
+    assert (got - want).norm() <= 1e-3 * want.norm()
+    # exact integer accumulation: the result does not depend on the order the records arrive in
+    if int(e.grid.n_levels) > 3:
+        a = int(e.grid.offset[3]) * 2
+        again = torch.zeros_like(grad)
+        _binned_bwd(H, e, ro.cuda(), rd.cuda(), z.cuda().reshape(-1), rows, rows, S, S, d_enc.cuda(), again)
+        assert torch.equal(again[a:], grad[a:]), 'hashed levels must be bit-reproducible'
+
+
+def test_binned_encode_backward_two_passes_and_level_groups(H):
+    """Coarse + fine pass in ONE launch (rows_pass1 / two strides) and the data-parallel level groups give the gradient of the
+    fp32-atomic kernel launched per pass; a non-finite upstream gradient raises found_inf."""
+    bound = 2.0
+    e = H.make_enc_desc('hg+freq', bound)
+    N, S1, S2 = 700, 24, 40       # rows not a multiple of the 512-row tile; tiles straddle the pass boundary
+    M1, M = N * S1, N * (S1 + S2)
+    g = torch.Generator().manual_seed(11)
+    ro = ((torch.rand(N, 3, generator=g) - 0.5) * bound).cuda()
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()
+    z = torch.cat([(torch.rand(N, S1, generator=g).sort(dim=1)[0] * 4).reshape(-1),
+                   (torch.rand(N, S2, generator=g).sort(dim=1)[0] * 4).reshape(-1)]).cuda().contiguous()
+    d_enc = torch.zeros(M, e.enc_pad, dtype=torch.float16, device='cuda')
+    d_enc[:, 12:44] = (torch.randn(M, 32, generator=g) * 0.05).half().cuda()
+    n = int(e.grid.n_entries) * 2
+    ref = torch.zeros(n, device='cuda')
+    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M1, S1, H.ptr(d_enc), H.ptr(ref), H.stream())
+    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, M - M1, S2, H.ptr(d_enc[M1:]), H.ptr(ref), H.stream())
+    got = torch.zeros(n, device='cuda')
+    _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, got)
+    assert (got - ref).norm().item() <= 1e-3 * ref.norm().item()
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    grouped = torch.zeros(n, device='cuda')
+    for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
+        _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, grouped, lo, hi)
+    assert (grouped - got).abs().max().item() <= 1e-5 * max(1.0, got.abs().max().item())
+    # accumulation semantics: a second call adds to the table
+    _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, grouped)
+    assert (grouped - 2 * got).abs().max().item() <= 2e-5 * max(1.0, got.abs().max().item())
+    # overflow watch
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    d_bad = d_enc.clone(); d_bad[5, 20] = float('inf')
+    gbad = torch.zeros(n, device='cuda')
+    _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_bad, gbad, flag=flag)
+    assert flag.item() == 1 and not torch.isfinite(gbad).all()
+
+
 # ------------------------------------------------------------------ MLPs
 MLP_SHAPES = [('sigma', 48, 128, 16, 2), ('color', 32, 128, 16, 2), ('semf', 16, 64, 64, 2), ('semo', 80, 64, 16, 1),
               ('semo_c32', 80, 64, 32, 1)]
