@@ -517,16 +517,16 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     }
     __syncthreads();
     if (tid < 64) {   // exclusive prefix over the slice counters; descriptors; reset the counters for level l + 2
-      const uint32_t n = cnt[par][lane];
-      uint32_t inc = n;
+      const uint32_t n = cnt[par][lane], np = n;
+      uint32_t inc = np;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
-      base[lane] = inc - n;
+      base[lane] = inc - np;
       cnt[par][lane] = 0;
       const int ex = (int)((vmax_s[par] >> 23) & 0xFFu) - 127;          // floor(log2(max)); inf / huge -> large -> shift 0
       const int sh = min(max(14 - ex, 0), BIN_MAX_SHIFT);
       if (lane == 63) { total_s = inc; shift_s = sh; }
-      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - n) | (n << 13) | ((uint32_t)sh << 26);
+      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - np) | (n << 13) | ((uint32_t)sh << 26);
     }
     __syncthreads();
     if (tid == 0) vmax_s[par] = 0u;    // next use: level l + 2, two barriers away from any reader
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
       }
     }
     __syncthreads();
-    const uint32_t total = total_s;
+    const uint32_t total = min(total_s, (uint32_t)BIN_CHUNK);
     uint4* dst = (uint4*)(b.pool + ((size_t)l * b.ntiles + tile) * BIN_CHUNK);
     const uint4* src = (const uint4*)sorted;
     for (uint32_t i = tid; i < (total + 1) / 2; i += BIN_TILE) dst[i] = src[i];
@@ -610,8 +610,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   for (int t0 = (part * nw + wave) * 64; t0 < a.ntiles; t0 += K * nw * 64) {
     const uint32_t dd = (t0 + lane < a.ntiles) ? d[t0 + lane] : 0u;
     const int nt = min(64, a.ntiles - t0);
-    // batches of 4 runs, the first 128 records of each run in two loads per lane; the next batch is requested before the
-    // current one is consumed (16 loads in flight per wave)
+    // batches of 4 runs, the first 128 records of each run in two 8-byte loads per lane (16-byte loads, two records per lane,
+    // were slower: half the lanes idle through the conversions); the next batch is requested before the current one is
+    // consumed (8 KB in flight per wave)
     uint2 r[2][8]; uint32_t st[2][4], n[2][4], up[2][4];
     auto request = [&](int buf, int j0) {
 #pragma unroll

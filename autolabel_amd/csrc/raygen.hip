@@ -47,9 +47,10 @@ extern "C" int aln_compute_direction(const float* R_WC, const int64_t* idx, int3
 
 struct RaygenArgs {
   AlnFrames fr; AlnBatch out; int B, chunk, frame_lo, frame_hi;
-  uint32_t k_frame, k_pix, k_jx, k_jy, k_cls;
+  uint32_t seed, step; const uint32_t* step_dev;   // step_dev (device memory, may be NULL) is added to step: hipGraph replays
   const int* chunk_frames; const int* ray_idx; const float* jitter;
 };
+struct RaygenKeys { uint32_t k_frame, k_pix, k_jx, k_jy, k_cls; };
 
 __device__ inline void gather_pixel(const AlnFrames& fr, const AlnBatch& out, int b, int frame, int64_t pix) {
   size_t hw = (size_t)fr.w * fr.h;
@@ -69,7 +70,13 @@ __device__ inline void gather_pixel(const AlnFrames& fr, const AlnBatch& out, in
   }
 }
 
-__global__ void k_raygen_train(RaygenArgs a) {
+__global__ void k_raygen_train(RaygenArgs args) {
+  const uint32_t st = args.step + (args.step_dev ? *args.step_dev : 0u);
+  struct A : RaygenArgs, RaygenKeys {} a;
+  (RaygenArgs&)a = args;
+  a.k_frame = aln_rand_key(args.seed, ALN_STREAM_FRAME, st); a.k_pix = aln_rand_key(args.seed, ALN_STREAM_PIXEL, st);
+  a.k_jx = aln_rand_key(args.seed, ALN_STREAM_JX, st); a.k_jy = aln_rand_key(args.seed, ALN_STREAM_JY, st);
+  a.k_cls = aln_rand_key(args.seed, ALN_STREAM_CLASS, st);
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x) {
     int ch = b / a.chunk;
     int frame; int64_t pix;
@@ -133,16 +140,14 @@ static int check_frames(const AlnFrames* fr, const AlnBatch* out) {
 
 extern "C" int aln_raygen_train(const AlnFrames* fr, const AlnBatch* out, int32_t B, int32_t chunk, int32_t frame_lo,
                                 int32_t frame_hi, uint32_t seed, uint32_t step, const int32_t* chunk_frames,
-                                const int32_t* ray_idx, const float* jitter, void* stream) {
+                                const int32_t* ray_idx, const float* jitter, const uint32_t* step_dev, void* stream) {
   if (int rc = check_frames(fr, out)) return rc;
   ALN_REQUIRE(chunk > 0 && B % chunk == 0, "raygen_train: batch %d is not a multiple of chunk %d", B, chunk);
   ALN_REQUIRE(chunk_frames || (0 <= frame_lo && frame_lo < frame_hi && frame_hi <= fr->n_frames), "raygen_train: bad frame range");
   ALN_REQUIRE(ray_idx || (fr->pixel_indices && fr->n_pix > 0), "raygen_train: pixel_indices missing");
   ALN_REQUIRE(fr->n_classes == 0 || (fr->cls_offsets && fr->cls_pixels), "raygen_train: class index arrays missing");
   if (B <= 0) return 0;
-  RaygenArgs a{*fr, *out, B, chunk, frame_lo, frame_hi, aln_rand_key(seed, ALN_STREAM_FRAME, step),
-               aln_rand_key(seed, ALN_STREAM_PIXEL, step), aln_rand_key(seed, ALN_STREAM_JX, step),
-               aln_rand_key(seed, ALN_STREAM_JY, step), aln_rand_key(seed, ALN_STREAM_CLASS, step), chunk_frames, ray_idx, jitter};
+  RaygenArgs a{*fr, *out, B, chunk, frame_lo, frame_hi, seed, step, step_dev, chunk_frames, ray_idx, jitter};
   hipLaunchKernelGGL(k_raygen_train, dim3(aln_grid_for(B, 256)), dim3(256), 0, (hipStream_t)stream, a);
   ALN_CHECK_LAUNCH("raygen_train");
   return 0;

@@ -50,8 +50,11 @@ extern "C" int aln_ray_aabb(const float* rays_o, const float* rays_d, int32_t N,
 
 // ------------------------------------------------------------------ coarse
 __global__ void k_sample_coarse(const float* __restrict__ ro, const float* __restrict__ rd, int N, int S1, float bound,
-                                float min_near, int perturb, uint32_t key, const float* __restrict__ noise,
-                                float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ z) {
+                                float min_near, int perturb, uint32_t seed, uint32_t step, const uint32_t* __restrict__ step_dev,
+                                const float* __restrict__ noise, float* __restrict__ nears, float* __restrict__ fars,
+                                float* __restrict__ z) {
+  // step_dev: the step number lives in device memory (added to `step`) so that a captured hipGraph replays with fresh noise
+  const uint32_t key = aln_rand_key(seed, ALN_STREAM_PERTURB, step + (step_dev ? *step_dev : 0u));
   size_t total = (size_t)N * S1;
   for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     int ray = (int)(t / S1), i = (int)(t % S1);
@@ -72,12 +75,11 @@ __global__ void k_sample_coarse(const float* __restrict__ ro, const float* __res
 
 extern "C" int aln_sample_coarse(const float* rays_o, const float* rays_d, int32_t N, int32_t S1, float bound,
                                  float min_near, int32_t perturb, uint32_t seed, uint32_t step, const float* noise,
-                                 float* nears, float* fars, float* z, void* stream) {
+                                 float* nears, float* fars, float* z, const uint32_t* step_dev, void* stream) {
   ALN_REQUIRE(rays_o && rays_d && nears && fars && z && S1 > 0 && S1 <= MAX_S, "sample_coarse: bad arguments");
   if (N <= 0) return 0;
-  uint32_t key = aln_rand_key(seed, ALN_STREAM_PERTURB, step);
   hipLaunchKernelGGL(k_sample_coarse, dim3(aln_grid_for((int64_t)N * S1, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
-                     rays_d, N, S1, bound, min_near, perturb, key, noise, nears, fars, z);
+                     rays_d, N, S1, bound, min_near, perturb, seed, step, step_dev, noise, nears, fars, z);
   ALN_CHECK_LAUNCH("sample_coarse");
   return 0;
 }
@@ -123,8 +125,9 @@ __device__ inline void scan_suffix_excl(const float* v, float* R, int n, int lan
 // ------------------------------------------------------------------ fine (importance) samples
 __global__ __launch_bounds__(64) void k_sample_fine(const float* __restrict__ zc, const float* __restrict__ sigma,
                                                    const float* __restrict__ nears, const float* __restrict__ fars, int N,
-                                                   int S1, int S2, float density_scale, int perturb, uint32_t key,
+                                                   int S1, int S2, float density_scale, int perturb, uint32_t seed, uint32_t step, const uint32_t* __restrict__ step_dev,
                                                    const float* __restrict__ u_in, float* __restrict__ zf) {
+  const uint32_t key = aln_rand_key(seed, ALN_STREAM_PDF, step + (step_dev ? *step_dev : 0u));
   extern __shared__ float sm[];
   float* z = sm;            // [S1]
   float* a = z + S1;        // [S1]  val / pdf scratch
@@ -202,15 +205,14 @@ __global__ __launch_bounds__(64) void k_sample_fine(const float* __restrict__ zc
 
 extern "C" int aln_sample_fine(const float* z_coarse, const float* sigma_coarse, const float* nears, const float* fars,
                                int32_t N, int32_t S1, int32_t S2, float density_scale, int32_t perturb, uint32_t seed,
-                               uint32_t step, const float* u, float* z_fine, void* stream) {
+                               uint32_t step, const float* u, float* z_fine, const uint32_t* step_dev, void* stream) {
   ALN_REQUIRE(z_coarse && sigma_coarse && nears && fars && z_fine, "sample_fine: NULL pointer");
   ALN_REQUIRE(S1 >= 3 && S1 <= MAX_S && S2 > 0 && S2 <= MAX_S, "sample_fine: S1=%d S2=%d out of range", S1, S2);
   if (N <= 0) return 0;
   int S2p = 1; while (S2p < S2) S2p <<= 1;
   size_t lds = (size_t)(4 * S1 + S2p) * sizeof(float);
-  uint32_t key = aln_rand_key(seed, ALN_STREAM_PDF, step);
   hipLaunchKernelGGL(k_sample_fine, dim3(N < 65535 ? N : 65535), dim3(64), lds, (hipStream_t)stream, z_coarse, sigma_coarse,
-                     nears, fars, N, S1, S2, density_scale, perturb, key, u, z_fine);
+                     nears, fars, N, S1, S2, density_scale, perturb, seed, step, step_dev, u, z_fine);
   ALN_CHECK_LAUNCH("sample_fine");
   return 0;
 }

@@ -503,13 +503,14 @@ class DeviceFrames:
         d.features = b['features'].data_ptr() if 'features' in b else None
         return d
 
-    def next_train(self, out, seed, step, frame_range=None, chunk=512, chunk_frames=None, ray_idx=None):
-        """Fill `out` (from alloc_batch) with one training batch; frame_range=(lo,hi) shards frames across ranks."""
+    def next_train(self, out, seed, step, frame_range=None, chunk=512, chunk_frames=None, ray_idx=None, step_dev=None):
+        """Fill `out` (from alloc_batch) with one training batch; frame_range=(lo,hi) shards frames across ranks.
+        step_dev: optional device int32[1] added to `step` inside the kernel (hipGraph replays: engine.GraphedStep)."""
         H = self.H
         B = out['rays_o'].shape[0]
         lo, hi = frame_range if frame_range is not None else (0, self.n_frames)
         H.call('aln_raygen_train', C.byref(self.desc), C.byref(self._batch_desc(out)), B, chunk, lo, hi, seed, step,
-               H.ptr(chunk_frames), H.ptr(ray_idx), None, H.stream())
+               H.ptr(chunk_frames), H.ptr(ray_idx), None, H.ptr(step_dev), H.stream())
         return out
 
     def get_test(self, frame, out=None):

@@ -46,12 +46,12 @@ _SIGS = {
     'aln_abi_version': (i32, []),
     'aln_grid_desc_init': (i32, [vp]),
     'aln_compute_direction': (i32, [vp, vp, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp]),
-    'aln_raygen_train': (i32, [vp, vp, i32, i32, i32, i32, u32, u32, vp, vp, vp, vp]),
+    'aln_raygen_train': (i32, [vp, vp, i32, i32, i32, i32, u32, u32, vp, vp, vp, vp, vp]),
     'aln_raygen_frame': (i32, [vp, vp, i32, vp]),
     'aln_ray_aabb': (i32, [vp, vp, i32, f32, f32, vp, vp, vp]),
     'aln_sh4': (i32, [vp, i32, i32, vp, vp]),
-    'aln_sample_coarse': (i32, [vp, vp, i32, i32, f32, f32, i32, u32, u32, vp, vp, vp, vp, vp]),
-    'aln_sample_fine': (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, u32, u32, vp, vp, vp]),
+    'aln_sample_coarse': (i32, [vp, vp, i32, i32, f32, f32, i32, u32, u32, vp, vp, vp, vp, vp, vp]),
+    'aln_sample_fine': (i32, [vp, vp, vp, vp, i32, i32, i32, f32, i32, u32, u32, vp, vp, vp, vp]),
     'aln_encode_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'aln_encode_fwd_ws_bytes': (i64, [vp, i32]),
     'aln_encode_fwd_phased': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),

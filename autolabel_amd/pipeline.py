@@ -228,8 +228,8 @@ class HipPipeline:
         if e.use_grid and rows >= self.phased_min_rows:
             # large batches: level-phased gathers (tables in flight stay L2-resident) + streaming row assembly
             planes = self.ws.scratch('enc_planes', int(e.grid.n_levels) * rows * 4)
-            H.call('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz),
-                   rows, stride, H.ptr(planes), H.ptr(enc), H.stream())
+            self._k('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz),
+                    rows, stride, H.ptr(planes), H.ptr(enc), H.stream(), tag=('enc_fwd', rows))
         else:
             H.call('aln_encode_fwd', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows,
                    stride, H.ptr(enc), H.stream())
@@ -239,7 +239,7 @@ class HipPipeline:
         H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sigma), H.stream())
 
     def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
-                want_semantic=True, bg=1.0):
+                want_semantic=True, bg=1.0, step_dev=None):
         L, P, ws = self.L, self.P, self.ws
         N = rays_o.shape[0]
         S, M = S1 + S2, N * (S1 + S2)
@@ -259,12 +259,12 @@ class HipPipeline:
         sout = c['sigma_out'] = g('sigma_out', (M, 16), f16)
         sigma = c['sigma'] = g('sigma', (M,), f32_)
         H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
-               H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.stream())
+               H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.ptr(step_dev), H.stream())
         self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train)
         if S2 > 0:
             zf = z[M1:]
             H.call('aln_sample_fine', H.ptr(z), H.ptr(sigma), H.ptr(c['nears']), H.ptr(c['fars']), N, S1, S2,
-                   self.density_scale, int(perturb), seed, step, H.ptr(u), H.ptr(zf), H.stream())
+                   self.density_scale, int(perturb), seed, step, H.ptr(u), H.ptr(zf), H.ptr(step_dev), H.stream())
             self.density_rows(N * S2, rays_o, rays_d, zf, None, S2, enc[M1:], h1[M1:] if save else h1,
                               h2[M1:] if save else h2, sout[M1:], sigma[M1:], train)
         perm = c['perm'] = g('perm', (N, S), torch.int16)

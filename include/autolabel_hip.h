@@ -96,7 +96,8 @@ typedef struct {
 int aln_raygen_train(const AlnFrames* fr, const AlnBatch* out, int32_t B, int32_t chunk,
                      int32_t frame_lo, int32_t frame_hi, uint32_t seed, uint32_t step,
                      const int32_t* chunk_frames, const int32_t* ray_idx, const float* jitter,
-                     void* stream);
+                     const uint32_t* step_dev /* device word added to step, or NULL: lets a captured hipGraph replay with a
+                                                 fresh step number */, void* stream);
 int aln_raygen_frame(const AlnFrames* fr, const AlnBatch* out, int32_t frame, void* stream);
 /* bare _compute_direction on an index list (fixture F1) */
 int aln_compute_direction(const float* R_WC, const int64_t* idx, int32_t n, int32_t w, double fx, double fy,
@@ -108,10 +109,12 @@ int aln_ray_aabb(const float* rays_o, const float* rays_d, int32_t N, float boun
                  float* fars, void* stream);
 int aln_sample_coarse(const float* rays_o, const float* rays_d, int32_t N, int32_t S1, float bound, float min_near,
                       int32_t perturb, uint32_t seed, uint32_t step, const float* noise /*[N,S1] or NULL*/,
-                      float* nears, float* fars, float* z /*[N,S1]*/, void* stream);
+                      float* nears, float* fars, float* z /*[N,S1]*/, const uint32_t* step_dev /*see aln_raygen_train*/,
+                      void* stream);
 int aln_sample_fine(const float* z_coarse, const float* sigma_coarse, const float* nears, const float* fars, int32_t N,
                     int32_t S1, int32_t S2, float density_scale, int32_t perturb, uint32_t seed, uint32_t step,
-                    const float* u /*[N,S2] or NULL*/, float* z_fine /*[N,S2] sorted*/, void* stream);
+                    const float* u /*[N,S2] or NULL*/, float* z_fine /*[N,S2] sorted*/, const uint32_t* step_dev,
+                    void* stream);
 
 /* ---- encoding: tcnn Frequency + GridEncoding, autolabel/models.py:51-59 */
 int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,

@@ -95,7 +95,7 @@ def test_raygen_train_replays_reference_batch(H, golden_dir):
     jitter = rng.random((B, 2)).astype(np.float32)
     b, t = _batch(H, B, Cf=int(f['feat_shape'][2]))
     cfd, rid, jd = dev(chunk_frames), dev(ray_idx), dev(jitter)
-    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, 0, 0, H.ptr(cfd), H.ptr(rid), H.ptr(jd), H.stream())
+    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, 0, 0, H.ptr(cfd), H.ptr(rid), H.ptr(jd), None, H.stream())
     w, h, fx, fy, cx, cy = f['intr']
     Hf, Wf, Cf = [int(v) for v in f['feat_shape']]
     for c in range(B // 512):
@@ -118,7 +118,7 @@ def test_raygen_train_counter_rng_matches_oracle_rng(H, golden_dir):
     fr, keep = _frames(H, f)
     B, seed, step = 2048, 77, 5
     b, t = _batch(H, B)
-    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, seed, step, None, None, None, H.stream())
+    H.call('aln_raygen_train', C.byref(fr), C.byref(b), B, 512, 0, fr.n_frames, seed, step, None, None, None, None, H.stream())
     frames = O.rand_u32(seed, O.STREAM_FRAME, step, np.arange(B // 512)) % np.uint32(fr.n_frames)
     pix = f['pixel_indices'][O.rand_u32(seed, O.STREAM_PIXEL, step, np.arange(B)) % np.uint32(fr.n_pix)]
     jx, jy = O.rand_uniform(seed, O.STREAM_JX, step, np.arange(B)), O.rand_uniform(seed, O.STREAM_JY, step, np.arange(B))
@@ -430,12 +430,12 @@ def test_sample_coarse_bit_exact(H):
     for perturb, want in [(0, z), (1, zp)]:
         nears, fars, zz = torch.empty(N, device='cuda'), torch.empty(N, device='cuda'), torch.empty(N, S1, device='cuda')
         H.call('aln_sample_coarse', H.ptr(od_), H.ptr(dd_), N, S1, bound, 0.2, perturb, 0, 0, H.ptr(nd_),
-               H.ptr(nears), H.ptr(fars), H.ptr(zz), H.stream())
+               H.ptr(nears), H.ptr(fars), H.ptr(zz), None, H.stream())
         assert torch.equal(nears.cpu(), near) and torch.equal(fars.cpu(), far)
         assert torch.equal(zz.cpu(), want)
     # internal counter RNG == oracle RNG
     H.call('aln_sample_coarse', H.ptr(od_), H.ptr(dd_), N, S1, bound, 0.2, 1, 9, 4, None, H.ptr(nears), H.ptr(fars),
-           H.ptr(zz), H.stream())
+           H.ptr(zz), None, H.stream())
     u = torch.from_numpy(O.rand_uniform(9, O.STREAM_PERTURB, 4, np.arange(N * S1))).view(N, S1)
     assert torch.equal(zz.cpu(), z + (u - 0.5) * ((far - near)[:, None] / np.float32(S1)))
 
@@ -482,7 +482,7 @@ def test_sample_fine_matches_sample_pdf(H, perturb):
     zf = torch.empty(N, S2, device='cuda')
     zd, sd_, nd_, fd_, ud = z.cuda(), sigma.cuda(), near.cuda(), far.cuda(), u.contiguous().cuda()
     H.call('aln_sample_fine', H.ptr(zd), H.ptr(sd_), H.ptr(nd_), H.ptr(fd_), N, S1, S2, 1.0, perturb,
-           0, 0, H.ptr(ud) if perturb else None, H.ptr(zf), H.stream())
+           0, 0, H.ptr(ud) if perturb else None, H.ptr(zf), None, H.stream())
     got = zf.cpu()
     assert (got[:, 1:] >= got[:, :-1]).all()
     # parallel scans re-associate the cumprod / cumsum: 1e-4 of the ray span (cdf steps can be steep)
