@@ -180,6 +180,16 @@ class HipPipeline:
         ev[1].record()
         self.kernel_events.append((ev, name, tag))
 
+    def binned_record_count(self, M):
+        """Records the last binned hash-grid backward over M sample rows streamed through HBM (sum of the per-(level, slice,
+        tile) descriptor counts; 8 bytes each, written once by phase 1 and read once by phase 2).  Host sync: reporting only."""
+        t = self.ws.bufs.get('enc_bwd_bins')
+        if t is None or not self.binned_bwd:
+            return None
+        nl, nt = int(self.L.enc.grid.n_levels), (M + 511) // 512
+        desc = t[1][nl * nt * 4096 * 8:nl * nt * 4096 * 8 + nl * 64 * nt * 4].view(torch.int32)
+        return int(((desc >> 13) & 0x1FFF).sum().item())
+
     # ---- library-GEMM heads (MlpSpec.lib): y = relu(x W0^T) ... ; fp16 operands, fp32 accumulate (hipBLASLt)
     def _lib_fwd(self, k, x, save):
         ws, h, hs = self.P.lib_w[k], x, []

@@ -324,7 +324,8 @@ def main():
                 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                 'traffic': pmc.get('encode_bwd_traffic_bytes_per_launch'), 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
                 'algorithmic_bytes_per_launch': sum(per_launch) / len(per_launch),
-                'records_per_launch': pmc.get('encode_bwd_records_per_launch'),
+                'records_per_launch': eng.pipe.binned_record_count(B * (eng.S1 + eng.S2)), 'record_bytes': 8,
+                'atomic_requests_per_launch_round1_kernel': (pmc.get('atomic_kernel_requests_per_launch') or {}).get('TCC_ATOMIC_sum'),
                 'note': 'HIP events around the launch pair over %d launch-by-launch steps right after the timed region (the timed '
                         'region itself replays a hipGraph, which cannot carry events); phase 1 sorts fp16x2 (index, value) records '
                         'by 64 KB table slice in LDS and streams them out (8 B/record), phase 2 streams them back and accumulates '
