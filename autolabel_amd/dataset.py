@@ -518,3 +518,22 @@ class DeviceFrames:
         out = out if out is not None else self.alloc_batch(self.w * self.h)
         H.call('aln_raygen_frame', C.byref(self.desc), C.byref(self._batch_desc(out)), int(frame), H.stream())
         return out
+
+
+class DeviceLoader:
+    """Endless iterable of device batches: frames resident in HBM, batches assembled by the HIP ray-generation kernel
+    (replaces DataLoader + worker process + H2D copy of scripts/train.py:64-68).  ``frame_range`` = this rank's shard of the
+    frames under data parallelism (parallel.frame_shard); ``seed`` should differ per rank (parallel.rank_seed)."""
+
+    def __init__(self, frames, batch_size, length, seed=0, frame_range=None):
+        self.frames, self.batch, self.length = frames, frames.alloc_batch(batch_size), length
+        self.seed, self.step, self.frame_range = seed, 0, frame_range
+
+    def __iter__(self):
+        for _ in range(self.length):
+            self.frames.next_train(self.batch, self.seed, self.step, frame_range=self.frame_range)
+            self.step += 1
+            yield self.batch
+
+    def __len__(self):
+        return self.length

@@ -170,8 +170,7 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self._once()
-        self.steps = warmup + 1    # (the captured pass itself does not execute)
-        self.steps -= 1
+        self.steps = warmup    # executed so far (the captured pass itself does not execute)
 
     def _once(self):
         self.body(self.counter)

@@ -121,12 +121,17 @@ class Trainer:
         return len({g['lr'] for g in o.param_groups}) == 1 and len({g['betas'] for g in o.param_groups}) == 1
 
     def _engine(self):
-        if self.engine is None:
+        """The fused engine bound to the model's CURRENT device buffers.  ``model.to()/cuda()`` re-binds the parameters to a
+        new flat buffer and ``load_state_dict`` / EMA ``copy_to`` rewrite the fp32 masters in place: ``_ensure_device`` is asked
+        every time (it refreshes the fp16 shadows when a parameter version changed), a new pipeline gets a new engine that
+        inherits the optimizer state, and a checkpoint's engine state is applied as soon as there is an engine to take it."""
+        pipe = self.model._ensure_device()
+        if self.engine is None or self.engine.pipe is not pipe:
             from .engine import TrainEngine
             g0 = self.optimizer.param_groups[0]
             wd = max(g.get('weight_decay', 0.0) for g in self.optimizer.param_groups)
-            pipe = self.model._ensure_device()
             opt = self.opt
+            old = self.engine
             self.engine = TrainEngine(pipe, lr=g0['lr'], betas=g0['betas'], eps=g0['eps'], weight_decay_net=wd,
                                       rgb_weight=opt.rgb_weight, depth_weight=opt.depth_weight,
                                       semantic_weight=opt.semantic_weight, feature_weight=opt.feature_weight,
@@ -134,9 +139,16 @@ class Trainer:
                                       num_steps=getattr(opt, 'num_steps', self.model.num_steps_default),
                                       upsample_steps=getattr(opt, 'upsample_steps', self.model.upsample_steps_default),
                                       process_group=self.process_group)
-            if getattr(self, '_engine_state', None) is not None:
-                self.engine.load_state_dict(self._engine_state)
-        self.engine.lr = self.optimizer.param_groups[0]['lr']  # follows the torch scheduler
+            if old is not None:   # same parameters on a new buffer: the Adam moments / loss scale / step counters carry over
+                self.engine.load_state_dict(old.state_dict())
+            self._graph = None
+        if getattr(self, '_engine_state', None) is not None:
+            self.engine.load_state_dict(self._engine_state)
+            self._engine_state = None
+        lr = self.optimizer.param_groups[0]['lr']  # follows the torch scheduler
+        if lr != self.engine.lr:
+            self.engine.lr = lr
+            self._graph = None   # the learning rate is baked into a captured step
         return self.engine
 
     def _to_device_batch(self, data):
@@ -224,6 +236,13 @@ class SimpleTrainer(Trainer):
     def train_iterations(self, dataloader, iterations):
         """`iterations` optimisation steps, then ONE ema update and ONE scheduler step (autolabel/trainer.py:32-52)."""
         self.model.train()
+        from .dataset import DeviceLoader
+        if self.fused and isinstance(dataloader, DeviceLoader) and self.world_size == 1 and os.environ.get('ALN_GRAPH', '1') != '0':
+            loss = self._graphed_iterations(dataloader, iterations)
+            if self.ema is not None:
+                self.ema.update()
+            self._step_scheduler(loss)
+            return
         iterator = iter(dataloader)
         bar = tqdm(range(iterations), desc='Loss: N/A', disable=self.mute or self.local_rank != 0)
         loss = None
@@ -254,6 +273,27 @@ class SimpleTrainer(Trainer):
         batch = data if torch.is_tensor(data['rays_o']) and data['rays_o'].is_cuda and data['semantic'].dtype == torch.int32 \
             else self._to_device_batch(data)
         eng.step(batch, seed=self.model._seed, step=self.global_step)
+        self.optimizer._opt_called = True   # the fused Adam stepped: torch's scheduler must not warn about its own optimizer
+        return eng.terms[4]
+
+    def _graphed_iterations(self, loader, iterations):
+        """Device-resident data (dataset.DeviceLoader): ray generation + the whole optimisation step replay from ONE hipGraph
+        (engine.GraphedStep); the capture is redone when the engine, the learning rate or the loader changes."""
+        eng = self._engine()
+        key = (id(loader), id(eng), eng.lr)
+        if getattr(self, '_graph', None) is None or self._graph[0] != key:
+            g = eng.graphed(loader.frames, loader.batch, loader.seed, self.model._seed, frame_range=loader.frame_range,
+                            first_step=self.global_step, warmup=1)
+            self.global_step += g.steps
+            loader.step += g.steps
+            self._graph = (key, g)
+            iterations -= g.steps
+        g = self._graph[1]
+        for _ in range(max(iterations, 0)):
+            g()
+        self.global_step += max(iterations, 0)
+        loader.step += max(iterations, 0)
+        self.optimizer._opt_called = True
         return eng.terms[4]
 
     def train_step(self, data):

@@ -1,5 +1,10 @@
 """Fit a scene (CLI of the reference's scripts/train.py).  `--synthetic room|cube` trains on a generated scene instead
-of a directory; `--device-data` keeps the frames in HBM and assembles batches with the HIP ray-generation kernels."""
+of a directory; `--device-data` keeps the frames in HBM and assembles batches with the HIP ray-generation kernels.
+
+Data parallel: start it under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1
+scripts/train.py ...` -- one process per GPU, frames sharded over the ranks, model replicated (rank 0's initialisation is
+broadcast), gradients averaged by the RCCL all-reduce inside the fused step, checkpoints written by rank 0 only.
+`--batch-size` is the per-GPU batch; `--global-batch B` fixes the global batch instead (B / N rays per GPU)."""
 import math
 import os
 import sys
@@ -11,7 +16,8 @@ import torch
 from torch import optim
 
 from autolabel_amd import model_utils
-from autolabel_amd.dataset import ArrayDataset, LenDataset, SceneDataset
+from autolabel_amd import parallel
+from autolabel_amd.dataset import ArrayDataset, DeviceLoader, LenDataset, SceneDataset
 from autolabel_amd.trainer import SimpleTrainer
 
 
@@ -27,27 +33,20 @@ def read_args():
     parser.add_argument('--workspace', type=str, default=None, help='Save results here instead of the scene directory.')
     parser.add_argument('--synthetic', choices=['room', 'cube'], default=None)
     parser.add_argument('--device-data', action='store_true', help='device-resident frames + HIP batch assembly')
+    parser.add_argument('--global-batch', type=int, default=0, help='data parallel: fixed global batch (overrides --batch-size)')
     return parser.parse_args()
-
-
-class DeviceLoader:
-    """Endless iterable of device batches (replaces DataLoader + worker process + H2D copy)."""
-
-    def __init__(self, frames, batch_size, length, seed=0):
-        self.frames, self.batch, self.length, self.seed, self.step = frames, frames.alloc_batch(batch_size), length, seed, 0
-
-    def __iter__(self):
-        for _ in range(self.length):
-            self.frames.next_train(self.batch, self.seed, self.step)
-            self.step += 1
-            yield self.batch
-
-    def __len__(self):
-        return self.length
 
 
 def main():
     flags = read_args()
+    rank, world, local = parallel.init_distributed()     # before any GPU call; a single process is rank 0 of 1
+    device = f'cuda:{local}'
+    if world > 1:
+        torch.cuda.set_device(local)
+        np.random.seed(parallel.rank_seed(0, rank) % (2 ** 32))   # host-side frame / pixel picks differ per rank
+        if flags.global_batch:
+            assert flags.global_batch % (512 * world) == 0, 'global batch must be a multiple of 512 rays per rank'
+            flags.batch_size = flags.global_batch // world
     if flags.synthetic:
         from autolabel_amd import synthetic
         scene = synthetic.make_room_scene(n_frames=60, feat_dim=64 if flags.features else 0) if flags.synthetic == 'room' \
@@ -64,7 +63,8 @@ def main():
         {'name': 'net', 'params': model.network_parameters(), 'weight_decay': 1e-6},
     ], lr=flags.lr, betas=(0.9, 0.99), eps=1e-15)
     if flags.device_data:
-        train_dataloader = DeviceLoader(dataset.device_frames('cuda'), flags.batch_size, 1000)
+        train_dataloader = DeviceLoader(dataset.device_frames(device), flags.batch_size, 1000, seed=parallel.rank_seed(0, rank),
+                                        frame_range=parallel.frame_shard(dataset.n_examples, rank, world))
     else:
         train_dataloader = torch.utils.data.DataLoader(LenDataset(dataset, 1000), batch_size=None, num_workers=flags.workers)
     train_dataloader._data = dataset
@@ -75,13 +75,21 @@ def main():
     scheduler = lambda optimizer: optim.lr_scheduler.StepLR(optimizer, gamma=gamma, step_size=step_size)
     epochs = int(np.ceil(flags.iters / 1000))
     model_dir = model_utils.model_dir(flags.scene, flags)
-    model_utils.write_params(model_dir, flags)
-    trainer = SimpleTrainer('ngp', opt, model, device='cuda:0', workspace=model_dir, optimizer=optimizer, criterion=criterion,
+    if rank == 0:
+        model_utils.write_params(model_dir, flags)
+    pg = torch.distributed.group.WORLD if world > 1 else None
+    trainer = SimpleTrainer('ngp', opt, model, device=device, workspace=model_dir, optimizer=optimizer, criterion=criterion,
                             fp16=True, ema_decay=0.95, lr_scheduler=scheduler, scheduler_update_every_step=False, metrics=[],
-                            use_checkpoint='latest')
+                            use_checkpoint='latest', local_rank=rank, world_size=world, process_group=pg)
+    if world > 1:   # replicas start identical (a resumed checkpoint is read by every rank; the broadcast also covers a fresh init)
+        parallel.broadcast_parameters(model._ensure_device().P.flat, pg)
+        model._shadow_version = None
     trainer.train(train_dataloader, epochs)
-    trainer.save_checkpoint()
-    if flags.eval:
+    if rank == 0:
+        trainer.save_checkpoint()
+    if world > 1:
+        torch.distributed.barrier()
+    if flags.eval and rank == 0:
         if flags.synthetic:
             testset = ArrayDataset(synthetic.subsample(scene, flags.factor_test), batch_size=flags.batch_size * 2, split='test')
         else:

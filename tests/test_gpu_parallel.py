@@ -92,3 +92,56 @@ def test_two_ranks_on_one_gpu_stay_in_lockstep_with_bucketed_allreduce():
         f1, f0 = res[rank][True]['flat'], res[rank][False]['flat']
         ng = res[rank][True]['n_grid']
         assert (f1[ng:] - f0[ng:]).abs().max() < 5e-2 and ((f1[:ng] - f0[:ng]).abs() > 1e-2).float().mean() < 0.02
+
+
+def _trainer_worker(rank, world, port, ret):
+    """scripts/train.py's data-parallel wiring driven through SimpleTrainer: DeviceLoader over this rank's frame shard,
+    rank seeds, broadcast of rank 0's initialisation, process_group handed to the trainer."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    from argparse import Namespace
+    from autolabel_amd import parallel, synthetic
+    r, w, local = parallel.init_distributed('gloo')
+    assert (r, w) == (rank, world)
+    torch.cuda.set_device(0)
+    from autolabel_amd.dataset import DeviceFrames, DeviceLoader
+    from autolabel_amd.models import ALNetwork
+    from autolabel_amd.trainer import SimpleTrainer
+    scene = synthetic.make_cube_scene(n_frames=8, size=32, seed=0, device='cuda')
+    torch.manual_seed(rank)   # different initialisations on purpose: the broadcast must make them equal
+    model = ALNetwork(encoding='hg+freq', num_layers=2, hidden_dim=128, geo_feat_dim=15, num_layers_color=2, hidden_dim_color=128,
+                      hidden_dim_semantic=64, semantic_classes=scene['n_classes'], bound=6.0, cuda_ray=False, density_scale=1)
+    model.reset_parameters(seed=rank)
+    opt = Namespace(rand_pose=-1, color_space='srgb', feature_loss=False, rgb_weight=1.0, depth_weight=0.1, semantic_weight=1.0,
+                    feature_weight=0.5, num_steps=32, upsample_steps=32)
+    optimizer = lambda m: torch.optim.Adam([{'name': 'encoding', 'params': list(m.encoder.parameters())},
+                                            {'name': 'net', 'params': m.network_parameters(), 'weight_decay': 1e-6}],
+                                           lr=5e-3, betas=(0.9, 0.99), eps=1e-15)
+    tr = SimpleTrainer('ngp', opt, model, device='cuda:0', workspace=None, optimizer=optimizer,
+                       criterion=torch.nn.MSELoss(reduction='none'), fp16=True, ema_decay=None,
+                       lr_scheduler=lambda o: torch.optim.lr_scheduler.StepLR(o, gamma=0.5, step_size=10), metrics=[],
+                       use_checkpoint='scratch', local_rank=rank, world_size=world, process_group=dist.group.WORLD, mute=True)
+    parallel.broadcast_parameters(model._ensure_device().P.flat, dist.group.WORLD)
+    model._shadow_version = None
+    loader = DeviceLoader(DeviceFrames.from_scene(scene, 'cuda'), 1024, 1000, seed=parallel.rank_seed(0, rank),
+                          frame_range=parallel.frame_shard(8, rank, world))
+    tr.train_iterations(loader, 4)
+    torch.cuda.synchronize()
+    flat = model._P.flat.detach().cpu()
+    both = [None] * world
+    dist.all_gather_object(both, flat)
+    ret[rank] = dict(same=bool(torch.equal(both[0], both[1])), finite=bool(torch.isfinite(flat).all()), fused=tr.fused,
+                     steps=int(tr.engine.state_i[0].item()), world=tr.engine.world, loss=float(tr.engine.terms[4]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_simple_trainer_data_parallel_on_two_ranks():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_trainer_worker, args=(world, port, ret), nprocs=world, join=True)
+        res = dict(ret)
+    for rank in range(world):
+        r = res[rank]
+        assert r['fused'] and r['world'] == 2 and r['steps'] == 4, r
+        assert r['same'] and r['finite'], 'replicas must stay bit-identical after the averaged-gradient steps'

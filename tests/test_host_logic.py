@@ -158,3 +158,13 @@ def test_synthetic_scene_round_trips_through_scene_directory(tmp_path):
     np.random.seed(0); random.seed(0)
     b = ds._next_train()
     assert b['rays_o'].shape == (1024, 3) and b['semantic'].dtype == np.int64 and (b['semantic'] >= -1).all()
+
+
+def test_bench_refuses_a_gpu_count_that_is_not_the_world_size():
+    """ADVICE r1: `--gpus N` must mean N ranks.  Under a launcher (RANK set) a mismatch exits non-zero before any GPU call;
+    with no launcher bench.py starts the ranks itself (covered on the GPU box by the driver's --gpus runs)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and 'WORLD_SIZE' in r.stderr
