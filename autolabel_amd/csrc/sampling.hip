@@ -231,6 +231,7 @@ struct CompFwd {
   uint16_t* perm;      // [N, S]
   float* w_row; float* T_row; float* delta_row;  // [M]
   float* wsum; float* depth; float* depth_var; float* coords;  // [N], [N], [N], [N,3]
+  const float* delta_in;   // [N, S1] explicit step lengths (occupancy-grid marching, S2 == 0) or NULL: differences of z
 };
 
 __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
     __syncthreads();
     const float sd = __fdiv_rn(__fsub_rn(p.fars[ray], p.nears[ray]), (float)p.S1);
     for (int k = lane; k < S; k += 64) {
-      float delta = (k + 1 < S) ? zs[k + 1] - zs[k] : sd;
+      float delta = p.delta_in ? p.delta_in[(size_t)ray * S + k] : ((k + 1 < S) ? zs[k + 1] - zs[k] : sd);
       float alpha = 1.f - expf(-delta * p.density_scale * sg[k]);
       v[k] = 1.f - alpha + 1e-15f;
       sg[k] = alpha;       // reuse: alpha
@@ -302,13 +303,15 @@ __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
 extern "C" int aln_composite_fwd(const float* rays_o, const float* rays_d, const float* norms, const float* nears,
                                  const float* fars, const float* z, const float* sigma, int32_t N, int32_t S1, int32_t S2,
                                  float bound, float density_scale, uint16_t* perm, float* w_row, float* T_row,
-                                 float* delta_row, float* wsum, float* depth, float* depth_var, float* coords, void* stream) {
+                                 float* delta_row, float* wsum, float* depth, float* depth_var, float* coords,
+                                 const float* delta_in, void* stream) {
   ALN_REQUIRE(rays_o && rays_d && norms && nears && fars && z && sigma && perm && w_row && T_row && delta_row && wsum &&
                   depth && depth_var && coords, "composite_fwd: NULL pointer");
   ALN_REQUIRE(S1 > 0 && S2 >= 0 && S1 + S2 <= 2 * MAX_S, "composite_fwd: sample counts out of range");
   if (N <= 0) return 0;
   CompFwd p{rays_o, rays_d, norms, nears, fars, z, sigma, N, S1, S2, bound, density_scale,
-            perm, w_row, T_row, delta_row, wsum, depth, depth_var, coords};
+            perm, w_row, T_row, delta_row, wsum, depth, depth_var, coords, delta_in};
+  ALN_REQUIRE(!delta_in || S2 == 0, "composite_fwd: explicit step lengths need a single pass (S2 == 0)");
   int S = S1 + S2;
   size_t lds = (size_t)S * (5 * sizeof(float) + sizeof(uint16_t)) + 16;
   hipLaunchKernelGGL(k_composite_fwd, dim3(N < 65535 ? N : 65535), dim3(64), lds, (hipStream_t)stream, p);

@@ -51,6 +51,12 @@ class TrainEngine:
         self.overlap_comm = self.world > 1 and os.environ.get('ALN_DP_OVERLAP', '1') != '0'   # ALN_DP_OVERLAP=0: one collective
         self._comm = torch.cuda.Stream(device=dv) if self.world > 1 else None
         self._g = {}
+        # occupancy-grid marching (pipe.occ set by enable_marching / ALNetwork(cuda_ray=True)): S1 rows per ray inside occupied
+        # cells, no importance pass; the density grid is refreshed every occ.update_interval steps (autolabel/trainer.py:34-36)
+        self.march = pipe.occ is not None
+        if self.march:
+            self.S1, self.S2 = pipe.occ.samples, 0
+        self._calls = 0
 
     def _gbuf(self, name, shape):
         t = self._g.get(name)
@@ -62,7 +68,7 @@ class TrainEngine:
         L, pipe = self.L, self.pipe
         N = batch['rays_o'].shape[0]
         out, ctx = pipe.forward(batch['rays_o'], batch['rays_d'], batch['direction_norms'].reshape(-1), self.S1, self.S2, True,
-                                train=True, seed=seed, step=step, noise=noise, u=u, step_dev=step_dev)
+                                train=True, seed=seed, step=step, noise=noise, u=u, step_dev=step_dev, march=self.march)
         gt_feat = batch.get('features') if self.feature_loss else None
         Cf = gt_feat.shape[1] if gt_feat is not None else 0
         g_image, g_depth = self._gbuf('g_image', (N, 3)), self._gbuf('g_depth', (N,))
@@ -123,7 +129,15 @@ class TrainEngine:
                self._blk_kind, int(bool(self.feature_loss)), H.ptr(self.counts), H.stream())
         P.refresh_shadows(grid=False)
 
-    def step(self, batch, seed, step, noise=None, u=None, step_dev=None):
+    def maybe_update_grid(self):
+        """`if self.model.cuda_ray and self.global_step % 16 == 0: update_extra_state()` (autolabel/trainer.py:34-36)."""
+        if self.march and self._calls % self.pipe.occ.update_interval == 0:
+            self.pipe.update_density_grid(step=self._calls)
+        self._calls += 1
+
+    def step(self, batch, seed, step, noise=None, u=None, step_dev=None, grid_update=True):
+        if grid_update:
+            self.maybe_update_grid()
         out = self.forward_backward(batch, seed, step, noise, u, step_dev)
         self.all_reduce_grads()
         self.optimizer_step()
@@ -137,8 +151,9 @@ class TrainEngine:
         removes the ~0.7 ms of Python + HIP launch overhead a step costs when issued call by call."""
         def body(step_dev):
             frames.next_train(batch, seed=data_seed, step=first_step, frame_range=frame_range, step_dev=step_dev)
-            self.step(batch, seed=seed, step=first_step, step_dev=step_dev)
-        return GraphedStep(body, self.P.device, warmup=warmup)
+            self.step(batch, seed=seed, step=first_step, step_dev=step_dev, grid_update=False)
+        # the density-grid refresh (every 16th step) stays outside the captured sequence: it runs launch by launch before the replay
+        return GraphedStep(body, self.P.device, warmup=warmup, pre_hook=self.maybe_update_grid if self.march else None)
 
     # checkpoint payload mirrors torch's {'optimizer', 'scaler'} entries (autolabel/backend.py:157-164)
     def state_dict(self):
@@ -157,13 +172,15 @@ class GraphedStep:
     workspace exists before the capture (allocation is not capturable).  Re-capture (``GraphedStep(...)`` again) after
     anything baked into the launches changes: learning rate, batch size, loss weights, level groups."""
 
-    def __init__(self, body, device, warmup=3):
+    def __init__(self, body, device, warmup=3, pre_hook=None):
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)
-        self.body = body
+        self.body, self.pre_hook = body, pre_hook
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
+                if pre_hook is not None:
+                    pre_hook()
                 self._once()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -177,5 +194,7 @@ class GraphedStep:
         self.counter.add_(1)
 
     def __call__(self):
+        if self.pre_hook is not None:
+            self.pre_hook()
         self.graph.replay()
         self.steps += 1

@@ -77,7 +77,11 @@ _SIGS = {
     'aln_assemble_grads': (i32, [vp, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
     'aln_relu_bwd': (i32, [vp, vp, i64, vp, vp]),
     'aln_assemble_dsemf_out': (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
-    'aln_composite_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'aln_composite_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'aln_march_rays': (i32, [vp, vp, i32, i32, f32, f32, vp, i32, i32, i32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'aln_grid_points': (i32, [i32, f32, u32, u32, vp, vp, vp]),
+    'aln_grid_update': (i32, [vp, vp, i32, f32, f32, f32, vp, vp, vp, vp]),
+    'aln_mark_untrained_grid': (i32, [vp, i32, f32, vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 6),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),

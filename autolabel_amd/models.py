@@ -146,6 +146,12 @@ class ALNetwork(NeRFRenderer):
                     P.flat[a:b].copy_(p.data.reshape(-1))
                     p.data = P.flat[a:b]
             self._P, self._pipe = P, HipPipeline(self._layout, P, density_scale=float(self.density_scale), min_near=float(self.min_near))
+            if self.cuda_ray:
+                from .pipeline import OccupancyGrid
+                self._pipe.occ = OccupancyGrid(p0.device, G=self.grid_size, max_steps=self.max_steps, samples=self.march_samples,
+                                               density_thresh=float(self.density_thresh), grid=self.density_grid,
+                                               bits=self.density_bitfield)
+                self._pipe.refresh_bitfield()    # (a loaded checkpoint carries the grid; the bit count is recomputed)
             self._shadow_version = None
         ver = tuple(p._version for _, p in self._param_blocks())
         if ver != self._shadow_version:

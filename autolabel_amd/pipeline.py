@@ -152,6 +152,28 @@ class Workspace:
 f16, f32_, i32_ = torch.float16, torch.float32, torch.int32
 
 
+class OccupancyGrid:
+    """Density grid + bitfield of the `cuda_ray` path (csrc/march.hip; hooks: autolabel/trainer.py:21-23,34-36,176).
+    One level, G^3 cells over [-bound, bound]^3; `grid` / `bits` may be the model's registered buffers (they travel with
+    state_dict like upstream's density_grid / density_bitfield)."""
+
+    def __init__(self, device, G=128, max_steps=1024, samples=96, density_thresh=0.01, decay=0.95, update_interval=16,
+                 grid=None, bits=None):
+        self.G, self.max_steps, self.samples = int(G), int(max_steps), int(samples)
+        self.density_thresh, self.decay, self.update_interval = float(density_thresh), float(decay), int(update_interval)
+        n = self.G ** 3
+        self.grid = grid if grid is not None else torch.zeros(n, dtype=f32_, device=device)
+        self.bits = bits if bits is not None else torch.zeros((n + 31) // 32, dtype=i32_, device=device)
+        assert self.grid.numel() == n and self.bits.numel() == (n + 31) // 32
+        self.stats = torch.zeros(2, dtype=f32_, device=device)
+        self.n_set = torch.zeros(1, dtype=i32_, device=device)
+        self.updates = 0
+
+    def occupancy(self):
+        """Fraction of cells with their bit set (host sync: reporting only)."""
+        return float(self.n_set.item()) / self.G ** 3
+
+
 class HipPipeline:
     """render forward / backward as a fixed launch sequence (renderer semantics: oracle/nerf_oracle.py run())."""
 
@@ -168,6 +190,7 @@ class HipPipeline:
                              for s in layout.nets.values())
         # hash-grid backward: binned two-pass scatter by default; ALN_ENC_BWD=atomic selects the fp32-atomic kernel
         self.binned_bwd = os.environ.get('ALN_ENC_BWD', 'binned') != 'atomic'
+        self.occ = None     # OccupancyGrid: forward(..., march=True) then places the samples by marching (enable_marching)
         self.kernel_events = None  # bench.py: list of ((start, end) HIP events, kernel, tag) around the timed launches
 
     def _k(self, name, *args, tag=None):
@@ -179,6 +202,45 @@ class HipPipeline:
         H.call(name, *args)
         ev[1].record()
         self.kernel_events.append((ev, name, tag))
+
+    # ---- occupancy-grid marching (csrc/march.hip)
+    def enable_marching(self, **kw):
+        self.occ = OccupancyGrid(self.P.device, **kw)
+        return self.occ
+
+    def update_density_grid(self, step=0, seed=0x5EED, chunk=1 << 19):
+        """NeRFRenderer.update_extra_state of the fork (autolabel/trainer.py:34-36: every 16 steps): density of one jittered point
+        per cell, grid = max(grid * decay, sigma * density_scale), bit = grid > min(mean, density_thresh)."""
+        occ, e = self.occ, self.L.enc
+        n = occ.G ** 3
+        xyz = self.ws.get('occ_xyz', (n, 3), f32_)
+        sig = self.ws.get('occ_sigma', (n,), f32_)
+        H.call('aln_grid_points', occ.G, e.bound, seed, step, None, H.ptr(xyz), H.stream())
+        enc = self.ws.get('occ_enc', (chunk, e.enc_pad), f16)
+        out = self.ws.get('occ_out', (chunk, 16), f16)
+        for a in range(0, n, chunk):
+            rows = min(chunk, n - a)
+            self.density_rows(rows, None, None, None, xyz[a:a + rows], 1, enc, None, None, out, sig[a:a + rows], train=False)
+        H.call('aln_grid_update', H.ptr(occ.grid), H.ptr(sig), occ.G, occ.decay, self.density_scale, occ.density_thresh,
+               H.ptr(occ.stats), H.ptr(occ.bits), H.ptr(occ.n_set), H.stream())
+        occ.updates += 1
+
+    def refresh_bitfield(self):
+        """Bitfield from the grid as it is (after mark_untrained_grid / a checkpoint load)."""
+        occ = self.occ
+        H.call('aln_grid_update', H.ptr(occ.grid), None, occ.G, occ.decay, self.density_scale, occ.density_thresh,
+               H.ptr(occ.stats), H.ptr(occ.bits), H.ptr(occ.n_set), H.stream())
+
+    def mark_untrained_grid(self, T_CW, intrinsics, size=None, z_near=0.0, sub=2):
+        """Cells no camera sees get -1 (never occupied).  T_CW: [F,4,4] world -> OpenCV camera in the renderer's frame."""
+        occ = self.occ
+        T = torch.as_tensor(T_CW, dtype=f32_).to(self.P.device).contiguous()
+        fx, fy, cx, cy = [float(v) for v in intrinsics]
+        w, h = size if size is not None else (2 * cx + 1, 2 * cy + 1)
+        H.call('aln_mark_untrained_grid', H.ptr(occ.grid), occ.G, self.L.enc.bound, H.ptr(T), T.shape[0], fx, fy, cx, cy, float(w),
+               float(h), float(z_near), int(sub), H.stream())
+        torch.cuda.current_stream().synchronize()   # T is a temporary
+        self.refresh_bitfield()
 
     def binned_record_count(self, M):
         """Records the last binned hash-grid backward over M sample rows streamed through HBM (sum of the per-(level, slice,
@@ -249,9 +311,12 @@ class HipPipeline:
         H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sigma), H.stream())
 
     def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
-                want_semantic=True, bg=1.0, step_dev=None):
+                want_semantic=True, bg=1.0, step_dev=None, march=False):
         L, P, ws = self.L, self.P, self.ws
         N = rays_o.shape[0]
+        if march:   # S1 rows per ray placed inside occupied cells, no importance pass (noise: [N] per-ray jitter)
+            assert self.occ is not None, 'forward(march=True) needs enable_marching()'
+            S2 = 0
         S, M = S1 + S2, N * (S1 + S2)
         M1 = N * S1
         e, nets = L.enc, L.nets
@@ -268,8 +333,16 @@ class HipPipeline:
         h2 = c['h2'] = g('h2', (M if save else 1, hs), f16)
         sout = c['sigma_out'] = g('sigma_out', (M, 16), f16)
         sigma = c['sigma'] = g('sigma', (M,), f32_)
-        H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
-               H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.ptr(step_dev), H.stream())
+        delta_in = None
+        if march:
+            occ = self.occ
+            delta_in = c['delta_in'] = g('delta_in', (M,), f32_)
+            H.call('aln_march_rays', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, H.ptr(occ.bits), occ.G, occ.max_steps,
+                   int(perturb), seed, step, H.ptr(step_dev), H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z),
+                   H.ptr(delta_in), None, H.stream())
+        else:
+            H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
+                   H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.ptr(step_dev), H.stream())
         self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train)
         if S2 > 0:
             zf = z[M1:]
@@ -286,7 +359,7 @@ class HipPipeline:
         H.call('aln_composite_fwd', H.ptr(rays_o), H.ptr(rays_d), H.ptr(norms), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z),
                H.ptr(sigma), N, S1, S2, e.bound, self.density_scale, H.ptr(perm), H.ptr(w_row), H.ptr(T_row), H.ptr(d_row),
                H.ptr(out['weights_sum']), H.ptr(out['depth']), H.ptr(out['depth_variance']), H.ptr(out['coordinates_map']),
-               H.stream())
+               H.ptr(delta_in), H.stream())
         # color head on live samples only (models.py:195-203)
         n_live, live_idx, cidx = g('n_live', (1,), i32_), g('live_idx', (M,), i32_), g('cidx_row', (M,), i32_)
         c.update(n_live=n_live, live_idx=live_idx, cidx_row=cidx)

@@ -25,7 +25,8 @@ class _RenderFn(torch.autograd.Function):
         pipe = model._pipe
         train = any(ctx.needs_input_grad[5:])  # (grad mode is off inside Function.forward)
         out, c = pipe.forward(rays_o, rays_d, norms, cfg['num_steps'], cfg['upsample_steps'], cfg['perturb'], train=train,
-                              seed=cfg['seed'], step=cfg['step'], noise=cfg.get('noise'), u=cfg.get('u'), bg=cfg['bg'])
+                              seed=cfg['seed'], step=cfg['step'], noise=cfg.get('noise'), u=cfg.get('u'), bg=cfg['bg'],
+                              march=cfg.get('march', False))
         ctx.model, ctx.c = model, (c if train else None)
         ctx.set_materialize_grads(False)  # unused outputs arrive as None: their heads then get grad None like in the reference
         keys = ['image', 'depth', 'semantic', 'semantic_features', 'depth_variance', 'coordinates_map', 'weights_sum']
@@ -56,7 +57,8 @@ class _RenderFn(torch.autograd.Function):
 
 class NeRFRenderer(nn.Module):
 
-    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1, **kwargs):
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=10.0, bg_radius=-1,
+                 grid_size=128, max_steps=1024, march_samples=96, **kwargs):
         super().__init__()
         self.bound = bound
         self.cuda_ray = cuda_ray
@@ -64,32 +66,56 @@ class NeRFRenderer(nn.Module):
         self.min_near = min_near
         self.density_thresh = density_thresh
         self.bg_radius = bg_radius
-        if cuda_ray:
-            raise NotImplementedError('cuda_ray (occupancy-grid marching) is not part of this hot path '
-                                      '(the reference always passes cuda_ray=False, autolabel/model_utils.py:72)')
+        # cuda_ray: occupancy-grid marching (csrc/march.hip).  The reference passes False (autolabel/model_utils.py:72); True
+        # places `march_samples` rows per ray inside occupied cells instead of num_steps + upsample_steps rows along the whole ray.
+        self.grid_size, self.max_steps, self.march_samples = int(grid_size), int(max_steps), int(march_samples)
+        if cuda_ray:   # like upstream's density_grid / density_bitfield buffers: part of the checkpoint
+            n = self.grid_size ** 3
+            self.register_buffer('density_grid', torch.zeros(n, dtype=torch.float32))
+            self.register_buffer('density_bitfield', torch.zeros((n + 31) // 32, dtype=torch.int32))
+        self._grid_updates = 0
         aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
         self.register_buffer('aabb_train', aabb)
         self.register_buffer('aabb_infer', aabb.clone())
         self._render_calls = 0
         self.num_steps_default, self.upsample_steps_default, self.max_ray_batch_default = 128, 128, 4096
 
-    # --- hooks of the cuda_ray path (dead in the reference configuration)
+    # --- hooks of the cuda_ray path (autolabel/trainer.py:21-23,34-36,176; no-ops when cuda_ray is False, as in the reference)
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        return
+        """poses: [F,4,4] camera-to-world in the renderer's frame (dataset.poses = _convert_pose output, whose camera axes are
+        x right / y down / z forward); intrinsic: (fx, fy, cx, cy).  Cells no camera sees are excluded for good."""
+        if not self.cuda_ray:
+            return
+        import numpy as np
+        T_WC = np.asarray(poses.cpu() if torch.is_tensor(poses) else poses, dtype=np.float64).reshape(-1, 4, 4)
+        self._ensure_device().mark_untrained_grid(np.linalg.inv(T_WC).astype(np.float32), intrinsic)
 
     def update_extra_state(self, decay=0.95, S=128):
-        return
+        if not self.cuda_ray:
+            return
+        pipe = self._ensure_device()
+        pipe.occ.decay = float(decay)
+        pipe.update_density_grid(step=self._grid_updates)
+        self._grid_updates += 1
 
     def reset_extra_state(self):
-        return
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.density_bitfield.zero_()
+        self._grid_updates = 0
 
     def run(self, rays_o, rays_d, direction_norms, num_steps=None, upsample_steps=None, bg_color=None, perturb=False,
             seed=None, noise=None, u=None, **kwargs):
         """One chunk of rays [N,3] -> per-ray outputs.  bg_color None -> white (upstream torch-ngp)."""
         self._ensure_device()
         N = rays_o.shape[0]
+        if self.cuda_ray:   # marching ignores num_steps / upsample_steps (as upstream's run_cuda does)
+            num_steps, upsample_steps = self.march_samples, 0
+            if self._grid_updates == 0 and int(self._pipe.occ.n_set.item()) == 0:
+                self.update_extra_state()   # never rendered through an empty bitfield
         cfg = dict(num_steps=int(num_steps if num_steps is not None else self.num_steps_default),
-                   upsample_steps=int(upsample_steps if upsample_steps is not None else self.upsample_steps_default),
+                   upsample_steps=int(upsample_steps if upsample_steps is not None else self.upsample_steps_default), march=bool(self.cuda_ray),
                    perturb=bool(perturb), seed=int(self._seed if seed is None else seed), step=self._render_calls,
                    bg=1.0 if bg_color is None else float(bg_color), noise=noise, u=u)
         self._render_calls += 1

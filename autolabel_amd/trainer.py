@@ -253,6 +253,8 @@ class SimpleTrainer(Trainer):
                 if it % 100 == 99 and hasattr(bar, 'set_description'):
                     bar.set_description(f'Loss: {float(self.engine.terms[4]):.04f}')  # the only host sync, every 100 steps
             else:
+                if self.model.cuda_ray and self.global_step % 16 == 0:   # autolabel/trainer.py:34-36
+                    self.model.update_extra_state()
                 for opt in self.optimizers:
                     opt.zero_grad()
                 with torch.autocast('cuda', enabled=self.fp16):
@@ -383,6 +385,8 @@ class InteractiveTrainer(SimpleTrainer):
         if self.fused:
             loss = self.fused_step(data)
         else:
+            if self.model.cuda_ray and self.global_step % 16 == 0:   # autolabel/trainer.py:176
+                self.model.update_extra_state()
             self.optimizer.zero_grad()
             with torch.autocast('cuda', enabled=self.fp16):
                 _, _, loss = self.train_step(data)

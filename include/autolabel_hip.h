@@ -205,13 +205,34 @@ int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d_semo_in, i
  * is OR-ed when a non-finite gradient passes */
 int aln_relu_bwd(void* g, const void* act, int64_t n, int32_t* found_inf, void* stream);
 
+/* ---- occupancy-grid marching (march.hip): the cuda_ray hooks of autolabel/trainer.py:21-23,34-36,176 and
+ * NeRFRenderer.mark_untrained_grid / update_extra_state of the torch-ngp fork (dead in the reference: model_utils.py:72).
+ * One-level G^3 density grid over [-bound,bound]^3 (-1 = never seen), one bit per cell. */
+/* every ray gets exactly S sample rows z[N,S] + step lengths delta[N,S] inside occupied cells (evenly subsampled when more than
+ * S of the max_steps uniform steps are occupied, padded with delta = 0 otherwise); counts[N] (optional) = occupied steps */
+int aln_march_rays(const float* rays_o, const float* rays_d, int32_t N, int32_t S, float bound, float min_near,
+                   const uint32_t* bitfield, int32_t G, int32_t max_steps, int32_t perturb, uint32_t seed, uint32_t step,
+                   const uint32_t* step_dev, const float* noise /*[N] or NULL*/, float* nears, float* fars, float* z, float* delta,
+                   int32_t* counts, void* stream);
+/* one jittered point per cell, xyz[G^3,3] (input of the density head for the grid update) */
+int aln_grid_points(int32_t G, float bound, uint32_t seed, uint32_t step, const float* noise /*[G^3,3] or NULL*/, float* xyz,
+                    void* stream);
+/* grid = max(grid * decay, sigma * density_scale) on cells >= 0 (sigma NULL: statistics only), then
+ * bit = grid > min(mean over cells >= 0, thresh); stats = 2 floats of scratch; n_set (optional) = number of set bits */
+int aln_grid_update(float* grid, const float* sigma, int32_t G, float decay, float density_scale, float thresh, float* stats,
+                    uint32_t* bitfield, int32_t* n_set, void* stream);
+/* cells no camera sees become -1; T_CW [n_poses,4,4] row-major world -> OpenCV camera, pinhole fx fy cx cy, image w x h */
+int aln_mark_untrained_grid(float* grid, int32_t G, float bound, const float* T_CW, int32_t n_poses, float fx, float fy,
+                            float cx, float cy, float w, float h, float z_near, int32_t sub, void* stream);
+
 /* ---- compositing: alpha / cumprod weights and weighted sums of NeRFRenderer.run (fork), outputs image, depth
  * (metric z-depth = sum w t / direction_norm), semantic, semantic_features, depth_variance, coordinates_map;
  * call sites autolabel/trainer.py:64-70, scripts/export.py:83-89, scripts/language/pointcloud.py:58-68 */
 int aln_composite_fwd(const float* rays_o, const float* rays_d, const float* norms, const float* nears, const float* fars,
                       const float* z, const float* sigma, int32_t N, int32_t S1, int32_t S2, float bound, float density_scale,
                       uint16_t* perm, float* w_row, float* T_row, float* delta_row, float* wsum, float* depth, float* depth_var,
-                      float* coords, void* stream);
+                      float* coords, const float* delta_in /*[N,S1] explicit step lengths (marching, S2 == 0) or NULL*/,
+                      void* stream);
 int aln_composite_out(const float* w_row, const int32_t* cidx_row, const void* color_out, const void* logits, const void* feat,
                       const float* wsum, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad, int32_t D, float bg,
                       float* image, float* semantic, float* features, void* stream);

@@ -510,3 +510,82 @@ def test_fused_semantic_heads_forward_is_bit_identical_to_two_launches(H):
             os.environ.pop('ALN_SEM_FWD_UNFUSED', None)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0].abs().max() > 0 and outs[0][1].abs().max() > 0
+
+
+# ------------------------------------------------------------------ occupancy-grid marching (csrc/march.hip vs oracle/march_oracle.py)
+def _march_case(N, G, seed, fill):
+    g = np.random.default_rng(seed)
+    bound = 2.0
+    o = ((g.random((N, 3)) - 0.5) * 2.0 * bound * 0.8).astype(np.float32)
+    d = g.normal(size=(N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o[::7] = (d[::7] * -3.0 * bound)[:len(o[::7])]          # outside, looking in
+    o[3::11] += 10.0 * bound                                 # misses the box
+    bits = g.random(G ** 3) < fill
+    return bound, o, d, bits
+
+
+@pytest.mark.parametrize('N,G,S,max_steps,fill', [(301, 32, 12, 256, 0.08), (64, 16, 16, 128, 0.6), (40, 8, 32, 64, 0.0), (17, 128, 96, 1024, 0.02)])
+def test_march_rays_matches_oracle_bit_exact(H, N, G, S, max_steps, fill):
+    """Step positions, per-ray occupied counts, the even subsampling for K > S and the zero-length padding rows: index
+    work and fp32 step arithmetic are held bit-exact to the oracle."""
+    from oracle import march_oracle as MO
+    bound, o, d, bits = _march_case(N, G, 1 + N, fill)
+    words = (np.pad(bits, (0, (-len(bits)) % 32)).reshape(-1, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(1).astype(np.uint32)
+    for perturb in (0, 1):
+        u = np.random.default_rng(5).random(N).astype(np.float32) if perturb else None
+        near, far, z, delta, counts = MO.march_rays(o, d, S, bound, 0.2, bits, G, max_steps, u)
+        od, dd = dev(o), dev(d)
+        zd, dl = torch.empty(N, S, device='cuda'), torch.empty(N, S, device='cuda')
+        nd, fd, cd = torch.empty(N, device='cuda'), torch.empty(N, device='cuda'), torch.empty(N, dtype=torch.int32, device='cuda')
+        wd, ud = dev(words.view(np.int32)), (dev(u) if perturb else None)     # (named: temporaries would be freed before the launch runs)
+        H.call('aln_march_rays', H.ptr(od), H.ptr(dd), N, S, bound, 0.2, H.ptr(wd), G, max_steps, perturb, 0, 0,
+               None, H.ptr(ud), H.ptr(nd), H.ptr(fd), H.ptr(zd), H.ptr(dl), H.ptr(cd), H.stream())
+        assert np.array_equal(cd.cpu().numpy(), counts)
+        assert np.array_equal(nd.cpu().numpy(), near) and np.array_equal(fd.cpu().numpy(), far)
+        assert np.array_equal(dl.cpu().numpy(), delta), 'step lengths'
+        assert np.array_equal(zd.cpu().numpy(), z), 'sample positions'
+    assert (counts > S).any() or fill < 0.05       # the subsampling branch is exercised by the dense cases
+    assert (counts == 0).any()
+
+
+def test_density_grid_update_and_untrained_mask_match_oracle(H):
+    from oracle import march_oracle as MO
+    G, bound = 24, 1.5
+    g = np.random.default_rng(3)
+    n = G ** 3
+    u = g.random((n, 3)).astype(np.float32)
+    xyz = torch.empty(n, 3, device='cuda')
+    ud = dev(u)
+    H.call('aln_grid_points', G, bound, 0, 0, H.ptr(ud), H.ptr(xyz), H.stream())
+    assert np.array_equal(xyz.cpu().numpy(), MO.grid_points(G, bound, u))
+    # counter-RNG points stay inside their cell
+    H.call('aln_grid_points', G, bound, 7, 3, None, H.ptr(xyz), H.stream())
+    cells = MO.cell_of(xyz.cpu().numpy(), bound, G)
+    assert (cells != np.arange(n)).mean() < 1e-4      # (u -> 1 may round onto the next cell's border in fp32)
+    # mark_untrained: two cameras inside the box
+    grid0 = g.random(n).astype(np.float32)
+    T = np.stack([np.eye(4), np.eye(4)]).astype(np.float32)
+    T[1, :3, :3] = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0]], np.float32)
+    T[1, :3, 3] = [0.3, -0.2, 0.5]
+    want = MO.mark_untrained(grid0, G, bound, T, 40.0, 40.0, 31.5, 23.5, 64.0, 48.0, 0.0, 2)
+    gd = dev(grid0.copy())
+    Td = dev(T)
+    H.call('aln_mark_untrained_grid', H.ptr(gd), G, bound, H.ptr(Td), 2, 40.0, 40.0, 31.5, 23.5, 64.0, 48.0, 0.0, 2, H.stream())
+    got = gd.cpu().numpy()
+    assert ((got < 0) != (want < 0)).mean() < 2e-3 and (want < 0).any() and (want >= 0).any()   # fp32 projection at the image border
+    # EMA-max update + bitfield
+    sigma = (g.random(n) ** 4 * 5).astype(np.float32)
+    grid_w, bits_w, mean_w = MO.grid_update(want, sigma, 0.95, 1.0, 0.01)
+    gd = dev(want.copy())
+    stats, nset = torch.zeros(2, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+    bits = torch.zeros((n + 31) // 32, dtype=torch.int32, device='cuda')
+    sd = dev(sigma)
+    H.call('aln_grid_update', H.ptr(gd), H.ptr(sd), G, 0.95, 1.0, 0.01, H.ptr(stats), H.ptr(bits), H.ptr(nset), H.stream())
+    assert np.array_equal(gd.cpu().numpy(), grid_w)
+    assert abs(stats[0].item() / stats[1].item() - mean_w) < 1e-5 * max(mean_w, 1.0)
+    unpacked = ((bits.cpu().numpy().view(np.uint32)[:, None] >> np.arange(32, dtype=np.uint32)[None]) & 1).astype(bool).reshape(-1)[:n]
+    th = min(mean_w, 0.01)
+    near_th = np.abs(grid_w - th) < 1e-6
+    assert np.array_equal(unpacked[~near_th], bits_w[~near_th]) and nset.item() == unpacked.sum()
+    assert not unpacked[grid_w < 0].any()

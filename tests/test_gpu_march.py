@@ -1,0 +1,131 @@
+"""Occupancy-grid marching (`cuda_ray=True`) end to end: skipping empty space must not change the picture,
+training through the marched samples must converge, and the grid travels with the checkpoint."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cuda_ray, C_, bound, **kw):
+    from autolabel_amd.models import ALNetwork
+    return ALNetwork(encoding='hg+freq', num_layers=2, hidden_dim=128, geo_feat_dim=15, num_layers_color=2, hidden_dim_color=128,
+                     hidden_dim_semantic=64, semantic_classes=C_, bound=bound, cuda_ray=cuda_ray, density_scale=1, **kw).cuda()
+
+
+def _train(model, frames, steps, batch=2048, graph=False):
+    from autolabel_amd.engine import TrainEngine
+    eng = TrainEngine(model._ensure_device(), num_steps=64, upsample_steps=64)
+    b = frames.alloc_batch(batch)
+    if graph:
+        g = eng.graphed(frames, b, 1, 2, warmup=2)
+        for _ in range(steps - g.steps):
+            g()
+    else:
+        for i in range(steps):
+            frames.next_train(b, seed=1, step=i)
+            eng.step(b, seed=2, step=i)
+    return eng
+
+
+def test_marching_render_equals_dense_stepping_when_the_bitfield_is_exact():
+    """Same uniform steps, once with every bit set (= dense stepping, nothing skipped) and once through a bitfield that is
+    EXACT for these rays: a cell is occupied iff one of the rays' steps inside it has optical thickness sigma * dt > 1e-5.
+    Marching then drops only steps with alpha <= 1e-5, so image / depth / semantic outputs must agree to ~max_steps * 1e-5.
+    (A grid sampled at one jittered point per cell is never exact -- hash-grid fields vary inside a cell -- which is why the
+    equivalence is tested with the bitfield built from the dense pass itself.)"""
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from oracle import march_oracle as MO
+    scene = synthetic.make_cube_scene(n_frames=8)
+    frames = DeviceFrames.from_scene(scene, 'cuda')
+    torch.manual_seed(0)
+    G, steps, bound = 64, 256, 6.0
+    model = _model(True, scene['n_classes'], bound, grid_size=G, max_steps=steps, march_samples=steps, density_thresh=10.0)
+    _train(model, frames, 300)
+    pipe, occ = model._ensure_device(), model._pipe.occ
+    t = frames.get_test(2)
+    ro, rd, dn = t['rays_o'].reshape(-1, 3)[::3].contiguous(), t['rays_d'].reshape(-1, 3)[::3].contiguous(), t['direction_norms'].reshape(-1)[::3].contiguous()
+    N = ro.shape[0]
+    occ.bits.fill_(-1)
+    dense, c = pipe.forward(ro, rd, dn, steps, 0, False, train=False, march=True)
+    z, sig, dl = c['z'].view(N, steps).cpu().numpy(), c['sigma'].view(N, steps).cpu().numpy(), c['delta_in'].view(N, steps).cpu().numpy()
+    dense = {k: v.clone() for k, v in dense.items()}
+    xyz = np.clip(ro.cpu().numpy()[:, None] + rd.cpu().numpy()[:, None] * z[..., None], -bound, bound)
+    cells = MO.cell_of(xyz, bound, G)
+    tau = (sig * dl).astype(np.float64)
+    eps = np.quantile(tau[dl > 0], 0.4)       # the thinnest 40 % of the steps are candidates for skipping
+    thick = tau > eps
+    bits = np.zeros(G ** 3, bool)
+    bits[cells[thick]] = True
+    assert 0.0 < bits.mean() < 0.9
+    skipped_steps = ~bits[cells] & (dl > 0)
+    tau_skipped = (tau * skipped_steps).sum(1)          # optical thickness each ray loses: bounds the change of its outputs
+    words = (bits.reshape(-1, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(1).astype(np.uint32)
+    occ.bits.copy_(torch.as_tensor(words.view(np.int32)).cuda())
+    marched, c2 = pipe.forward(ro, rd, dn, steps, 0, False, train=False, march=True)
+    skipped = 1.0 - (c2['delta_in'] > 0).float().mean().item() / max((torch.as_tensor(dl) > 0).float().mean().item(), 1e-9)
+    assert skipped > 0.02, f'only {skipped:.3f} of the steps were skipped: the test would not exercise the compaction'
+    assert np.isclose(skipped, skipped_steps.sum() / (dl > 0).sum(), atol=1e-6), 'the kernel skipped exactly the steps of empty cells'
+    # removing steps of total thickness tau scales every later weight by <= e^tau and drops <= tau of weight:
+    # |d output| <= (2 tau + fp16 noise) * max|per-sample value|
+    lim = torch.as_tensor(2.0 * np.expm1(tau_skipped) + 3e-3, dtype=torch.float32, device='cuda')
+    for k, scale in [('image', 1.0), ('weights_sum', 1.0), ('depth', float(z.max())), ('semantic', None), ('semantic_features', None)]:
+        d = (marched[k] - dense[k]).abs()
+        d = d.reshape(N, -1).max(dim=1).values
+        sc = scale if scale is not None else max(1.0, 4.0 * dense[k].abs().max().item())
+        assert (d <= lim * sc).all(), (k, (d / (lim * sc)).max().item())
+    assert (marched['image'] - dense['image']).abs().max().item() > 0 or skipped == 0
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_training_through_marched_samples_converges(graph):
+    """cuda_ray=True with the default budget (96 rows per ray instead of 128 + 128): loss drops, a training view is reproduced,
+    the density grid empties out; the hipGraph replay (grid refresh outside the capture) behaves the same."""
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    scene = synthetic.make_cube_scene()
+    frames = DeviceFrames.from_scene(scene, 'cuda')
+    torch.manual_seed(0)
+    model = _model(True, scene['n_classes'], 6.0, grid_size=64, max_steps=512, march_samples=96, density_thresh=10.0)
+    eng = _train(model, frames, 400, graph=graph)
+    assert eng.march and eng.S1 == 96 and eng.S2 == 0
+    assert int(eng.state_i[0].item()) == 400 and torch.isfinite(model._P.flat).all()
+    occ = model._pipe.occ
+    assert occ.updates == 400 // 16 and 0.0005 < occ.occupancy() < 0.6
+    t = frames.get_test(0)
+    with torch.inference_mode():
+        out = model.eval().render(t['rays_o'], t['rays_d'], t['direction_norms'], staged=True, perturb=False)
+    psnr = -10 * math.log10(((out['image'] - t['pixels'].view_as(out['image'])) ** 2).mean().item())
+    assert psnr > 11.0, psnr      # (400 steps in a box 12x the cube: the dense path reaches the same)
+    # the grid and the bitfield are part of the checkpoint (upstream: density_grid / density_bitfield buffers)
+    sd = model.state_dict()
+    assert 'density_grid' in sd and 'density_bitfield' in sd and (sd['density_grid'] > 0).any()
+    m2 = _model(True, scene['n_classes'], 6.0, grid_size=64, max_steps=512, march_samples=96, density_thresh=10.0)
+    m2.load_state_dict(sd)
+    with torch.inference_mode():
+        out2 = m2.eval().render(t['rays_o'], t['rays_d'], t['direction_norms'], staged=True, perturb=False)
+    assert torch.equal(out2['image'], out['image'])
+
+
+def test_mark_untrained_grid_excludes_unseen_cells_through_the_model_api():
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import ArrayDataset
+    scene = synthetic.make_cube_scene(n_frames=4)
+    ds = ArrayDataset(scene, batch_size=512)
+    model = _model(True, scene['n_classes'], 6.0, grid_size=32, max_steps=128, march_samples=32)
+    model.mark_untrained_grid(ds.poses, ds.intrinsics)          # the call of autolabel/trainer.py:21-23
+    grid = model.density_grid.cpu().numpy()
+    assert (grid < 0).any() and (grid >= 0).any()
+    from oracle import march_oracle as MO
+    T_CW = np.linalg.inv(ds.poses.astype(np.float64)).astype(np.float32)
+    fx, fy, cx, cy = ds.intrinsics
+    want = MO.mark_untrained(np.zeros(32 ** 3, np.float32), 32, 6.0, T_CW, fx, fy, cx, cy, 2 * cx + 1, 2 * cy + 1, 0.0, 2)
+    assert ((grid < 0) != (want < 0)).mean() < 2e-3
+    model.update_extra_state()
+    bits = model.density_bitfield.cpu().numpy().view(np.uint32)
+    unpacked = ((bits[:, None] >> np.arange(32, dtype=np.uint32)[None]) & 1).astype(bool).reshape(-1)[:32 ** 3]
+    assert not unpacked[model.density_grid.cpu().numpy() < 0].any()
