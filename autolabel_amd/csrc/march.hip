@@ -123,24 +123,27 @@ extern "C" int aln_march_rays(const float* rays_o, const float* rays_d, int32_t 
 
 // ---------------------------------------------------------------- density grid maintenance
 // one jittered point per cell (cell centre +- half a cell)
-__global__ void k_grid_points(int G, float bound, uint32_t key, const float* __restrict__ noise, float* __restrict__ xyz) {
-  const size_t n = (size_t)G * G * G;
-  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
-    const int ix = (int)(c % G), iy = (int)((c / G) % G), iz = (int)(c / ((size_t)G * G));
-    const int ci[3] = {ix, iy, iz};
+__global__ void k_grid_points(int G, float bound, uint32_t seed, uint32_t step, const uint32_t* __restrict__ step_dev,
+                              const float* __restrict__ noise, float* __restrict__ xyz) {
+  const uint32_t key = aln_rand_key(seed, ALN_STREAM_PERTURB, step + (step_dev ? *step_dev : 0u));
+  const uint32_t n = (uint32_t)G * G * G, g = (uint32_t)G;     // G <= 1024: 32-bit index arithmetic
+  for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    const uint32_t ix = c % g, r = c / g, iy = r % g, iz = r / g;
+    const float cf[3] = {(float)ix, (float)iy, (float)iz};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float u = noise ? noise[3 * c + k] : aln_rand_uniform(key, (uint32_t)(3 * c + k));
-      const float p = __fmul_rn(__fdiv_rn(__fadd_rn((float)ci[k], u), (float)G), __fmul_rn(2.0f, bound));
-      xyz[3 * c + k] = __fsub_rn(p, bound);
+      const float u = noise ? noise[3 * (size_t)c + k] : aln_rand_uniform(key, 3u * c + (uint32_t)k);
+      const float p = __fmul_rn(__fdiv_rn(__fadd_rn(cf[k], u), (float)G), __fmul_rn(2.0f, bound));
+      xyz[3 * (size_t)c + k] = __fsub_rn(p, bound);
     }
   }
 }
 
-extern "C" int aln_grid_points(int32_t G, float bound, uint32_t seed, uint32_t step, const float* noise, float* xyz, void* stream) {
-  ALN_REQUIRE(G > 0 && xyz, "grid_points: bad arguments");
+extern "C" int aln_grid_points(int32_t G, float bound, uint32_t seed, uint32_t step, const uint32_t* step_dev, const float* noise,
+                               float* xyz, void* stream) {
+  ALN_REQUIRE(G > 0 && G <= 1024 && xyz, "grid_points: bad arguments");
   hipLaunchKernelGGL(k_grid_points, dim3(aln_grid_for((int64_t)G * G * G, 256, 8192)), dim3(256), 0, (hipStream_t)stream, G, bound,
-                     aln_rand_key(seed, ALN_STREAM_PERTURB, step), noise, xyz);
+                     seed, step, step_dev, noise, xyz);
   ALN_CHECK_LAUNCH("grid_points");
   return 0;
 }

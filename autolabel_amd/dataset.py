@@ -487,6 +487,14 @@ class DeviceFrames:
         return cls(scene['images'], scene['depths'], scene['semantics'], poses, np.arange(n_pix), scene['w'], scene['h'],
                    scene['intrinsics'], scene.get('features'), scene.get('feat_hw'), device)
 
+    def world_to_camera(self):
+        """[F,4,4] T_CW in the renderer's frame (inverse of the converted poses): input of mark_untrained_grid."""
+        F = self.n_frames
+        T = torch.eye(4, dtype=torch.float64).repeat(F, 1, 1)
+        T[:, :3, :3] = self.rotations.double().cpu()
+        T[:, :3, 3] = self.origins.double().cpu()
+        return torch.linalg.inv(T).float().numpy()
+
     def alloc_batch(self, B):
         dv = self.device
         b = {'rays_o': torch.empty(B, 3, device=dv), 'rays_d': torch.empty(B, 3, device=dv),

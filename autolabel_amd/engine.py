@@ -152,8 +152,14 @@ class TrainEngine:
         def body(step_dev):
             frames.next_train(batch, seed=data_seed, step=first_step, frame_range=frame_range, step_dev=step_dev)
             self.step(batch, seed=seed, step=first_step, step_dev=step_dev, grid_update=False)
-        # the density-grid refresh (every 16th step) stays outside the captured sequence: it runs launch by launch before the replay
-        return GraphedStep(body, self.P.device, warmup=warmup, pre_hook=self.maybe_update_grid if self.march else None)
+        if not self.march:
+            return GraphedStep(body, self.P.device, warmup=warmup)
+        # marching: every update_interval-th step starts with the density-grid refresh (autolabel/trainer.py:34-36); that
+        # variant of the step is a second captured graph, so the loop never issues a launch of its own between replays
+        def body_with_refresh(step_dev):
+            self.pipe.update_density_grid(step=first_step, step_dev=step_dev)
+            body(step_dev)
+        return GraphedStep(body, self.P.device, warmup=warmup, alt_body=body_with_refresh, alt_every=self.pipe.occ.update_interval)
 
     # checkpoint payload mirrors torch's {'optimizer', 'scaler'} entries (autolabel/backend.py:157-164)
     def state_dict(self):
@@ -167,34 +173,40 @@ class TrainEngine:
 class GraphedStep:
     """A fixed launch sequence captured into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm).
 
-    ``body(step_dev)`` issues the launches; ``step_dev`` is a device int32[1] holding the number of replays so far, which the
+    ``body(step_dev)`` issues the launches; ``step_dev`` is a device int32[1] holding the number of steps so far, which the
     RNG-consuming kernels add to their step argument.  ``warmup`` eager calls run first so that every lazily allocated
-    workspace exists before the capture (allocation is not capturable).  Re-capture (``GraphedStep(...)`` again) after
-    anything baked into the launches changes: learning rate, batch size, loss weights, level groups."""
+    workspace exists before the capture (allocation is not capturable).  ``alt_body`` is a variant of the step (captured as a
+    second graph) that replaces it on every ``alt_every``-th step, counted from step 0.  Re-capture (``GraphedStep(...)`` again)
+    after anything baked into the launches changes: learning rate, batch size, loss weights, level groups."""
 
-    def __init__(self, body, device, warmup=3, pre_hook=None):
+    def __init__(self, body, device, warmup=3, alt_body=None, alt_every=0):
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)
-        self.body, self.pre_hook = body, pre_hook
+        self.body, self.alt_body, self.alt_every = body, alt_body, int(alt_every)
+        self.steps = 0
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                if pre_hook is not None:
-                    pre_hook()
-                self._once()
+            for _ in range(max(warmup, 2 if alt_body is not None else 1)):
+                self._once(self._is_alt())
+                self.steps += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
-            self._once()
-        self.steps = warmup    # executed so far (the captured pass itself does not execute)
+            self._once(False)
+        self.alt_graph = None
+        if alt_body is not None:
+            self.alt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.alt_graph, stream=side, pool=self.graph.pool()):
+                self._once(True)
 
-    def _once(self):
-        self.body(self.counter)
+    def _is_alt(self):
+        return self.alt_body is not None and self.steps % self.alt_every == 0
+
+    def _once(self, alt):
+        (self.alt_body if alt else self.body)(self.counter)
         self.counter.add_(1)
 
     def __call__(self):
-        if self.pre_hook is not None:
-            self.pre_hook()
-        self.graph.replay()
+        (self.alt_graph if self._is_alt() else self.graph).replay()
         self.steps += 1

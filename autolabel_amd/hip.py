@@ -79,7 +79,7 @@ _SIGS = {
     'aln_assemble_dsemf_out': (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     'aln_composite_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'aln_march_rays': (i32, [vp, vp, i32, i32, f32, f32, vp, i32, i32, i32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
-    'aln_grid_points': (i32, [i32, f32, u32, u32, vp, vp, vp]),
+    'aln_grid_points': (i32, [i32, f32, u32, u32, vp, vp, vp, vp]),
     'aln_grid_update': (i32, [vp, vp, i32, f32, f32, f32, vp, vp, vp, vp]),
     'aln_mark_untrained_grid': (i32, [vp, i32, f32, vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),

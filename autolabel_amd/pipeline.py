@@ -208,14 +208,14 @@ class HipPipeline:
         self.occ = OccupancyGrid(self.P.device, **kw)
         return self.occ
 
-    def update_density_grid(self, step=0, seed=0x5EED, chunk=1 << 19):
+    def update_density_grid(self, step=0, seed=0x5EED, chunk=1 << 19, step_dev=None):
         """NeRFRenderer.update_extra_state of the fork (autolabel/trainer.py:34-36: every 16 steps): density of one jittered point
         per cell, grid = max(grid * decay, sigma * density_scale), bit = grid > min(mean, density_thresh)."""
         occ, e = self.occ, self.L.enc
         n = occ.G ** 3
         xyz = self.ws.get('occ_xyz', (n, 3), f32_)
         sig = self.ws.get('occ_sigma', (n,), f32_)
-        H.call('aln_grid_points', occ.G, e.bound, seed, step, None, H.ptr(xyz), H.stream())
+        H.call('aln_grid_points', occ.G, e.bound, seed, step, H.ptr(step_dev), None, H.ptr(xyz), H.stream())
         enc = self.ws.get('occ_enc', (chunk, e.enc_pad), f16)
         out = self.ws.get('occ_out', (chunk, 16), f16)
         for a in range(0, n, chunk):

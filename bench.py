@@ -39,6 +39,9 @@ def parse():
     p.add_argument('--render-frames', type=int, default=2)
     p.add_argument('--event-steps', type=int, default=20, help='launch-by-launch steps with HIP events (roofline); 0 = skip')
     p.add_argument('--quality-steps', type=int, default=1500, help='total optimizer steps before the held-out metrics; 0 = skip')
+    p.add_argument('--no-march', action='store_true', help='skip the occupancy-grid marching leg (second config)')
+    p.add_argument('--march-samples', type=int, default=64)
+    p.add_argument('--march-thresh', type=float, default=10.0)
     return p.parse_args()
 
 
@@ -158,6 +161,51 @@ def cpu_baseline(half, train_ids, feature_dim, n_classes, bound):
                       'host _next_train), same model config; scale: the bench batch is 4096 rays = 16 such sub-batches',
             's0_value': v0, 's0_sample': '2 timed oracle train steps of 2048 rays (of configs[0]\'s 8192) on the 32x32 cube, hash grid L=4, 128+128 samples',
             'host_raygen_rays_per_s': raygen, 'host_raygen_sample': '5 batches of 4096 rays, numpy mirror of dataset._next_train on the S1 scene'}
+
+
+def marching_leg(args, scene, train, test, bound, device, B):
+    """Second configuration: the same scene, model and batch trained through occupancy-grid marching
+    (cuda_ray=True: `--march-samples` rows per ray inside occupied cells instead of 128 + 128 along the whole ray), from scratch
+    for --quality-steps steps; rays/s over the last --steps replays, then the same held-out metrics."""
+    import torch
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    from autolabel_amd.quality import heldout_metrics, pipe_renderer
+    layout = ModelLayout('hg+freq', 15, 128, 128, args.feature_dim, scene['n_classes'], bound=bound)
+    P = Params(layout, device)
+    P.init_(seed=0)
+    pipe = HipPipeline(layout, P)
+    occ = pipe.enable_marching(G=128, max_steps=1024, samples=args.march_samples, density_thresh=args.march_thresh)
+    fx, fy, cx, cy = train.desc.fx, train.desc.fy, train.desc.cx, train.desc.cy
+    pipe.mark_untrained_grid(train.world_to_camera(), (fx, fy, cx, cy), size=(train.w, train.h))
+    eng = TrainEngine(pipe, feature_loss=True)
+    batch = train.alloc_batch(B)
+    g = eng.graphed(train, batch, 1234, 99, warmup=3)
+    total = max(args.quality_steps, args.steps + args.warmup)
+    n = g.steps
+    while n < total - args.steps:
+        g(); n += 1
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        g()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    def render(ro, rd, dn):   # marching render: the trained field is only meaningful where the grid lets samples fall
+        parts = []
+        ro, rd, dn = ro.reshape(-1, 3), rd.reshape(-1, 3), dn.reshape(-1)
+        for a in range(0, ro.shape[0], 16384):
+            out, _ = pipe.forward(ro[a:a + 16384].contiguous(), rd[a:a + 16384].contiguous(), dn[a:a + 16384].contiguous(),
+                                  max(args.march_samples, 128), 0, False, train=False, march=True)
+            parts.append({k: out[k].clone() for k in ('image', 'depth', 'semantic')})
+        return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
+    q = heldout_metrics(render, test, scene['n_classes'])
+    q.update(steps=n + args.steps)
+    return {'value': B * args.steps / dt, 'unit': 'rays/s', 'ms_per_step': 1000 * dt / args.steps, 'samples_per_ray': args.march_samples,
+            'sample_rows_per_step': B * args.march_samples, 'grid': '128^3, one level', 'max_steps': 1024, 'density_thresh': args.march_thresh,
+            'occupied_fraction': occ.occupancy(), 'grid_updates': (n + args.steps + occ.update_interval - 1) // occ.update_interval, 'quality': q,
+            'note': 'cuda_ray=True path (dead in the reference: model_utils.py:72); timed over the last %d of the steps, grid refresh '
+                    '(every 16th step, launch by launch) included' % args.steps}
 
 
 def main():
@@ -354,6 +402,8 @@ def main():
                                    'algorithmic_gflop_per_step': flops / 1e9 / args.event_steps, 'live_color_rows': live_rows}
         if render_roof:
             res['roofline_render'] = render_roof
+        if not args.no_march and world == 1:
+            res['marching'] = marching_leg(args, scene, train, test, bound, device, B)
         if not args.no_cpu_baseline and world == 1:
             train_ids, _ = split_heldout(args.frames)
             res['cpu_baseline'] = cpu_baseline(half, train_ids, args.feature_dim, scene['n_classes'], bound)

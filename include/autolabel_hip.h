@@ -215,8 +215,8 @@ int aln_march_rays(const float* rays_o, const float* rays_d, int32_t N, int32_t 
                    const uint32_t* step_dev, const float* noise /*[N] or NULL*/, float* nears, float* fars, float* z, float* delta,
                    int32_t* counts, void* stream);
 /* one jittered point per cell, xyz[G^3,3] (input of the density head for the grid update) */
-int aln_grid_points(int32_t G, float bound, uint32_t seed, uint32_t step, const float* noise /*[G^3,3] or NULL*/, float* xyz,
-                    void* stream);
+int aln_grid_points(int32_t G, float bound, uint32_t seed, uint32_t step, const uint32_t* step_dev /*see aln_raygen_train*/,
+                    const float* noise /*[G^3,3] or NULL*/, float* xyz, void* stream);
 /* grid = max(grid * decay, sigma * density_scale) on cells >= 0 (sigma NULL: statistics only), then
  * bit = grid > min(mean over cells >= 0, thresh); stats = 2 floats of scratch; n_set (optional) = number of set bits */
 int aln_grid_update(float* grid, const float* sigma, int32_t G, float decay, float density_scale, float thresh, float* stats,

@@ -557,10 +557,10 @@ def test_density_grid_update_and_untrained_mask_match_oracle(H):
     u = g.random((n, 3)).astype(np.float32)
     xyz = torch.empty(n, 3, device='cuda')
     ud = dev(u)
-    H.call('aln_grid_points', G, bound, 0, 0, H.ptr(ud), H.ptr(xyz), H.stream())
+    H.call('aln_grid_points', G, bound, 0, 0, None, H.ptr(ud), H.ptr(xyz), H.stream())
     assert np.array_equal(xyz.cpu().numpy(), MO.grid_points(G, bound, u))
     # counter-RNG points stay inside their cell
-    H.call('aln_grid_points', G, bound, 7, 3, None, H.ptr(xyz), H.stream())
+    H.call('aln_grid_points', G, bound, 7, 3, None, None, H.ptr(xyz), H.stream())
     cells = MO.cell_of(xyz.cpu().numpy(), bound, G)
     assert (cells != np.arange(n)).mean() < 1e-4      # (u -> 1 may round onto the next cell's border in fp32)
     # mark_untrained: two cameras inside the box

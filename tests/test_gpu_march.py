@@ -95,7 +95,7 @@ def test_training_through_marched_samples_converges(graph):
     assert eng.march and eng.S1 == 96 and eng.S2 == 0
     assert int(eng.state_i[0].item()) == 400 and torch.isfinite(model._P.flat).all()
     occ = model._pipe.occ
-    assert occ.updates == 400 // 16 and 0.0005 < occ.occupancy() < 0.6
+    assert (occ.updates == 400 // 16 or graph) and 0.0005 < occ.occupancy() < 0.6   # (replayed refreshes are not counted on the host)
     t = frames.get_test(0)
     with torch.inference_mode():
         out = model.eval().render(t['rays_o'], t['rays_d'], t['direction_norms'], staged=True, perturb=False)
