@@ -49,7 +49,7 @@ __device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn
   uint32_t gi[3]; float fr[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float pos = __fadd_rn(__fmul_rn(xn[k], scale), 0.5f);
+    float pos = g.pos_fma ? __fmaf_rn(xn[k], scale, 0.5f) : __fadd_rn(__fmul_rn(xn[k], scale), 0.5f);
     float fl = floorf(pos);
     gi[k] = (uint32_t)(int)fl;
     fr[k] = __fsub_rn(pos, fl);
@@ -80,7 +80,7 @@ __device__ inline void grid_weights(const AlnGridDesc& g, int l, const float* xn
   float fr[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float pos = __fadd_rn(__fmul_rn(xn[k], scale), 0.5f);
+    float pos = g.pos_fma ? __fmaf_rn(xn[k], scale, 0.5f) : __fadd_rn(__fmul_rn(xn[k], scale), 0.5f);
     float fl = floorf(pos);
     base[k] = (uint32_t)(int)fl;
     fr[k] = __fsub_rn(pos, fl);

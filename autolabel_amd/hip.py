@@ -18,7 +18,7 @@ class AlnGridDesc(C.Structure):
     _fields_ = [('n_levels', i32), ('n_features', i32), ('log2_hashmap_size', i32), ('base_resolution', i32),
                 ('per_level_scale', f32), ('scale', f32 * ALN_MAX_LEVELS), ('res', u32 * ALN_MAX_LEVELS),
                 ('size', u32 * ALN_MAX_LEVELS), ('offset', u32 * ALN_MAX_LEVELS), ('dense', u32 * ALN_MAX_LEVELS),
-                ('n_entries', u32)]
+                ('n_entries', u32), ('pos_fma', i32)]
 
 
 class AlnEncDesc(C.Structure):
@@ -135,9 +135,10 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_grid_desc(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=2.0):
+def make_grid_desc(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=2.0, pos_fma=False):
     """tcnn GridEncoding level table (autolabel/models.py:38-48), evaluated in fp32 on the host."""
     g = AlnGridDesc(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale)
+    g.pos_fma = int(bool(pos_fma))
     offset = 0
     for l in range(n_levels):
         scale = np.float32(np.exp2(np.float32(l) * np.log2(np.float32(per_level_scale))) * np.float32(base_resolution)

@@ -66,12 +66,14 @@ class ALNetwork(NeRFRenderer):
         self.hidden_dim_semantic, self.semantic_classes = hidden_dim_semantic, semantic_classes
         self.encoding = encoding
         grid = None
+        self.tcnn_fma = bool(kwargs.pop('tcnn_fma', False)) if 'tcnn_fma' in kwargs else False
         if encoding == 'hg':
             # torch-ngp hashgrid: 16 levels, base 16 up to desired_resolution 2**18 * bound
             pls = float(2.0 ** (math.log2(2 ** 18 * bound / 16) / 15))
             grid = H.make_grid_desc(per_level_scale=pls)
         self._layout = ModelLayout(encoding, geo_feat_dim, hidden_dim, hidden_dim_color, hidden_dim_semantic, semantic_classes,
                                    num_layers=num_layers, num_layers_color=num_layers_color, bound=float(bound), grid=grid)
+        self.set_tcnn_fma(self.tcnn_fma)
         L = self._layout
         self.encoder, self.in_dim = self._get_encoder(encoding)
         nets = L.nets
@@ -85,6 +87,13 @@ class ALNetwork(NeRFRenderer):
         self._seed = 0
         self._shadow_version = None
         self.reset_parameters()
+
+    def set_tcnn_fma(self, on=True):
+        """Grid position as ONE fused multiply-add (what tcnn's kernel compiles `x * scale + 0.5` to) instead of this build's
+        two-rounding spec.  Fields trained by the reference were fitted through the fused form: model_utils.load_checkpoint
+        (reference=True) switches it on so their finest-level cells are hit exactly as during training."""
+        self.tcnn_fma = bool(on)
+        self._layout.enc.grid.pos_fma = int(self.tcnn_fma)
 
     def _get_encoder(self, encoding):
         if encoding == 'freq':

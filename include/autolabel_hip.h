@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 1
+#define ALN_ABI_VERSION 2
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -33,6 +33,8 @@ typedef struct {
   float scale[ALN_MAX_LEVELS];
   uint32_t res[ALN_MAX_LEVELS], size[ALN_MAX_LEVELS], offset[ALN_MAX_LEVELS], dense[ALN_MAX_LEVELS];
   uint32_t n_entries;
+  int32_t pos_fma; /* 0: pos = x * scale + 0.5 in two fp32 roundings (this build's reproducible spec); 1: one fused multiply-add,
+                      what tcnn's grid kernel compiles to -- for fields trained by the reference (checkpoint import) */
 } AlnGridDesc;
 
 /* input encoding: models.py:25-27 (freq), :51-59 (hg+freq), :142-143 (hg) */

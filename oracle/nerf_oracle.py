@@ -77,6 +77,7 @@ class GridSpec:
     log2_hashmap_size: int = 19
     base_resolution: int = 16
     per_level_scale: float = 2.0
+    pos_fma: bool = False    # True: pos = fma(x, scale, 0.5) (one rounding, what tcnn's kernel compiles to) instead of the unfused SPEC
 
     def levels(self):
         out, offset = [], 0
@@ -91,7 +92,7 @@ class GridSpec:
             size = min(size, 1 << self.log2_hashmap_size)
             # dense indexing is used while the running stride stays <= size
             dense = (res * res * res) <= size
-            out.append(dict(scale=float(scale), res=res, size=size, offset=offset, dense=dense))
+            out.append(dict(scale=float(scale), res=res, size=size, offset=offset, dense=dense, pos_fma=self.pos_fma))
             offset += size
         return out
 
@@ -117,7 +118,10 @@ def grid_corner_indices(xn: torch.Tensor, level: dict):
     Corner c uses +1 along dim d iff bit d of c is set; accumulation order c=0..7.
     """
     scale = torch.tensor(level['scale'], dtype=torch.float32)
-    pos = xn * scale + 0.5
+    if level.get('pos_fma'):   # x * scale (48 significant bits) + 0.5 is exact in fp64: one rounding to fp32 = the fused result
+        pos = (xn.double() * scale.double() + 0.5).float()
+    else:
+        pos = xn * scale + 0.5
     g = torch.floor(pos)
     frac = pos - g
     g = g.to(torch.int64)

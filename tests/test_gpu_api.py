@@ -397,3 +397,48 @@ def test_open_vocabulary_queries_follow_the_reference_recipe():
     feats = model.render(o.cuda(), d.cuda(), torch.ones(H_ * W_, 1, device='cuda'), staged=True, perturb=False, num_steps=64,
                          upsample_steps=32)['semantic_features']
     assert torch.equal(img, Q.similarity_argmax(feats, text.cuda()))
+
+
+def test_reference_checkpoint_import_and_fused_grid_position(tmp_path):
+    """a `checkpoints/*.pth` in the reference's format (tcnn flat `params`, fp16 copies, fork-only buffers) loads
+    through model_utils.load_checkpoint(reference=True); the grid position then follows tcnn's fused multiply-add and the
+    hash-grid features are bit-exact to the oracle evaluated the same way."""
+    import ctypes as C
+    from autolabel_amd import hip as H, model_utils
+    model = make_model(D=64, C_=5, bound=2.0, grid_scale=2e3)
+    own = model.state_dict()
+    ref_sd = {}
+    for k, v in own.items():
+        if k.endswith('.params'):
+            t = v.detach().cpu().clone()
+            ref_sd[k] = t.half() if 'grid' in k else t          # tcnn: the grid often travels as fp16
+        elif k in ('aabb_train', 'aabb_infer'):
+            ref_sd[k] = v.detach().cpu().clone()
+    ref_sd['density_grid'] = torch.zeros(1, 128 ** 3)            # fork-only buffers: ignored
+    ref_sd['step_counter'] = torch.zeros(16, 2, dtype=torch.int32)
+    os.makedirs(tmp_path / 'checkpoints')
+    torch.save({'model': ref_sd, 'epoch': 10}, tmp_path / 'checkpoints' / 'ngp_ep0010.pth')
+    m2 = make_model(D=64, C_=5, bound=2.0, grid_scale=1.0)
+    assert not m2.tcnn_fma
+    model_utils.load_checkpoint(m2, str(tmp_path / 'checkpoints'), reference=True)
+    assert m2.tcnn_fma and m2._layout.enc.grid.pos_fma == 1
+    a, b = m2.encoder.grid_encoding.params.detach().cpu(), own['encoder.grid_encoding.params'].cpu().half().float()
+    assert torch.equal(a, b) and torch.equal(m2.sigma_net.params.detach().cpu(), own['sigma_net.params'].cpu())
+    # a wrong head width is refused with both counts in the message
+    bad = dict(ref_sd); bad['semantic_out.params'] = torch.zeros(7)
+    with pytest.raises(ValueError, match='semantic_out.params'):
+        model_utils.import_reference_state_dict(make_model(D=64, C_=5, bound=2.0), bad)
+    # features: HIP (fma on) == oracle (pos_fma=True) bit for bit; with the switch off a few last-bit cases differ
+    oracle, cfg = oracle_of(m2)
+    cfg.grid = O.GridSpec(pos_fma=True)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(4000, 3, generator=g) * 2 - 1) * 2.0
+    want = O.OracleModel(cfg, params=oracle.params, half_sim=True).encode(x)[:, 12:].half()
+    pipe, e = m2._ensure_device(), m2._layout.enc
+    enc = torch.zeros(4000, e.enc_pad, dtype=torch.float16, device='cuda')
+    xd = x.cuda().contiguous()
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(pipe.P.table16), None, None, None, H.ptr(xd), 4000, 1, H.ptr(enc), H.stream())
+    assert torch.equal(enc.cpu()[:, 12:44], want)
+    m2.set_tcnn_fma(False)
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(pipe.P.table16), None, None, None, H.ptr(xd), 4000, 1, H.ptr(enc), H.stream())
+    assert not torch.equal(enc.cpu()[:, 12:44], want)

@@ -185,3 +185,26 @@ def test_rng_reference_values_are_stable():
     assert r.dtype == np.uint32 and len(set(r.tolist())) == 4
     u = O.rand_uniform(1234, 2, 7, np.arange(10000))
     assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
+
+
+def test_fused_grid_position_differs_only_where_the_two_roundings_do():
+    """GridSpec.pos_fma (tcnn's fused x * scale + 0.5): evaluated through fp64, where product and sum are exact, so the single
+    rounding is the fma result.  Known answer: x = 1/3 (0x3EAAAAAB), scale = 524287: unfused fl(fl(x*s) + 0.5) vs fused fl(x*s + 0.5)."""
+    x, s = np.float32(1.0 / 3.0), np.float32(524287.0)
+    unfused = np.float32(np.float32(x * s) + np.float32(0.5))
+    fused = np.float32(np.float64(x) * np.float64(s) + 0.5)
+    spec_u, spec_f = O.GridSpec(), O.GridSpec(pos_fma=True)
+    xn = torch.tensor([[float(x)] * 3], dtype=torch.float32)
+    for spec, want in ((spec_u, unfused), (spec_f, fused)):
+        lv = spec.levels()[15]
+        assert lv['scale'] == 524287.0
+        idx, w = O.grid_corner_indices(xn, lv)
+        frac = float(want - np.floor(want))
+        assert abs(float(w[0, 7]) - frac ** 3) < 1e-6       # corner (1,1,1) weight = frac^3
+    # on random points the two specs agree except for a small share of last-bit cases
+    g = torch.Generator().manual_seed(0)
+    xs = torch.rand(20000, 3, generator=g)
+    iu, wu = O.grid_corner_indices(xs, spec_u.levels()[15])
+    if_, wf = O.grid_corner_indices(xs, spec_f.levels()[15])
+    assert 0 < (wu != wf).any(dim=1).float().mean().item() < 0.9
+    assert (iu != if_).any(dim=1).float().mean().item() < 1e-3          # a different CELL only when pos rounds across an integer
