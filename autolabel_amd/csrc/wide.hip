@@ -1,0 +1,327 @@
+// Wide semantic heads (LSeg configuration: hidden_dim_semantic = 512, autolabel/models.py:117-136, docs/vision-language.md:19,
+// scripts/ros/node.py:166-176): semantic_features 16 -> 512 -> 512 -> 512 and semantic_out 528 -> 64 -> C as hand-written
+// MFMA GEMMs.  512 x 512 fp16 weights (512 KB per layer) do not fit the 160 KB LDS, so these heads cannot use the
+// register-chained kernels of mlp.hip (weights resident in LDS, activations in registers); here every layer is one launch
+// that streams the sample rows once, with the weight tiles re-read from L2 (1.1 MB for the whole head) and everything that
+// used to be a separate pass fused into the prologue / epilogue:
+//   * prologue: the layer input is built on the fly -- [geo_feat, 1] from the density head's output rows, relu(f) ++ [geo_feat, 1]
+//     for semantic_out (models.py:254: cat[relu(features), geo_feat]) -- no [rows, 528] operand is ever materialised;
+//   * epilogue: ReLU, ReLU' mask of the backward pass ((G W) * (act > 0)), accumulation into an existing gradient
+//     (d f = d f_composite + mask * (dH W)), fp16 overflow watch.
+// Two kernels:
+//   k_wide_nt : Y[M, N]  = epi( A[M, K] W[N, K]^T )          forward layers and the data gradients (with W^T copies)
+//   k_wide_tn : dW[N, K] += G[M, N]^T A[M, K]                weight gradients (contraction over the samples)
+// v_mfma_f32_32x32x16_f16 throughout; operand tiles staged in LDS; k_wide_tn reads them with ds_read_b64_tr_b16.
+#include "common.h"
+
+typedef __attribute__((address_space(3))) h16 lds_h16w;
+typedef short s16x4w __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4w* lds_s16x4w_ptr;
+
+__device__ inline f32x16 wmfma(h16x8 a, h16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// A-operand source: columns [0, K1) from a1 (optionally through ReLU), columns [K1, K1 + 16) = [geo_feat(1..15), 1] taken from
+// the density head's output rows (sigma_out: [h0, geo1 .. geo15]) when geo != NULL.
+struct WideSrc {
+  const h16* a1; int lda1, K1, relu1;
+  const h16* geo;   // sigma_out [M, 16] or NULL
+  int G;            // geo_feat_dim (columns G .. 15 of the geo block are 1-padding)
+};
+
+__device__ inline h16x8 wide_chunk(const WideSrc& s, size_t row, int k0, int K) {
+  h16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (h16)0.f;
+  if (k0 >= K) return v;
+  if (k0 < s.K1) {
+    v = *(const h16x8*)(s.a1 + row * (size_t)s.lda1 + k0);
+    if (s.relu1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] > (h16)0.f ? v[j] : (h16)0.f;
+    }
+    return v;
+  }
+  const int j0 = k0 - s.K1;   // 0 or 8 within the geo block
+  const h16* g = s.geo + row * 16;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = j0 + j;                 // column of [geo1 .. geoG, 1, 1, ...]
+    v[j] = c < s.G ? g[1 + c] : (h16)1.0f;
+  }
+  return v;
+}
+
+struct WideNT {
+  WideSrc a; int M, N, K;
+  const h16* w; int ldw;        // [N, ldw] row-major, K columns used
+  h16* y; int ldy;              // [M, ldy]
+  int relu;                     // epilogue ReLU
+  const h16* mask; int ldm;     // multiply by (mask[m][n] > 0) (ReLU' of the layer this gradient flows into) or NULL
+  const h16* add; int lda;      // + add[m][n] before the store or NULL
+  int* found_inf;               // raised when an output is not finite in fp16
+};
+
+#define WNT_BM 128
+#define WNT_BK 32
+#define WNT_PITCH (WNT_BK + 8)   // 80-byte rows: the 16-byte fragment reads of 16 consecutive rows fall into distinct 16-byte bank groups
+
+template <int BN>
+__global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
+  __shared__ __attribute__((aligned(16))) h16 Xs[WNT_BM * WNT_PITCH];
+  __shared__ __attribute__((aligned(16))) h16 Ws[BN * WNT_PITCH];
+  constexpr int NB = BN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
+  const int m0 = blockIdx.x * WNT_BM, n0 = blockIdx.y * BN;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  const int nkt = (p.K + WNT_BK - 1) / WNT_BK;
+  // global -> register staging of one k-tile: X: 128 rows x 4 chunks = 512 chunks (2 per thread); W: BN x 4 chunks
+  h16x8 xr[2], wr[(BN * 4 + 255) / 256];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 2, k0 = kt * WNT_BK + (ch & 3) * 8;
+      const int m = m0 + r;
+      if (m < p.M) xr[i] = wide_chunk(p.a, (size_t)m, k0, p.K);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[i][j] = (h16)0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (BN * 4 + 255) / 256; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 2, k0 = kt * WNT_BK + (ch & 3) * 8;
+      h16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (h16)0.f;
+      if (ch < BN * 4 && n0 + r < p.N && k0 < p.K) v = *(const h16x8*)(p.w + (size_t)(n0 + r) * p.ldw + k0);
+      wr[i] = v;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Xs + (ch >> 2) * WNT_PITCH + (ch & 3) * 8) = xr[i]; }
+#pragma unroll
+    for (int i = 0; i < (BN * 4 + 255) / 256; ++i) {
+      const int ch = tid + 256 * i;
+      if (ch < BN * 4) *(h16x8*)(Ws + (ch >> 2) * WNT_PITCH + (ch & 3) * 8) = wr[i];
+    }
+  };
+  fetch(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();            // the previous tile has been consumed
+    stash();
+    __syncthreads();
+    if (kt + 1 < nkt) fetch(kt + 1);   // in flight while this tile is multiplied
+#pragma unroll
+    for (int ks = 0; ks < WNT_BK / 16; ++ks) {
+      // B operand = this wave's 32 sample rows, A operand = 32 weight rows (output columns): lane owns sample row c
+      const h16x8 xb = *(const h16x8*)(Xs + (wave * 32 + c) * WNT_PITCH + ks * 16 + hf * 8);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const h16x8 wa = *(const h16x8*)(Ws + (b * 32 + c) * WNT_PITCH + ks * 16 + hf * 8);
+        acc[b] = wmfma(wa, xb, acc[b]);
+      }
+    }
+  }
+  // epilogue: lane holds sample row m = m0 + wave * 32 + c; register r of block b is output column 32 b + 8 (r / 4) + 4 hf + r % 4
+  const int m = m0 + wave * 32 + c;
+  bool bad = false;
+  if (m < p.M) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = n0 + b * 32 + rg * 8 + hf * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[b][rg * 4 + j];
+        if (p.mask) {
+          const h16x4 mk = *(const h16x4*)(p.mask + (size_t)m * p.ldm + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = mk[j] > (h16)0.f ? v[j] : 0.f;
+        }
+        if (p.add) {
+          const h16x4 ad = *(const h16x4*)(p.add + (size_t)m * p.lda + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)ad[j];
+        }
+        h16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.relu) v[j] = fmaxf(v[j], 0.f);
+          o[j] = (h16)v[j];
+          bad |= !(fabsf(v[j]) <= 65504.f);
+        }
+        *(h16x4*)(p.y + (size_t)m * p.ldy + n) = o;
+      }
+    }
+  }
+  if (bad && p.found_inf) *p.found_inf = 1;
+}
+
+extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo, int32_t G, int32_t M, int32_t N,
+                           const void* w, int32_t ldw, void* y, int32_t ldy, int32_t relu, const void* mask, int32_t ldm,
+                           const void* add, int32_t lda, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(w && y && (a1 || geo) && M >= 0 && N > 0, "wide_nt: bad arguments");
+  ALN_REQUIRE(K1 % 8 == 0 && N % 4 == 0 && ldw % 8 == 0 && (!a1 || lda1 % 8 == 0) && ldy % 4 == 0, "wide_nt: K1 / N / leading dimensions must be multiples of 8 / 4");
+  ALN_REQUIRE((!mask || ldm % 4 == 0) && (!add || lda % 4 == 0), "wide_nt: mask / addend leading dimensions must be multiples of 4");
+  if (M == 0) return 0;
+  WideNT p;
+  p.a = WideSrc{(const h16*)a1, lda1, a1 ? K1 : 0, relu1, (const h16*)geo, G};
+  p.M = M; p.N = N; p.K = p.a.K1 + (geo ? 16 : 0);
+  p.w = (const h16*)w; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = relu;
+  p.mask = (const h16*)mask; p.ldm = ldm; p.add = (const h16*)add; p.lda = lda; p.found_inf = found_inf;
+  ALN_REQUIRE(ldw >= p.K, "wide_nt: weight rows shorter than K");
+  const int gm = (M + WNT_BM - 1) / WNT_BM;
+  hipStream_t s = (hipStream_t)stream;
+  if (N > 64) hipLaunchKernelGGL(k_wide_nt<128>, dim3(gm, (N + 127) / 128), dim3(256), 0, s, p);
+  else if (N > 32) hipLaunchKernelGGL(k_wide_nt<64>, dim3(gm, 1), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(k_wide_nt<32>, dim3(gm, 1), dim3(256), 0, s, p);
+  ALN_CHECK_LAUNCH("wide_nt");
+  return 0;
+}
+
+// ---------------------------------------------------------------- weight gradients
+struct WideTN {
+  WideSrc a; int M, N, K;
+  const h16* g; int ldg;     // [M, ldg], N columns used
+  float* dw; int lddw;       // [N, lddw] fp32, accumulated with atomics
+  int slab;                  // sample rows per block
+};
+
+#define WTN_BM 64            // sample rows per LDS tile
+#define WTN_T 128            // tile edge in n and k
+#define WTN_PITCH 152        // halves (304 B: rows stay 16-byte aligned for the staging stores)
+
+struct WTile {
+  lds_h16w* p;
+  __device__ inline lds_h16w* at(int row, int col) const { return p + row * WTN_PITCH + col; }
+};
+__device__ inline h16x8 wtr_frag(WTile t, int col0, int ks, int lane) {
+  // operand fragment for mfma 32x32x16: lane (i = lane & 31, hf = lane >> 5) gets tile[16 ks + 8 hf + 0..7][col0 + i]
+  const int hf = lane >> 5;
+  const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w_ptr)t.at(row, col));
+  s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w_ptr)t.at(row + 4, col));
+  union { struct { s16x4w l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
+  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PITCH];
+  __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * WTN_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
+  const int n0 = blockIdx.x * WTN_T, k0 = blockIdx.y * WTN_T;
+  const int mlo = blockIdx.z * p.slab, mhi = min(p.M, mlo + p.slab);
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;   // wave tile 64 (n) x 64 (k)
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const WTile tG{(lds_h16w*)Gs}, tA{(lds_h16w*)As};
+  // 64 rows x 16 chunks of 8 halves per tile = 1024 chunks: 4 per thread and tile
+  h16x8 gr[4], ar[4];
+  auto fetch = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
+      const int m = mt + r;
+      h16x8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
+      gr[i] = z; ar[i] = z;
+      if (m < mhi) {
+        if (n0 + cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)m * p.ldg + n0 + cc);
+        ar[i] = wide_chunk(p.a, (size_t)m, k0 + cc, p.K);
+      }
+    }
+  };
+  fetch(mlo);
+  for (int mt = mlo; mt < mhi; mt += WTN_BM) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
+      *(h16x8*)(Gs + r * WTN_PITCH + cc) = gr[i];
+      *(h16x8*)(As + r * WTN_PITCH + cc) = ar[i];
+    }
+    __syncthreads();
+    if (mt + WTN_BM < mhi) fetch(mt + WTN_BM);
+#pragma unroll
+    for (int ks = 0; ks < WTN_BM / 16; ++ks) {
+      h16x8 ga[2], ab[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ga[i] = wtr_frag(tG, wn + 32 * i, ks, lane); ab[i] = wtr_frag(tA, wk + 32 * i, ks, lane); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = wmfma(ga[i], ab[j], acc[i][j]);
+    }
+  }
+  // lane holds column k = k0 + wk + 32 j + c; register r of block (i, j) is row n = n0 + wn + 32 i + 8 (r / 4) + 4 hf + r % 4
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk + 32 * j + c;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn + 32 * i + 8 * (r >> 2) + 4 * hf + (r & 3);
+        if (n < p.N && acc[i][j][r] != 0.f) unsafeAtomicAdd(p.dw + (size_t)n * p.lddw + k, acc[i][j][r]);
+      }
+    }
+}
+
+extern "C" int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo,
+                           int32_t G, int32_t M, int32_t N, float* dw, int32_t lddw, void* stream) {
+  ALN_REQUIRE(g && dw && (a1 || geo) && M >= 0 && N > 0, "wide_tn: bad arguments");
+  ALN_REQUIRE(ldg % 8 == 0 && N % 8 == 0 && K1 % 8 == 0 && (!a1 || lda1 % 8 == 0), "wide_tn: N / K1 / leading dimensions must be multiples of 8");
+  if (M == 0) return 0;
+  WideTN p;
+  p.a = WideSrc{(const h16*)a1, lda1, a1 ? K1 : 0, relu1, (const h16*)geo, G};
+  p.M = M; p.N = N; p.K = p.a.K1 + (geo ? 16 : 0);
+  p.g = (const h16*)g; p.ldg = ldg; p.dw = dw; p.lddw = lddw;
+  ALN_REQUIRE(lddw >= p.K, "wide_tn: gradient rows shorter than K");
+  const int tn = (N + WTN_T - 1) / WTN_T, tk = (p.K + WTN_T - 1) / WTN_T;
+  // enough slabs to fill the chip (>= ~1024 blocks), each a multiple of the 64-row tile
+  int slabs = (1024 + tn * tk - 1) / (tn * tk);
+  int slab = ((M + slabs - 1) / slabs + WTN_BM - 1) / WTN_BM * WTN_BM;
+  if (slab < WTN_BM) slab = WTN_BM;
+  slabs = (M + slab - 1) / slab;
+  p.slab = slab;
+  hipLaunchKernelGGL(k_wide_tn, dim3(tn, tk, slabs), dim3(256), 0, (hipStream_t)stream, p);
+  ALN_CHECK_LAUNCH("wide_tn");
+  return 0;
+}
+
+// row-major transpose of an fp16 matrix [R, C] -> [C, R] (W^T copies for the data gradients; weights only: tiny)
+__global__ void k_transpose_h16(const h16* __restrict__ src, int R, int C, h16* __restrict__ dst) {
+  __shared__ h16 t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = by + j, cidx = bx + threadIdx.x;
+    t[j][threadIdx.x] = (r < R && cidx < C) ? src[(size_t)r * C + cidx] : (h16)0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int cidx = bx + j, r = by + threadIdx.x;
+    if (cidx < C && r < R) dst[(size_t)cidx * R + r] = t[threadIdx.x][j];
+  }
+}
+extern "C" int aln_transpose_f16(const void* src, int32_t R, int32_t C, void* dst, void* stream) {
+  ALN_REQUIRE(src && dst && R > 0 && C > 0, "transpose_f16: bad arguments");
+  hipLaunchKernelGGL(k_transpose_h16, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, (const h16*)src, R, C, (h16*)dst);
+  ALN_CHECK_LAUNCH("transpose_f16");
+  return 0;
+}

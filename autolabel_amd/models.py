@@ -229,6 +229,9 @@ class ALNetwork(NeRFRenderer):
         so = torch.zeros(n, 16, dtype=f16, device=dev)
         so[:, 1:1 + L.G] = geo_features.to(f16)
         fs, os_ = L.nets['semf'], L.nets['semo']
+        if L.sem_wide and not L.sem_lib:     # LSeg-width heads: wide.hip GEMMs, inputs built inside the kernels
+            logits, feat, _ = pipe.wide_sem_fwd(so, n, lambda name, shp: torch.empty(shp, dtype=f16, device=dev))
+            return logits[:, :L.C], feat[:, :L.D]
         fin = torch.empty(n, fs.in_pad, dtype=f16, device=dev)
         feat = torch.empty(n, fs.out_pad, dtype=f16, device=dev)
         oin = torch.empty(n, os_.in_pad, dtype=f16, device=dev)

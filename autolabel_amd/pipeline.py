@@ -31,10 +31,11 @@ class MlpSpec:
         self.n_params = sum(o * i for o, i in self.shapes)
         if n_hidden not in (1, 2):
             raise NotImplementedError(f'{name}: n_hidden={n_hidden} is not supported (1-2 hidden layers)')
-        # Heads too wide for the register-chained MFMA kernels (LSeg: D=512 -> semf 16->512->512->512, semo 528->64->C;
-        # or hundreds of classes) run as plain library GEMMs (hipBLASLt through torch.mm): they are ordinary large
-        # dense layers (512x512 weights do not fit LDS), exactly the case the design rules reserve for the library.
-        self.lib = hidden not in (64, 128) or self.in_pad > 96 or self.out_pad > 64
+        # Heads too wide for the register-chained MFMA kernels of mlp.hip (weights resident in LDS) -- LSeg: D=512 -> semf
+        # 16->512->512->512, semo 528->64->C; or hundreds of classes -- run layer by layer on the hand-written MFMA GEMMs of
+        # wide.hip (weights streamed from L2, inputs / ReLU / masks / accumulation fused into prologue and epilogue).
+        self.wide = hidden not in (64, 128) or self.in_pad > 96 or self.out_pad > 64
+        self.lib = False   # (round 1 sent these heads to hipBLASLt through torch.mm; ALN_WIDE=lib keeps that path for A/B timing)
 
 
 class ModelLayout:
@@ -59,6 +60,10 @@ class ModelLayout:
             o += s.n_params
         self.n_total = o
         self.Cpad = self.nets['semo'].out_pad
+        self.sem_wide = self.nets['semf'].wide or self.nets['semo'].wide    # then BOTH semantic heads take the wide path
+        self.sem_lib = self.sem_wide and os.environ.get('ALN_WIDE') == 'lib'
+        if self.sem_lib:
+            self.nets['semf'].lib = self.nets['semo'].lib = True
 
 
 class Params:
@@ -70,10 +75,11 @@ class Params:
         self.flat = torch.zeros(L.n_total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(L.n_total + 8, dtype=torch.float32, device=device)  # +8: side channel for DP (found_inf)
         self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
-        self.frags, self.descs, self.lib_w = {}, {}, {}
+        self.frags, self.descs, self.lib_w, self.wide_wt = {}, {}, {}, {}
         for k, s in L.nets.items():
-            if s.lib:
+            if s.lib or (L.sem_wide and k in ('semf', 'semo')):   # row-major fp16 [out, in] per layer (+ transposes for the data gradients)
                 self.lib_w[k] = [torch.zeros(o, i, dtype=torch.float16, device=device) for o, i in s.shapes]
+                self.wide_wt[k] = [torch.zeros(i, o, dtype=torch.float16, device=device) for o, i in s.shapes]
                 continue
             nf = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 0)
             nb = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 1)
@@ -114,10 +120,11 @@ class Params:
             H.call('aln_cast_f16', H.ptr(self.flat), H.ptr(self.table16), L.n_grid, H.stream())
         fused = []
         for k, s in L.nets.items():
-            if s.lib:
+            if k in self.lib_w:
                 o = L.offsets[k]
-                for w in self.lib_w[k]:
+                for w, wt in zip(self.lib_w[k], self.wide_wt[k]):
                     w.copy_(self.flat[o:o + w.numel()].view_as(w))
+                    H.call('aln_transpose_f16', H.ptr(w), w.shape[0], w.shape[1], H.ptr(wt), H.stream())
                     o += w.numel()
             else:
                 fused.append(k)
@@ -186,8 +193,8 @@ class HipPipeline:
         self.phased_min_rows = 1 << 16   # hash-grid forward: level-phased from this many sample rows on
         # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
-        self.recompute = all(s.lib or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
-                             for s in layout.nets.values())
+        self.recompute = all(k in params.lib_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
+                             for k, s in layout.nets.items())
         # hash-grid backward: binned two-pass scatter by default; ALN_ENC_BWD=atomic selects the fp32-atomic kernel
         self.binned_bwd = os.environ.get('ALN_ENC_BWD', 'binned') != 'atomic'
         self.occ = None     # OccupancyGrid: forward(..., march=True) then places the samples by marching (enable_marching)
@@ -251,6 +258,64 @@ class HipPipeline:
         nl, nt = int(self.L.enc.grid.n_levels), (M + 511) // 512
         desc = t[1][nl * nt * 4096 * 8:nl * nt * 4096 * 8 + nl * 64 * nt * 4].view(torch.int32)
         return int(((desc >> 13) & 0x1FFF).sum().item())
+
+    # ---- wide semantic heads on the hand-written MFMA GEMMs of wide.hip (models.py:248-256 at LSeg width)
+    def _nt(self, M, N, w, y, a1=None, K1=0, relu1=0, geo=None, relu=0, mask=None, add=None, watch=False, tag=None):
+        self._k('aln_wide_nt', H.ptr(a1), a1.shape[1] if a1 is not None else 0, K1, relu1, H.ptr(geo), self.L.G, M, N, H.ptr(w), w.shape[1],
+                H.ptr(y), y.shape[1], relu, H.ptr(mask), mask.shape[1] if mask is not None else 0, H.ptr(add),
+                add.shape[1] if add is not None else 0, H.ptr(self.found_inf) if watch else None, H.stream(),
+                tag=('wide', M, N * (K1 + (16 if geo is not None else 0))))
+
+    def _tn(self, M, N, g, dw_off, ldw, a1=None, K1=0, relu1=0, geo=None, tag=None):
+        self._k('aln_wide_tn', H.ptr(g), g.shape[1], H.ptr(a1), a1.shape[1] if a1 is not None else 0, K1, relu1, H.ptr(geo), self.L.G, M, N,
+                C.c_void_p(self.P.grad.data_ptr() + 4 * dw_off), ldw, H.stream(), tag=('wide', M, N * (K1 + (16 if geo is not None else 0))))
+
+    def wide_sem_fwd(self, sout, M, bufs):
+        """f = semantic_features([geo, 1]); logits = semantic_out([relu(f), geo, 1]) for M rows of the density head's output.
+        bufs: callable name, shape -> fp16 buffer.  Returns (logits [M, Cpad], f [M, D], saved activations)."""
+        L = self.L
+        fs, os_ = L.nets['semf'], L.nets['semo']
+        Wf, Wo = self.P.lib_w['semf'], self.P.lib_w['semo']
+        fl = ('sem', M)
+        h1, h2 = bufs('wide_h1', (M, fs.hidden)), bufs('wide_h2', (M, fs.hidden))
+        feat, ho = bufs('feat', (M, fs.out_pad)), bufs('wide_ho', (M, os_.hidden))
+        logits = bufs('logits', (M, os_.out_pad))
+        self._nt(M, fs.hidden, Wf[0], h1, geo=sout, relu=1, tag=fl)
+        self._nt(M, fs.hidden, Wf[1], h2, a1=h1, K1=fs.hidden, relu=1, tag=fl)
+        self._nt(M, fs.out_pad, Wf[2], feat, a1=h2, K1=fs.hidden, tag=fl)
+        self._nt(M, os_.hidden, Wo[0], ho, a1=feat, K1=L.D, relu1=1, geo=sout, relu=1, tag=fl)
+        self._nt(M, os_.out_pad, Wo[1], logits, a1=ho, K1=os_.hidden, tag=fl)
+        return logits, feat, (h1, h2, ho)
+
+    def wide_sem_bwd(self, sout, M, feat, saved, d_logits, d_feat, bufs):
+        """Backward of wide_sem_fwd: weight gradients into P.grad, returns (d semf_in [M,16], d geo-part of semo_in [M,16]).
+        d_feat is updated in place with the gradient arriving through relu(f) -> semantic_out."""
+        L = self.L
+        fs, os_ = L.nets['semf'], L.nets['semo']
+        Wft, Wot = self.P.wide_wt['semf'], self.P.wide_wt['semo']
+        h1, h2, ho = saved
+        bl = ('sem', M)
+        of, oo = L.offsets['semf'], L.offsets['semo']
+        sf, so = fs.shapes, os_.shapes
+        # ---- semantic_out: logits = W2 relu(W1 [relu f, geo, 1])
+        dho = bufs('wide_dho', (M, os_.hidden))
+        self._nt(M, os_.hidden, Wot[1], dho, a1=d_logits, K1=os_.out_pad, mask=ho, watch=True, tag=bl)
+        self._tn(M, os_.out_pad, d_logits, oo + so[0][0] * so[0][1], os_.hidden, a1=ho, K1=os_.hidden, tag=bl)
+        self._tn(M, os_.hidden, dho, oo, os_.in_pad, a1=feat, K1=L.D, relu1=1, geo=sout, tag=bl)
+        d_ogeo = bufs('wide_d_ogeo', (M, 16))
+        self._nt(M, L.D, Wot[0][:L.D], d_feat, a1=dho, K1=os_.hidden, mask=feat, add=d_feat, watch=True, tag=bl)
+        self._nt(M, 16, Wot[0][L.D:L.D + 16], d_ogeo, a1=dho, K1=os_.hidden, watch=True, tag=bl)
+        # ---- semantic_features: f = W3 relu(W2 relu(W1 [geo, 1]))
+        dh2, dh1 = bufs('wide_dh2', (M, fs.hidden)), bufs('wide_dh1', (M, fs.hidden))
+        n0, n1 = sf[0][0] * sf[0][1], sf[1][0] * sf[1][1]
+        self._nt(M, fs.hidden, Wft[2], dh2, a1=d_feat, K1=fs.out_pad, mask=h2, watch=True, tag=bl)
+        self._tn(M, fs.out_pad, d_feat, of + n0 + n1, fs.hidden, a1=h2, K1=fs.hidden, tag=bl)
+        self._nt(M, fs.hidden, Wft[1], dh1, a1=dh2, K1=fs.hidden, mask=h1, watch=True, tag=bl)
+        self._tn(M, fs.hidden, dh2, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=bl)
+        d_fin = bufs('d_semf_in', (M, fs.in_pad))
+        self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=bl)
+        self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=sout, tag=bl)
+        return d_fin, d_ogeo
 
     # ---- library-GEMM heads (MlpSpec.lib): y = relu(x W0^T) ... ; fp16 operands, fp32 accumulate (hipBLASLt)
     def _lib_fwd(self, k, x, save):
@@ -380,8 +445,12 @@ class HipPipeline:
         logits = feat = None
         if want_semantic:
             fs, os_ = nets['semf'], nets['semo']
-            c['sem_fused'] = self.recompute and not fs.lib and not os_.lib
-            if c['sem_fused']:  # inputs are built inside the kernels from sigma_out / f (no semf_in / semo_in tensors)
+            c['sem_fused'] = self.recompute and not L.sem_wide
+            c['sem_wide'] = L.sem_wide and not L.sem_lib
+            if c['sem_wide']:
+                logits, feat, c['wide_saved'] = self.wide_sem_fwd(sout, M, lambda n, shp: g(n, shp, f16))
+                c['feat'], c['logits'] = feat, logits
+            elif c['sem_fused']:  # inputs are built inside the kernels from sigma_out / f (no semf_in / semo_in tensors)
                 feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
                 logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
                 self._k('aln_sem_heads_fwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sout), M, L.D, L.G,
@@ -458,6 +527,8 @@ class HipPipeline:
             self._k('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),
                     H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_oin), H.ptr(d_fin),
                     gp('semf'), gp('semo'), fi, H.stream(), tag=('sem', M))
+        elif sem and c.get('sem_wide'):
+            d_fin, d_oin = self.wide_sem_bwd(c['sigma_out'], M, c['feat'], c['wide_saved'], d_logits, d_feat, lambda n, shp: g(n, shp, f16))
         elif sem:
             fs, os_ = nets['semf'], nets['semo']
             if os_.lib:
@@ -474,8 +545,9 @@ class HipPipeline:
                 H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
                        None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
         d_sout = g('d_sigma_out', (M, 16), f16)
-        H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), nets['semo'].in_pad, L.D,
-               H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
+        wide = sem and c.get('sem_wide')   # the wide path hands over the 16 geo columns of d(semo_in) only
+        H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), 16 if wide else nets['semo'].in_pad,
+               0 if wide else L.D, H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
         d_enc = g('d_enc', (M, e.enc_pad), f16)
         self._k('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
                 H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))

@@ -45,7 +45,7 @@ def point_features(model, points):
     sigma_out, _ = model._sigma_rows(points)
     n = sigma_out.shape[0]
     fs, os_ = L.nets['semf'], L.nets['semo']
-    if fs.lib or os_.lib:   # wide (LSeg) heads run as library GEMMs inside model.semantic
+    if L.sem_wide:   # wide (LSeg) heads: model.semantic runs them on the wide.hip GEMMs
         return model.semantic(sigma_out[:, 1:1 + L.G])[1].float()
     feat = torch.empty(n, fs.out_pad, dtype=f16, device=sigma_out.device)
     logits = torch.empty(n, os_.out_pad, dtype=f16, device=sigma_out.device)

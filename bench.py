@@ -388,6 +388,10 @@ def main():
         mac = {'sigma': macs('sigma'), 'color': macs('color'), 'sem': macs('semf') + macs('semo')}
         flops = t_mlp = 0.0
         for e, n, t in events:
+            if n.startswith('aln_wide'):   # one GEMM per launch: 2 M N K
+                flops += 2.0 * t[1] * t[2]
+                t_mlp += e[0].elapsed_time(e[1]) * 1e-3
+                continue
             if not n.startswith(('aln_mlp', 'aln_sem_heads')):
                 continue
             head, r = t
@@ -396,7 +400,7 @@ def main():
             flops += (2.0 if n.endswith('_fwd') else 4.0) * mac[head] * r
             t_mlp += e[0].elapsed_time(e[1]) * 1e-3
         if t_mlp > 0:
-            res['roofline_mlp'] = {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + k_mlp_bwd_recomp8 (all heads)', 'bound': 'mfma',
+            res['roofline_mlp'] = {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + k_mlp_bwd_recomp8 (all heads)' + (' + k_wide_nt / k_wide_tn' if L.sem_wide else ''), 'bound': 'mfma',
                                    'achieved': flops / t_mlp / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
                                    'frac': flops / t_mlp / 1e12 / 2500.0, 'us_per_step': t_mlp * 1e6 / args.event_steps,
                                    'algorithmic_gflop_per_step': flops / 1e9 / args.event_steps, 'live_color_rows': live_rows}

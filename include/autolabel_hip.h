@@ -207,6 +207,19 @@ int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d_semo_in, i
  * is OR-ed when a non-finite gradient passes */
 int aln_relu_bwd(void* g, const void* act, int64_t n, int32_t* found_inf, void* stream);
 
+/* ---- wide semantic heads (wide.hip): semantic_features / semantic_out at LSeg width (hidden_dim_semantic = 512,
+ * autolabel/models.py:117-136, scripts/ros/node.py:166-176), one hand-written MFMA GEMM launch per layer.
+ * A operand = [a1 (K1 columns, optionally through ReLU) | geo block (16 columns [geo_feat, 1..] built from the density head's
+ * output rows sigma_out[M,16]) when geo != NULL]. */
+/* Y[M,N] = epi(A W[N,K]^T): epi = (* (mask > 0)) (+ add) (ReLU), fp16 out; found_inf raised on a non-finite output */
+int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo, int32_t G, int32_t M, int32_t N,
+                const void* w, int32_t ldw, void* y, int32_t ldy, int32_t relu, const void* mask, int32_t ldm, const void* add,
+                int32_t lda, int32_t* found_inf, void* stream);
+/* dW[N,K] (fp32, row-major, leading dimension lddw) += G[M,N]^T A[M,K] */
+int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo, int32_t G,
+                int32_t M, int32_t N, float* dw, int32_t lddw, void* stream);
+int aln_transpose_f16(const void* src /*[R,C]*/, int32_t R, int32_t C, void* dst /*[C,R]*/, void* stream);
+
 /* ---- occupancy-grid marching (march.hip): the cuda_ray hooks of autolabel/trainer.py:21-23,34-36,176 and
  * NeRFRenderer.mark_untrained_grid / update_extra_state of the torch-ngp fork (dead in the reference: model_utils.py:72).
  * One-level G^3 density grid over [-bound,bound]^3 (-1 = never seen), one bit per cell. */

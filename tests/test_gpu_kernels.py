@@ -589,3 +589,65 @@ def test_density_grid_update_and_untrained_mask_match_oracle(H):
     near_th = np.abs(grid_w - th) < 1e-6
     assert np.array_equal(unpacked[~near_th], bits_w[~near_th]) and nset.item() == unpacked.sum()
     assert not unpacked[grid_w < 0].any()
+
+
+# ------------------------------------------------------------------ wide heads (csrc/wide.hip) vs plain fp32 torch
+def _geo_block(sout, G):
+    g = torch.ones(sout.shape[0], 16)
+    g[:, :G] = sout[:, 1:1 + G].float()
+    return g
+
+
+@pytest.mark.parametrize('M,N,K1,geo,relu1,relu,mask,add', [(300, 512, 0, True, 0, 1, False, False), (1000, 512, 512, False, 0, 1, False, False),
+                                                          (257, 64, 512, True, 1, 1, False, False), (129, 48, 64, False, 0, 0, False, False),
+                                                          (500, 512, 64, False, 0, 0, True, True), (77, 16, 512, False, 0, 0, False, False)])
+def test_wide_nt_gemm_matches_fp32(H, M, N, K1, geo, relu1, relu, mask, add):
+    """Y = epi(A W^T) with the prologue sources ([a1 | geo block], ReLU on load) and epilogues (mask, addend, ReLU) the wide
+    semantic heads use; fp16 operands, fp32 accumulate: vs fp32 torch on the same fp16 values, 2e-3 of the output scale."""
+    g = torch.Generator().manual_seed(M + N)
+    G = 15
+    a1 = (torch.randn(M, max(K1, 8), generator=g) * 0.5).half()
+    sout = (torch.randn(M, 16, generator=g) * 0.5).half()
+    K = K1 + (16 if geo else 0)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    mk = torch.randn(M, N, generator=g).half()
+    ad = torch.randn(M, N, generator=g).half()
+    A = torch.cat(([torch.relu(a1[:, :K1].float()) if relu1 else a1[:, :K1].float()] if K1 else []) + ([_geo_block(sout, G)] if geo else []), 1)
+    want = A @ w.float().t()
+    if mask:
+        want = want * (mk.float() > 0)
+    if add:
+        want = want + ad.float()
+    if relu:
+        want = torch.relu(want)
+    y = torch.full((M, N), float('nan'), dtype=torch.float16, device='cuda')
+    a1d, sd, wd, md, add_d = a1.cuda(), sout.cuda(), w.cuda().contiguous(), mk.cuda(), ad.cuda()
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    H.call('aln_wide_nt', H.ptr(a1d) if K1 else None, a1d.shape[1], K1, relu1, H.ptr(sd) if geo else None, G, M, N, H.ptr(wd), K, H.ptr(y), N,
+           relu, H.ptr(md) if mask else None, N, H.ptr(add_d) if add else None, N, H.ptr(flag), H.stream())
+    got = y.cpu().float()
+    assert torch.isfinite(got).all() and flag.item() == 0
+    assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+    if add:   # in-place accumulation (y is add)
+        H.call('aln_wide_nt', H.ptr(a1d), a1d.shape[1], K1, relu1, None, G, M, N, H.ptr(wd), K, H.ptr(add_d), N, relu, H.ptr(md), N,
+               H.ptr(add_d), N, None, H.stream())
+        assert (add_d.cpu().float() - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize('M,N,K1,geo,relu1', [(1000, 512, 512, False, 0), (300, 64, 512, True, 1), (4500, 512, 0, True, 0), (130, 48, 64, False, 0)])
+def test_wide_tn_weight_gradient_matches_fp32(H, M, N, K1, geo, relu1):
+    """dW += G^T A over the sample rows (slab-split, fp32 atomics): vs fp32 torch, accumulation semantics included."""
+    g = torch.Generator().manual_seed(M + N + 1)
+    G = 15
+    a1 = (torch.randn(M, max(K1, 8), generator=g) * 0.5).half()
+    sout = (torch.randn(M, 16, generator=g) * 0.5).half()
+    K = K1 + (16 if geo else 0)
+    gr = (torch.randn(M, N, generator=g) * 0.1).half()
+    A = torch.cat(([torch.relu(a1[:, :K1].float()) if relu1 else a1[:, :K1].float()] if K1 else []) + ([_geo_block(sout, G)] if geo else []), 1)
+    want = gr.float().t() @ A
+    dw = torch.ones(N, K, device='cuda')
+    a1d, sd, gd = a1.cuda(), sout.cuda(), gr.cuda()
+    H.call('aln_wide_tn', H.ptr(gd), N, H.ptr(a1d) if K1 else None, a1d.shape[1], K1, relu1, H.ptr(sd) if geo else None, G, M, N, H.ptr(dw), K,
+           H.stream())
+    got = dw.cpu() - 1.0
+    assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())

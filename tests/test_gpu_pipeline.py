@@ -172,9 +172,11 @@ def test_train_step_gradients_match_oracle_autograd(n_classes, G, hidden):
 
 def test_lseg_width_heads_match_oracle():
     """LSeg configuration (docs/vision-language.md:19, scripts/ros/node.py:166-176): 512-d feature head, many classes.
-    The wide heads run as library GEMMs; everything else is the HIP path.  Forward and gradients vs the oracle."""
+    The wide heads run on the hand-written MFMA GEMMs of wide.hip (no library dispatch).  Forward and gradients vs the oracle."""
     oracle, pipe, cfg = build_pair(L=4, D=512, C_=40)
-    assert pipe.L.nets['semf'].lib and pipe.L.nets['semo'].lib and not pipe.L.nets['sigma'].lib
+    nets = pipe.L.nets
+    assert nets['semf'].wide and nets['semo'].wide and not nets['sigma'].wide and pipe.L.sem_wide
+    assert not any(n.lib for n in nets.values()) and not pipe.L.sem_lib, 'no head may go to a library GEMM'
     N, S1, S2, C_, D, Cf = 24, 32, 32, 40, 512, 512
     o, d, norms = make_rays(N, seed=3)
     g = torch.Generator().manual_seed(5)
