@@ -13,6 +13,7 @@
 //   k_wide_tn : dW[N, K] += G[M, N]^T A[M, K]                weight gradients (contraction over the samples)
 // v_mfma_f32_32x32x16_f16 throughout; operand tiles staged in LDS; k_wide_tn reads them with ds_read_b64_tr_b16.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) h16 lds_h16w;
 typedef short s16x4w __attribute__((__vector_size__(4 * sizeof(short))));
@@ -61,29 +62,32 @@ struct WideNT {
   int* found_inf;               // raised when an output is not finite in fp16
 };
 
-#define WNT_BM 128
-#define WNT_BK 32
-#define WNT_PITCH (WNT_BK + 8)   // 80-byte rows: the 16-byte fragment reads of 16 consecutive rows fall into distinct 16-byte bank groups
+#define WNT_BK 64
+#define WNT_PITCH (WNT_BK + 8)   // 144-byte rows: the 16-byte fragment reads of 16 consecutive rows fall into distinct 16-byte bank groups
 
-template <int BN>
+// Block = 4 waves; wave w owns WM = 32 * MT sample rows x BN output columns (MT x BN/32 accumulator blocks): with MT = 2, BN = 128
+// a k-step costs 6 fragment reads for 8 MFMAs (a 32 x 128 wave tile needs 5 for 4 and is LDS-bound).
+template <int BN, int MT>
 __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
-  __shared__ __attribute__((aligned(16))) h16 Xs[WNT_BM * WNT_PITCH];
+  constexpr int BM = 128 * MT, NB = BN / 32, XC = BM * (WNT_BK / 8) / 256, WC = (BN * (WNT_BK / 8) + 255) / 256;
+  __shared__ __attribute__((aligned(16))) h16 Xs[BM * WNT_PITCH];
   __shared__ __attribute__((aligned(16))) h16 Ws[BN * WNT_PITCH];
-  constexpr int NB = BN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
-  const int m0 = blockIdx.x * WNT_BM, n0 = blockIdx.y * BN;
-  f32x16 acc[NB];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc[MT][NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.f;
   const int nkt = (p.K + WNT_BK - 1) / WNT_BK;
-  // global -> register staging of one k-tile: X: 128 rows x 4 chunks = 512 chunks (2 per thread); W: BN x 4 chunks
-  h16x8 xr[2], wr[(BN * 4 + 255) / 256];
+  // global -> register staging of one k-tile (8 chunks of 8 halves per row)
+  h16x8 xr[XC], wr[WC];
   auto fetch = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = tid + 256 * i, r = ch >> 2, k0 = kt * WNT_BK + (ch & 3) * 8;
+    for (int i = 0; i < XC; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 3, k0 = kt * WNT_BK + (ch & 7) * 8;
       const int m = m0 + r;
       if (m < p.M) xr[i] = wide_chunk(p.a, (size_t)m, k0, p.K);
       else {
@@ -92,22 +96,22 @@ __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < (BN * 4 + 255) / 256; ++i) {
-      const int ch = tid + 256 * i, r = ch >> 2, k0 = kt * WNT_BK + (ch & 3) * 8;
+    for (int i = 0; i < WC; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 3, k0 = kt * WNT_BK + (ch & 7) * 8;
       h16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (h16)0.f;
-      if (ch < BN * 4 && n0 + r < p.N && k0 < p.K) v = *(const h16x8*)(p.w + (size_t)(n0 + r) * p.ldw + k0);
+      if (ch < BN * 8 && n0 + r < p.N && k0 < p.K) v = *(const h16x8*)(p.w + (size_t)(n0 + r) * p.ldw + k0);
       wr[i] = v;
     }
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Xs + (ch >> 2) * WNT_PITCH + (ch & 3) * 8) = xr[i]; }
+    for (int i = 0; i < XC; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Xs + (ch >> 3) * WNT_PITCH + (ch & 7) * 8) = xr[i]; }
 #pragma unroll
-    for (int i = 0; i < (BN * 4 + 255) / 256; ++i) {
+    for (int i = 0; i < WC; ++i) {
       const int ch = tid + 256 * i;
-      if (ch < BN * 4) *(h16x8*)(Ws + (ch >> 2) * WNT_PITCH + (ch & 3) * 8) = wr[i];
+      if (ch < BN * 8) *(h16x8*)(Ws + (ch >> 3) * WNT_PITCH + (ch & 7) * 8) = wr[i];
     }
   };
   fetch(0);
@@ -118,19 +122,24 @@ __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
     if (kt + 1 < nkt) fetch(kt + 1);   // in flight while this tile is multiplied
 #pragma unroll
     for (int ks = 0; ks < WNT_BK / 16; ++ks) {
-      // B operand = this wave's 32 sample rows, A operand = 32 weight rows (output columns): lane owns sample row c
-      const h16x8 xb = *(const h16x8*)(Xs + (wave * 32 + c) * WNT_PITCH + ks * 16 + hf * 8);
+      // B operand = sample rows, A operand = weight rows (output columns): the lane owns sample row c of its 32-row group
+      h16x8 xb[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xb[t] = *(const h16x8*)(Xs + ((wave * MT + t) * 32 + c) * WNT_PITCH + ks * 16 + hf * 8);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const h16x8 wa = *(const h16x8*)(Ws + (b * 32 + c) * WNT_PITCH + ks * 16 + hf * 8);
-        acc[b] = wmfma(wa, xb, acc[b]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][b] = wmfma(wa, xb[t], acc[t][b]);
       }
     }
   }
-  // epilogue: lane holds sample row m = m0 + wave * 32 + c; register r of block b is output column 32 b + 8 (r / 4) + 4 hf + r % 4
-  const int m = m0 + wave * 32 + c;
+  // epilogue: lane holds sample row m; register r of block b is output column 32 b + 8 (r / 4) + 4 hf + r % 4
   bool bad = false;
-  if (m < p.M) {
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = m0 + (wave * MT + t) * 32 + c;
+    if (m >= p.M) continue;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[b][rg * 4 + j];
+        for (int j = 0; j < 4; ++j) v[j] = acc[t][b][rg * 4 + j];
         if (p.mask) {
           const h16x4 mk = *(const h16x4*)(p.mask + (size_t)m * p.ldm + n);
 #pragma unroll
@@ -177,11 +186,19 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
   p.w = (const h16*)w; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = relu;
   p.mask = (const h16*)mask; p.ldm = ldm; p.add = (const h16*)add; p.lda = lda; p.found_inf = found_inf;
   ALN_REQUIRE(ldw >= p.K, "wide_nt: weight rows shorter than K");
-  const int gm = (M + WNT_BM - 1) / WNT_BM;
   hipStream_t s = (hipStream_t)stream;
-  if (N > 64) hipLaunchKernelGGL(k_wide_nt<128>, dim3(gm, (N + 127) / 128), dim3(256), 0, s, p);
-  else if (N > 32) hipLaunchKernelGGL(k_wide_nt<64>, dim3(gm, 1), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(k_wide_nt<32>, dim3(gm, 1), dim3(256), 0, s, p);
+  // (measured on the 1M x 512 x 512 layers: wave tile 32 x 128 at 2 waves/SIMD 1.3 ms; 64 x 128 needs > 256 VGPRs, one wave per
+  //  SIMD: 1.5 ms)
+  static const int mt = getenv("ALN_WIDE_MT") ? atoi(getenv("ALN_WIDE_MT")) : 1;
+  if (mt == 2) {
+    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 2>), dim3((M + 255) / 256, (N + 127) / 128), dim3(256), 0, s, p);
+    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 2>), dim3((M + 255) / 256, 1), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wide_nt<32, 2>), dim3((M + 255) / 256, 1), dim3(256), 0, s, p);
+  } else {
+    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 1>), dim3((M + 127) / 128, (N + 127) / 128), dim3(256), 0, s, p);
+    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 1>), dim3((M + 127) / 128, 1), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wide_nt<32, 1>), dim3((M + 127) / 128, 1), dim3(256), 0, s, p);
+  }
   ALN_CHECK_LAUNCH("wide_nt");
   return 0;
 }
@@ -195,14 +212,18 @@ struct WideTN {
 };
 
 #define WTN_BM 64            // sample rows per LDS tile
-#define WTN_T 128            // tile edge in n and k
-#define WTN_PITCH 152        // halves (304 B: rows stay 16-byte aligned for the staging stores)
+#define WTN_TN 128           // tile edge in n
+#define WTN_TK 256           // tile edge in k
+#define WTN_PG (WTN_TN + 24) // halves (304 B: rows stay 16-byte aligned for the staging stores)
+#define WTN_PA (WTN_TK + 24)
 
+template <int PITCH>
 struct WTile {
   lds_h16w* p;
-  __device__ inline lds_h16w* at(int row, int col) const { return p + row * WTN_PITCH + col; }
+  __device__ inline lds_h16w* at(int row, int col) const { return p + row * PITCH + col; }
 };
-__device__ inline h16x8 wtr_frag(WTile t, int col0, int ks, int lane) {
+template <class T>
+__device__ inline h16x8 wtr_frag(T t, int col0, int ks, int lane) {
   // operand fragment for mfma 32x32x16: lane (i = lane & 31, hf = lane >> 5) gets tile[16 ks + 8 hf + 0..7][col0 + i]
   const int hf = lane >> 5;
   const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
@@ -215,64 +236,67 @@ __device__ inline h16x8 wtr_frag(WTile t, int col0, int ks, int lane) {
 }
 
 __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
-  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PITCH];
-  __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * WTN_PITCH];
+  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PG];
+  __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * WTN_PA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
-  const int n0 = blockIdx.x * WTN_T, k0 = blockIdx.y * WTN_T;
+  const int n0 = blockIdx.x * WTN_TN, k0 = blockIdx.y * WTN_TK;
   const int mlo = blockIdx.z * p.slab, mhi = min(p.M, mlo + p.slab);
-  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;   // wave tile 64 (n) x 64 (k)
-  f32x16 acc[2][2];
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;   // wave tile 64 (n) x 128 (k): 6 fragment reads per 8 MFMAs
+  f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const WTile tG{(lds_h16w*)Gs}, tA{(lds_h16w*)As};
-  // 64 rows x 16 chunks of 8 halves per tile = 1024 chunks: 4 per thread and tile
-  h16x8 gr[4], ar[4];
+  const WTile<WTN_PG> tG{(lds_h16w*)Gs};
+  const WTile<WTN_PA> tA{(lds_h16w*)As};
+  // G tile: 64 rows x 16 chunks (4 per thread); A tile: 64 rows x 32 chunks (8 per thread)
+  h16x8 gr[4], ar[8];
   auto fetch = [&](int mt) {
+    h16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
-      const int m = mt + r;
-      h16x8 z;
+      gr[i] = z;
+      if (mt + r < mhi && n0 + cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)(mt + r) * p.ldg + n0 + cc);
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
-      gr[i] = z; ar[i] = z;
-      if (m < mhi) {
-        if (n0 + cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)m * p.ldg + n0 + cc);
-        ar[i] = wide_chunk(p.a, (size_t)m, k0 + cc, p.K);
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 5, cc = (ch & 31) * 8;
+      ar[i] = z;
+      if (mt + r < mhi) ar[i] = wide_chunk(p.a, (size_t)(mt + r), k0 + cc, p.K);
     }
   };
   fetch(mlo);
   for (int mt = mlo; mt < mhi; mt += WTN_BM) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
-      *(h16x8*)(Gs + r * WTN_PITCH + cc) = gr[i];
-      *(h16x8*)(As + r * WTN_PITCH + cc) = ar[i];
-    }
+    for (int i = 0; i < 4; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Gs + (ch >> 4) * WTN_PG + (ch & 15) * 8) = gr[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int ch = tid + 256 * i; *(h16x8*)(As + (ch >> 5) * WTN_PA + (ch & 31) * 8) = ar[i]; }
     __syncthreads();
     if (mt + WTN_BM < mhi) fetch(mt + WTN_BM);
 #pragma unroll
     for (int ks = 0; ks < WTN_BM / 16; ++ks) {
-      h16x8 ga[2], ab[2];
+      h16x8 ga[2], ab[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { ga[i] = wtr_frag(tG, wn + 32 * i, ks, lane); ab[i] = wtr_frag(tA, wk + 32 * i, ks, lane); }
+      for (int i = 0; i < 2; ++i) ga[i] = wtr_frag(tG, wn + 32 * i, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ab[j] = wtr_frag(tA, wk + 32 * j, ks, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = wmfma(ga[i], ab[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = wmfma(ga[i], ab[j], acc[i][j]);
     }
   }
   // lane holds column k = k0 + wk + 32 j + c; register r of block (i, j) is row n = n0 + wn + 32 i + 8 (r / 4) + 4 hf + r % 4
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const int k = k0 + wk + 32 * j + c;
       if (k >= p.K) continue;
 #pragma unroll
@@ -293,7 +317,7 @@ extern "C" int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t l
   p.M = M; p.N = N; p.K = p.a.K1 + (geo ? 16 : 0);
   p.g = (const h16*)g; p.ldg = ldg; p.dw = dw; p.lddw = lddw;
   ALN_REQUIRE(lddw >= p.K, "wide_tn: gradient rows shorter than K");
-  const int tn = (N + WTN_T - 1) / WTN_T, tk = (p.K + WTN_T - 1) / WTN_T;
+  const int tn = (N + WTN_TN - 1) / WTN_TN, tk = (p.K + WTN_TK - 1) / WTN_TK;
   // enough slabs to fill the chip (>= ~1024 blocks), each a multiple of the 64-row tile
   int slabs = (1024 + tn * tk - 1) / (tn * tk);
   int slab = ((M + slabs - 1) / slabs + WTN_BM - 1) / WTN_BM * WTN_BM;
