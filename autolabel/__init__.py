@@ -1,6 +1,12 @@
 """Drop-in alias: ``import autolabel.models`` / ``autolabel.trainer`` / ``autolabel.dataset`` / ``autolabel.model_utils`` /
-``autolabel.utils`` resolve to the MI355X-native implementations in ``autolabel_amd`` so that the reference's own
-``scripts/train.py``, ``render.py`` and ``export.py`` import and run unchanged."""
+``autolabel.utils`` / ``autolabel.renderer`` resolve to the MI355X-native implementations in ``autolabel_amd``, so code written
+against the reference's hot-path modules (its ``scripts/train.py`` and ``scripts/export.py``: they import exactly these) runs
+on them unchanged.  NOT aliased -- out of the hot path: ``autolabel.constants``, ``autolabel.visualization``,
+``autolabel.utils.feature_utils``, ``autolabel.backend``, ``autolabel.evaluation``; the reference's ``scripts/render.py`` imports
+the first three for its colour maps / video writer and therefore needs the reference package for those (this repo's
+``scripts/render.py`` restates the rendering part).  One data-path deviation: depth frames are resized with nearest-neighbour
+sampling here; the reference's ``cv2.resize(depth, size, cv2.INTER_NEAREST)`` passes the flag in the ``dst`` position and so
+resizes bilinearly (autolabel/dataset.py:372)."""
 import importlib
 import sys
 

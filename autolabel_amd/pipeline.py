@@ -30,7 +30,10 @@ class MlpSpec:
         self.shapes = [(hidden, self.in_pad)] + [(hidden, hidden)] * (n_hidden - 1) + [(self.out_pad, hidden)]
         self.n_params = sum(o * i for o, i in self.shapes)
         if n_hidden not in (1, 2):
-            raise NotImplementedError(f'{name}: n_hidden={n_hidden} is not supported (1-2 hidden layers)')
+            raise NotImplementedError(
+                f'{name}: {n_hidden} hidden layers are not supported by the HIP heads (1-2).  Note: the reference class default '
+                'num_layers_color=3 (autolabel/models.py:70) is never used by the reference itself -- create_model passes 2 '
+                '(autolabel/model_utils.py:66); construct ALNetwork with num_layers_color=2.')
         # Heads too wide for the register-chained MFMA kernels of mlp.hip (weights resident in LDS) -- LSeg: D=512 -> semf
         # 16->512->512->512, semo 528->64->C; or hundreds of classes -- run layer by layer on the hand-written MFMA GEMMs of
         # wide.hip (weights streamed from L2, inputs / ReLU / masks / accumulation fused into prologue and epilogue).
@@ -387,8 +390,9 @@ class HipPipeline:
         e, nets = L.enc, L.nets
         dev = rays_o.device
         g = lambda n, shp, dt: ws.get(n, shp, dt)
+        self._serial = getattr(self, '_serial', 0) + 1   # every forward rewrites the shared, name-keyed workspaces
         c = dict(N=N, S1=S1, S2=S2, M=M, train=train, want_semantic=want_semantic, bg=float(bg),
-                 rays_o=rays_o, rays_d=rays_d, norms=norms)
+                 rays_o=rays_o, rays_d=rays_d, norms=norms, serial=self._serial)
         save = train and not self.recompute
         c['nears'], c['fars'] = g('nears', (N,), f32_), g('fars', (N,), f32_)
         z = c['z'] = g('z', (M,), f32_)
@@ -493,6 +497,10 @@ class HipPipeline:
         its all-reduce overlaps the remaining scatter."""
         L, P, ws = self.L, self.P, self.ws
         assert c['train'], 'backward needs a forward(train=True) context'
+        if c.get('serial') != getattr(self, '_serial', None):
+            raise RuntimeError('HipPipeline.backward: another forward() ran on this pipeline since the context was created; the '
+                               'intermediates live in shared workspaces and have been overwritten (call backward before the next '
+                               'render, e.g. one render() per loss, or render previews under a second model)')
         N, S1, S2, M = c['N'], c['S1'], c['S2'], c['M']
         M1 = N * S1
         nets, e = L.nets, L.enc
