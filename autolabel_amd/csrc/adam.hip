@@ -12,7 +12,7 @@
 //
 // state (device):
 //   si[0] = applied optimizer steps   si[1] = growth tracker   si[2] = found_inf flag   si[3] = -   si[4+b] = step count of block b
-//   sf[0] = loss scale
+//   sf[0] = loss scale   sf[1] = learning rate (> 0: overrides the host argument, so a captured hipGraph follows the scheduler)
 // consts (written by k_adam_prepare): c[0] = skip all (0/1), c[3] = 1/scale_used, c[4+2b] = lr / bc1_b (0 = block inactive),
 //                                     c[5+2b] = 1/sqrt(bc2_b)
 #define ADAM_MAX_BLOCKS 8
@@ -37,7 +37,8 @@ __global__ void k_adam_prepare(int* si, float* sf, float* c, AdamHyper h, AdamBl
       if (!active) { c[4 + 2 * b] = 0.f; c[5 + 2 * b] = 1.f; continue; }
       int t = si[4 + b] + 1; si[4 + b] = t;
       double bc1 = 1.0 - pow((double)h.beta1, (double)t), bc2 = 1.0 - pow((double)h.beta2, (double)t);
-      c[4 + 2 * b] = (float)((double)h.lr / bc1); c[5 + 2 * b] = (float)(1.0 / sqrt(bc2));
+      const float lr = sf[1] > 0.f ? sf[1] : h.lr;
+      c[4 + 2 * b] = (float)((double)lr / bc1); c[5 + 2 * b] = (float)(1.0 / sqrt(bc2));
     }
     int tr = si[1] + 1;
     if (tr >= h.growth_interval) { sf[0] = scale * h.growth; tr = 0; }

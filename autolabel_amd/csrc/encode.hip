@@ -21,9 +21,24 @@ struct EncParams {
   const float* rays_o; const float* rays_d; const float* z; const float* xyz;
   int rows, rays_stride;
   int level_lo, level_hi;   // backward only: levels [level_lo, level_hi) of this launch
+  // cell mode (density-grid refresh of the marching path, march.hip): row r is one jittered point of occupancy-grid cell
+  // cell0 + r -- the positions of aln_grid_points, generated in place instead of being read from a [G^3, 3] buffer
+  int cell_G, cell0; uint32_t cell_seed, cell_step; const uint32_t* cell_step_dev;
 };
 
 __device__ inline void row_position(const EncParams& p, int row, float* x) {
+  if (p.cell_G) {
+    const uint32_t key = aln_rand_key(p.cell_seed, ALN_STREAM_PERTURB, p.cell_step + (p.cell_step_dev ? *p.cell_step_dev : 0u));
+    const uint32_t g = (uint32_t)p.cell_G, c = (uint32_t)(p.cell0 + row);
+    const uint32_t r = c / g;
+    const float cf[3] = {(float)(c % g), (float)(r % g), (float)(r / g)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float u = aln_rand_uniform(key, 3u * c + (uint32_t)k);
+      x[k] = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn(cf[k], u), (float)p.cell_G), __fmul_rn(2.0f, p.e.bound)), p.e.bound);
+    }
+    return;
+  }
   if (p.xyz) {
     x[0] = p.xyz[3 * (size_t)row]; x[1] = p.xyz[3 * (size_t)row + 1]; x[2] = p.xyz[3 * (size_t)row + 2];
   } else {
@@ -360,6 +375,7 @@ static int fill_params(EncParams& p, const AlnEncDesc* e, const void* table, con
   ALN_REQUIRE(e->enc_dim == 6 * e->n_freq + (e->use_grid ? 2 * e->grid.n_levels : 0), "encode: enc_dim mismatch");
   p.e = *e; p.table = (const uint32_t*)table; p.rays_o = rays_o; p.rays_d = rays_d; p.z = z; p.xyz = xyz;
   p.rows = rows; p.rays_stride = stride;
+  p.cell_G = 0; p.cell0 = 0; p.cell_seed = p.cell_step = 0; p.cell_step_dev = nullptr;
   p.level_lo = 0; p.level_hi = e->use_grid ? (int)e->grid.n_levels : 0;
   return 0;
 }
@@ -371,6 +387,36 @@ extern "C" int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const 
   if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
   ALN_REQUIRE(!e->use_grid || table_f16, "encode_fwd: table is NULL");
   if (rows == 0) return 0;
+  int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
+  int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
+  size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);
+  hipLaunchKernelGGL(k_encode_fwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (h16*)enc_out);
+  ALN_CHECK_LAUNCH("encode_fwd");
+  return 0;
+}
+
+// encoding of one jittered point per occupancy-grid cell (cells [cell0, cell0 + rows) of a G^3 grid): the input of the density
+// head for NeRFRenderer.update_extra_state (march.hip); same positions as aln_grid_points, never stored
+extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, int32_t G, uint32_t seed, uint32_t step,
+                                    const uint32_t* step_dev, int32_t cell0, int32_t rows, void* planes_ws, void* enc_out,
+                                    void* stream) {
+  EncParams p;
+  static const float dummy = 0.f;   // fill_params wants a position source; cell mode overrides it
+  if (int rc = fill_params(p, e, table_f16, nullptr, nullptr, nullptr, &dummy, rows, 1)) return rc;
+  ALN_REQUIRE(G > 0 && G <= 1024 && cell0 >= 0 && (int64_t)cell0 + rows <= (int64_t)G * G * G && enc_out, "encode_fwd_cells: bad cell range");
+  ALN_REQUIRE(!e->use_grid || table_f16, "encode_fwd_cells: table is NULL");
+  p.xyz = nullptr; p.cell_G = G; p.cell0 = cell0; p.cell_seed = seed; p.cell_step = step; p.cell_step_dev = step_dev;
+  if (rows == 0) return 0;
+  if (e->use_grid && planes_ws) {
+    static const int lg = getenv("ALN_ENC_LG") ? atoi(getenv("ALN_ENC_LG")) : ENC_LG;
+    const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
+    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
+    ALN_CHECK_LAUNCH("encode_grid_phased");
+    hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
+                       (const h16x2*)planes_ws, (h16*)enc_out);
+    ALN_CHECK_LAUNCH("encode_assemble");
+    return 0;
+  }
   int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
   int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
   size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);

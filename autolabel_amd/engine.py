@@ -21,7 +21,7 @@ class TrainEngine:
                  scaler=None, process_group=None):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
         dv = self.P.device
-        self.lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(weight_decay_net)
+        self._lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(weight_decay_net)
         self.weights = (float(rgb_weight), float(depth_weight), float(semantic_weight), float(feature_weight))
         self.feature_loss = feature_loss
         self.S1, self.S2 = int(num_steps), int(upsample_steps)
@@ -31,7 +31,7 @@ class TrainEngine:
         self.m = torch.zeros(n, device=dv)
         self.v = torch.zeros(n, device=dv)
         self.state_i = torch.zeros(16, dtype=torch.int32, device=dv)  # [steps, growth tracker, found_inf, -, per-block steps]
-        self.state_f = torch.tensor([sc['init_scale'], 0, 0, 0], dtype=torch.float32, device=dv)  # [loss scale]
+        self.state_f = torch.tensor([sc['init_scale'], float(lr), 0, 0], dtype=torch.float32, device=dv)  # [loss scale, lr]
         self.consts = torch.zeros(24, device=dv)
         # parameter blocks = the reference's parameter tensors (torch skips tensors whose grad is None)
         L = self.L
@@ -57,6 +57,19 @@ class TrainEngine:
         if self.march:
             self.S1, self.S2 = pipe.occ.samples, 0
         self._calls = 0
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        """The learning rate lives in device memory (state_f[1], read by the Adam kernel): a captured step follows the scheduler
+        without being re-captured."""
+        value = float(value)
+        if value != self._lr:
+            self._lr = value
+            self.state_f[1:2].fill_(value)
 
     def _gbuf(self, name, shape):
         t = self._g.get(name)
@@ -167,7 +180,8 @@ class TrainEngine:
 
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.state_i.copy_(sd['state_i']); self.state_f.copy_(sd['state_f'])
-        self.lr = float(sd.get('lr', self.lr))
+        self._lr = float(sd.get('lr', self._lr))
+        self.state_f[1:2].fill_(self._lr)
 
 
 class GraphedStep:
@@ -175,9 +189,9 @@ class GraphedStep:
 
     ``body(step_dev)`` issues the launches; ``step_dev`` is a device int32[1] holding the number of steps so far, which the
     RNG-consuming kernels add to their step argument.  ``warmup`` eager calls run first so that every lazily allocated
-    workspace exists before the capture (allocation is not capturable).  ``alt_body`` is a variant of the step (captured as a
+    workspace exists before the capture (allocation is not capturable).  The learning rate is NOT baked in (device word).  ``alt_body`` is a variant of the step (captured as a
     second graph) that replaces it on every ``alt_every``-th step, counted from step 0.  Re-capture (``GraphedStep(...)`` again)
-    after anything baked into the launches changes: learning rate, batch size, loss weights, level groups."""
+    after anything baked into the launches changes: batch size, loss weights, level groups."""
 
     def __init__(self, body, device, warmup=3, alt_body=None, alt_every=0):
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)
@@ -197,7 +211,7 @@ class GraphedStep:
         self.alt_graph = None
         if alt_body is not None:
             self.alt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.alt_graph, stream=side, pool=self.graph.pool()):
+            with torch.cuda.graph(self.alt_graph, stream=side):
                 self._once(True)
 
     def _is_alt(self):

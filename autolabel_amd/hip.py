@@ -55,6 +55,7 @@ _SIGS = {
     'aln_encode_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'aln_encode_fwd_ws_bytes': (i64, [vp, i32]),
     'aln_encode_fwd_phased': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'aln_encode_fwd_cells': (i32, [vp, vp, i32, u32, u32, vp, i32, i32, vp, vp, vp]),
     'aln_dev_encode_fwd_levels': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, vp]),
     'aln_encode_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'aln_encode_bwd_levels': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp]),

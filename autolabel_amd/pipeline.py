@@ -223,14 +223,17 @@ class HipPipeline:
         per cell, grid = max(grid * decay, sigma * density_scale), bit = grid > min(mean, density_thresh)."""
         occ, e = self.occ, self.L.enc
         n = occ.G ** 3
-        xyz = self.ws.get('occ_xyz', (n, 3), f32_)
         sig = self.ws.get('occ_sigma', (n,), f32_)
-        H.call('aln_grid_points', occ.G, e.bound, seed, step, H.ptr(step_dev), None, H.ptr(xyz), H.stream())
         enc = self.ws.get('occ_enc', (chunk, e.enc_pad), f16)
         out = self.ws.get('occ_out', (chunk, 16), f16)
+        planes = self.ws.scratch('enc_planes', int(e.grid.n_levels) * chunk * 4) if e.use_grid else None
         for a in range(0, n, chunk):
             rows = min(chunk, n - a)
-            self.density_rows(rows, None, None, None, xyz[a:a + rows], 1, enc, None, None, out, sig[a:a + rows], train=False)
+            # the cell points (aln_grid_points' positions) are generated inside the encoding kernels: no [G^3, 3] buffer
+            H.call('aln_encode_fwd_cells', C.byref(e), H.ptr(self.P.table16), occ.G, seed, step, H.ptr(step_dev), a, rows, H.ptr(planes),
+                   H.ptr(enc), H.stream())
+            H.call('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, None, None, H.ptr(out), H.stream())
+            H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sig[a:a + rows]), H.stream())
         H.call('aln_grid_update', H.ptr(occ.grid), H.ptr(sig), occ.G, occ.decay, self.density_scale, occ.density_thresh,
                H.ptr(occ.stats), H.ptr(occ.bits), H.ptr(occ.n_set), H.stream())
         occ.updates += 1

@@ -145,10 +145,7 @@ class Trainer:
         if getattr(self, '_engine_state', None) is not None:
             self.engine.load_state_dict(self._engine_state)
             self._engine_state = None
-        lr = self.optimizer.param_groups[0]['lr']  # follows the torch scheduler
-        if lr != self.engine.lr:
-            self.engine.lr = lr
-            self._graph = None   # the learning rate is baked into a captured step
+        self.engine.lr = self.optimizer.param_groups[0]['lr']  # follows the torch scheduler (a device word: captured steps see it)
         return self.engine
 
     def _to_device_batch(self, data):
@@ -280,9 +277,9 @@ class SimpleTrainer(Trainer):
 
     def _graphed_iterations(self, loader, iterations):
         """Device-resident data (dataset.DeviceLoader): ray generation + the whole optimisation step replay from ONE hipGraph
-        (engine.GraphedStep); the capture is redone when the engine, the learning rate or the loader changes."""
+        (engine.GraphedStep); the capture is redone when the engine or the loader changes (not for the learning rate: a device word)."""
         eng = self._engine()
-        key = (id(loader), id(eng), eng.lr)
+        key = (id(loader), id(eng))
         if getattr(self, '_graph', None) is None or self._graph[0] != key:
             g = eng.graphed(loader.frames, loader.batch, loader.seed, self.model._seed, frame_range=loader.frame_range,
                             first_step=self.global_step, warmup=1)

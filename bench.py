@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')   # see autolabel_amd/__init__.py: must be set before HIP initialises
 
 
 def parse():
@@ -180,17 +181,31 @@ def marching_leg(args, scene, train, test, bound, device, B):
     pipe.mark_untrained_grid(train.world_to_camera(), (fx, fy, cx, cy), size=(train.w, train.h))
     eng = TrainEngine(pipe, feature_loss=True)
     batch = train.alloc_batch(B)
+    dbg = lambda m: (torch.cuda.synchronize(), print('[march]', m, file=sys.stderr, flush=True)) if os.environ.get('ALN_BENCH_DEBUG') else None
+    dbg('engine built')
     g = eng.graphed(train, batch, 1234, 99, warmup=3)
+    dbg('captured')
     total = max(args.quality_steps, args.steps + args.warmup)
     n = g.steps
-    while n < total - args.steps:
+    while n < args.warmup:
         g(); n += 1
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
+    for _ in range(args.steps):      # timed like the dense leg: the steps right after the warm-up, lr 5e-3
         g()
     torch.cuda.synchronize()
     dt = time.time() - t0
+    n += args.steps
+    dbg('timed')
+    for frac, lr in ((0.6, 5e-3), (0.8, 2.5e-3), (1.0, 1.25e-3)):     # the dense leg's schedule
+        eng.lr = lr
+        dbg(f'lr set {lr} state_f {eng.state_f.tolist()} terms {eng.terms.tolist()}')
+        while n < int(frac * total):
+            g(); n += 1
+            if os.environ.get('ALN_BENCH_DEBUG') and n % 16 in (0, 1, 2):
+                dbg(f'n={n} terms {eng.terms.tolist()} scale {eng.state_f[0].item()}')
+        dbg(f'lr {lr} done n={n}')
+    torch.cuda.synchronize()
     def render(ro, rd, dn):   # marching render: the trained field is only meaningful where the grid lets samples fall
         parts = []
         ro, rd, dn = ro.reshape(-1, 3), rd.reshape(-1, 3), dn.reshape(-1)
@@ -200,12 +215,13 @@ def marching_leg(args, scene, train, test, bound, device, B):
             parts.append({k: out[k].clone() for k in ('image', 'depth', 'semantic')})
         return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
     q = heldout_metrics(render, test, scene['n_classes'])
-    q.update(steps=n + args.steps)
+    q.update(steps=n)
     return {'value': B * args.steps / dt, 'unit': 'rays/s', 'ms_per_step': 1000 * dt / args.steps, 'samples_per_ray': args.march_samples,
             'sample_rows_per_step': B * args.march_samples, 'grid': '128^3, one level', 'max_steps': 1024, 'density_thresh': args.march_thresh,
-            'occupied_fraction': occ.occupancy(), 'grid_updates': (n + args.steps + occ.update_interval - 1) // occ.update_interval, 'quality': q,
-            'note': 'cuda_ray=True path (dead in the reference: model_utils.py:72); timed over the last %d of the steps, grid refresh '
-                    '(every 16th step, launch by launch) included' % args.steps}
+            'occupied_fraction': occ.occupancy(), 'grid_updates': (n + occ.update_interval - 1) // occ.update_interval, 'quality': q,
+            'note': 'cuda_ray=True path (dead in the reference: model_utils.py:72); timed over %d steps after %d warm-up steps like the dense '
+                    'leg, grid refresh (every 16th step, its own captured graph) included; then trained on to the same step count and '
+                    'learning-rate schedule as the dense leg' % (args.steps, args.warmup)}
 
 
 def main():
@@ -323,14 +339,18 @@ def main():
     # quality of the trained state: continue to --quality-steps optimizer steps, then held-out metrics
     quality = None
     if args.quality_steps > 0:
-        while done[0] < args.quality_steps:
-            step()
+        # StepLR of scripts/train.py:70-75 compressed to this run: lr halves at 60 % and 80 % of the steps (the learning rate is a
+        # device word the Adam kernel reads, so the captured step follows it without re-capture)
+        for frac, lr in ((0.6, 5e-3), (0.8, 2.5e-3), (1.0, 1.25e-3)):
+            eng.lr = lr
+            while done[0] < int(frac * args.quality_steps):
+                step()
         sync()
         if rank == 0:
             quality = heldout_metrics(pipe_renderer(eng.pipe), test, scene['n_classes'])
-            quality.update(steps=done[0], batch_per_gpu=B, lr=eng.lr, adam_steps_applied=int(eng.state_i[0].item()),
+            quality.update(steps=done[0], batch_per_gpu=B, lr='5e-3, halved at 60 % and 80 % of the steps', adam_steps_applied=int(eng.state_i[0].item()),
                            note='held-out frames (every 20th) of the bench scene at the training resolution, 256 samples/ray; labels on '
-                                'every 10th training frame only; constant lr; fp32-oracle parity of the same metrics: '
+                                'every 10th training frame only; oracle parity of the same metrics: '
                                 'tests/test_gpu_quality.py')
 
     if rank == 0:

@@ -129,6 +129,11 @@ int64_t aln_encode_fwd_ws_bytes(const AlnEncDesc* e, int32_t rows);
 int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
                           const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* planes_ws, void* enc_out,
                           void* stream);
+/* encoding of one jittered point per occupancy-grid cell, cells [cell0, cell0 + rows) of a G^3 grid over [-bound,bound]^3 (the
+ * positions of aln_grid_points, generated inside the kernel): input of the density head for the density-grid refresh,
+ * NeRFRenderer.update_extra_state at autolabel/trainer.py:34-36.  planes_ws != NULL selects the level-phased kernels. */
+int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, int32_t G, uint32_t seed, uint32_t step,
+                         const uint32_t* step_dev, int32_t cell0, int32_t rows, void* planes_ws, void* enc_out, void* stream);
 /* development probe (scripts/dev/probe_encode_fwd_levels.py): the tile kernel for levels [level_lo, level_hi) only */
 int aln_dev_encode_fwd_levels(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
                               const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* enc_out,

@@ -12,6 +12,7 @@ from argparse import Namespace
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import autolabel_amd  # noqa: F401  (sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before HIP initialises)
 import torch
 from torch import optim
 

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')   # autolabel_amd/__init__.py: before HIP initialises
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -463,3 +463,31 @@ def test_backward_through_an_overwritten_render_context_raises():
     with pytest.raises(NotImplementedError, match='num_layers_color=2'):
         from autolabel_amd.models import ALNetwork
         ALNetwork(encoding='hg+freq', hidden_dim=128, hidden_dim_color=128)    # class default num_layers_color=3
+
+
+def test_graph_replays_survive_kernel_launches_in_between():
+    """ROCm 7.2: with hipGraph packet capture enabled (the default), an ordinary kernel launch between two replays of a captured
+    step leaves the next replay with stale kernel arguments (NaN losses or a memory access fault) -- reproduced with
+    scripts/dev/debug_graph_eager.py.  autolabel_amd sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime initialises;
+    this is the regression test of that setting: torch kernels and library kernels interleaved with the replays."""
+    import ctypes as C
+    from autolabel_amd import hip as H, synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    assert os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'
+    scene = synthetic.make_cube_scene(n_frames=8)
+    frames = DeviceFrames.from_scene(scene, 'cuda')
+    model = make_model(D=64, C_=scene['n_classes'], bound=6.0, grid_scale=1.0)
+    eng = TrainEngine(model._ensure_device(), num_steps=64, upsample_steps=64)
+    batch = frames.alloc_batch(2048)
+    g = eng.graphed(frames, batch, 1, 2, warmup=2)
+    a, b = torch.zeros(1 << 20, device='cuda'), torch.zeros(1 << 20, dtype=torch.float16, device='cuda')
+    for i in range(60):
+        g()
+        if i % 5 == 4:
+            torch.zeros(4, device='cuda').fill_(1.0)                       # torch elementwise kernel
+            eng.lr = 5e-3 * 0.99 ** i                                      # device word the Adam kernel reads
+            H.call('aln_cast_f16', H.ptr(a), H.ptr(b), a.numel(), H.stream())  # a kernel of this library
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.terms).all() and torch.isfinite(model._P.flat).all()
+    assert int(eng.state_i[0].item()) == g.steps

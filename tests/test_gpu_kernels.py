@@ -651,3 +651,25 @@ def test_wide_tn_weight_gradient_matches_fp32(H, M, N, K1, geo, relu1):
            H.stream())
     got = dw.cpu() - 1.0
     assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+
+
+def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
+    """aln_encode_fwd_cells generates the jittered cell points inside the kernel: same bits as encoding aln_grid_points' output,
+    for both the tile kernel and the level-phased kernels, at a cell offset."""
+    G, bound = 20, 1.5
+    e = H.make_enc_desc('hg+freq', bound)
+    n = G ** 3
+    g = torch.Generator().manual_seed(1)
+    table = ((torch.rand(int(e.grid.n_entries), 2, generator=g) - 0.5)).half().cuda()
+    xyz = torch.empty(n, 3, device='cuda')
+    H.call('aln_grid_points', G, bound, 11, 4, None, None, H.ptr(xyz), H.stream())
+    a, rows = 1000, 5003
+    want = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+    xs = xyz[a:a + rows].contiguous()
+    H.call('aln_encode_fwd', C.byref(e), H.ptr(table), None, None, None, H.ptr(xs), rows, 1, H.ptr(want), H.stream())
+    step_dev = torch.tensor([3], dtype=torch.int32, device='cuda')
+    for phased in (False, True):
+        got = torch.zeros_like(want)
+        planes = torch.empty(int(H.lib().aln_encode_fwd_ws_bytes(C.byref(e), rows)), dtype=torch.uint8, device='cuda') if phased else None
+        H.call('aln_encode_fwd_cells', C.byref(e), H.ptr(table), G, 11, 1, H.ptr(step_dev), a, rows, H.ptr(planes), H.ptr(got), H.stream())
+        assert torch.equal(got, want), f'phased={phased}'
