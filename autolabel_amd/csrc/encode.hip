@@ -616,6 +616,7 @@ __device__ inline long long fx_from_half(h16 h) {
 #define FX_UNIT (1.0 / 68719476736.0)   // 2^-36
 
 #define ACC_THREADS 1024
+#define ACC_RB 6                // runs per batch in the accumulate loop (8 spills at the 128-VGPR budget of 16 waves per CU)
 __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
   long long* acc = (long long*)acc_smem;   // [BIN_SLICE][2] = 128 KB
@@ -653,39 +654,44 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
       }
     }
   } else
-  for (int t0 = (part * nw + wave) * 64; t0 < a.ntiles; t0 += K * nw * 64) {
-    const uint32_t dd = (t0 + lane < a.ntiles) ? d[t0 + lane] : 0u;
-    const int nt = min(64, a.ntiles - t0);
-    // batches of 4 runs, the first 128 records of each run in two 8-byte loads per lane (16-byte loads, two records per lane,
-    // were slower: half the lanes idle through the conversions); the next batch is requested before the current one is
-    // consumed (8 KB in flight per wave)
-    uint2 r[2][8]; uint32_t st[2][4], n[2][4], up[2][4];
-    auto request = [&](int buf, int j0) {
+  {
+    // the tiles are dealt out to the 16 waves in equal contiguous shares (all waves busy for any tile count); a wave walks its
+    // share in rounds of <= 64 tiles (one descriptor per lane) and batches of ACC_RB runs: the first 128 records of each run in
+    // two 8-byte loads per lane (16-byte loads, two records per lane, were slower: half the lanes idle through the conversions),
+    // the next batch requested before the current one is consumed (2 x ACC_RB KB in flight per wave)
+    const int share = ((a.ntiles + nw - 1) / nw + ACC_RB - 1) / ACC_RB * ACC_RB;
+    const int tlo = min(wave * share, a.ntiles), thi = min(tlo + share, a.ntiles);
+    for (int t0 = tlo; t0 < thi; t0 += 64) {
+      const int nt = min(64, thi - t0);
+      const uint32_t dd = (lane < nt) ? d[t0 + lane] : 0u;
+      uint2 r[2][2 * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB], up[2][ACC_RB];
+      auto request = [&](int buf, int j0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t q = __builtin_amdgcn_readlane(dd, (j0 + u) & 63);
-        st[buf][u] = q & 0x1FFFu; n[buf][u] = (j0 + u < nt) ? ((q >> 13) & 0x1FFFu) : 0u; up[buf][u] = BIN_MAX_SHIFT - (q >> 26);
-        const uint2* src = pool + (size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u];
-        r[buf][2 * u] = r[buf][2 * u + 1] = make_uint2(0u, 0u);
-        if ((uint32_t)lane < n[buf][u]) r[buf][2 * u] = src[lane];
-        if ((uint32_t)lane + 64u < n[buf][u]) r[buf][2 * u + 1] = src[lane + 64];
-      }
-    };
-    auto consume = [&](int buf, int j0) {
+        for (int u = 0; u < ACC_RB; ++u) {
+          const uint32_t q = __builtin_amdgcn_readlane(dd, (j0 + u) & 63);
+          st[buf][u] = q & 0x1FFFu; n[buf][u] = (j0 + u < nt) ? ((q >> 13) & 0x1FFFu) : 0u; up[buf][u] = BIN_MAX_SHIFT - (q >> 26);
+          const uint2* src = pool + (size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u];
+          r[buf][2 * u] = r[buf][2 * u + 1] = make_uint2(0u, 0u);
+          if ((uint32_t)lane < n[buf][u]) r[buf][2 * u] = src[lane];
+          if ((uint32_t)lane + 64u < n[buf][u]) r[buf][2 * u + 1] = src[lane + 64];
+        }
+      };
+      auto consume = [&](int buf, int j0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if ((uint32_t)lane < n[buf][u]) add(r[buf][2 * u], up[buf][u]);
-        if ((uint32_t)lane + 64u < n[buf][u]) add(r[buf][2 * u + 1], up[buf][u]);
-        for (uint32_t k = 128 + lane; k < n[buf][u]; k += 64)   // long runs
-          add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], up[buf][u]);
+        for (int u = 0; u < ACC_RB; ++u) {
+          if ((uint32_t)lane < n[buf][u]) add(r[buf][2 * u], up[buf][u]);
+          if ((uint32_t)lane + 64u < n[buf][u]) add(r[buf][2 * u + 1], up[buf][u]);
+          for (uint32_t k = 128 + lane; k < n[buf][u]; k += 64)   // long runs
+            add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], up[buf][u]);
+        }
+      };
+      request(0, 0);
+      for (int j0 = 0; j0 < nt; j0 += 2 * ACC_RB) {
+        request(1, j0 + ACC_RB);
+        consume(0, j0);
+        request(0, j0 + 2 * ACC_RB);
+        consume(1, j0 + ACC_RB);
       }
-    };
-    request(0, 0);
-    for (int j0 = 0; j0 < nt; j0 += 8) {
-      request(1, j0 + 4);
-      consume(0, j0);
-      request(0, j0 + 8);
-      consume(1, j0 + 4);
     }
   }
   __syncthreads();

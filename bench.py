@@ -164,7 +164,7 @@ def cpu_baseline(half, train_ids, feature_dim, n_classes, bound):
             'host_raygen_rays_per_s': raygen, 'host_raygen_sample': '5 batches of 4096 rays, numpy mirror of dataset._next_train on the S1 scene'}
 
 
-def marching_leg(args, scene, train, test, bound, device, B):
+def marching_leg(args, scene, train, test, bound, device, B, full=None):
     """Second configuration: the same scene, model and batch trained through occupancy-grid marching
     (cuda_ray=True: `--march-samples` rows per ray inside occupied cells instead of 128 + 128 along the whole ray), from scratch
     for --quality-steps steps; rays/s over the last --steps replays, then the same held-out metrics."""
@@ -216,9 +216,25 @@ def marching_leg(args, scene, train, test, bound, device, B):
         return {k: torch.cat([p[k] for p in parts]) for k in parts[0]}
     q = heldout_metrics(render, test, scene['n_classes'])
     q.update(steps=n)
+    # render throughput through the occupancy grid: full 640x480 frames, the same 128 rows per ray as the quality render
+    render_mrays = None
+    if full is not None and args.render_frames > 0:
+        fb = full.alloc_batch(full.w * full.h)
+        def render_frame(f):
+            full.get_test(f, fb)
+            for a in range(0, full.w * full.h, 16384):
+                pipe.forward(fb['rays_o'][a:a + 16384], fb['rays_d'][a:a + 16384], fb['direction_norms'][a:a + 16384].reshape(-1),
+                             max(args.march_samples, 128), 0, False, train=False, march=True)
+        render_frame(0)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for f in range(args.render_frames):
+            render_frame(f % full.n_frames)
+        torch.cuda.synchronize()
+        render_mrays = full.w * full.h * args.render_frames / (time.time() - t1) / 1e6
     return {'value': B * args.steps / dt, 'unit': 'rays/s', 'ms_per_step': 1000 * dt / args.steps, 'samples_per_ray': args.march_samples,
             'sample_rows_per_step': B * args.march_samples, 'grid': '128^3, one level', 'max_steps': 1024, 'density_thresh': args.march_thresh,
-            'occupied_fraction': occ.occupancy(), 'grid_updates': (n + occ.update_interval - 1) // occ.update_interval, 'quality': q,
+            'render_Mrays_per_s': render_mrays, 'render_rows_per_ray': max(args.march_samples, 128), 'occupied_fraction': occ.occupancy(), 'grid_updates': (n + occ.update_interval - 1) // occ.update_interval, 'quality': q,
             'note': 'cuda_ray=True path (dead in the reference: model_utils.py:72); timed over %d steps after %d warm-up steps like the dense '
                     'leg, grid refresh (every 16th step, its own captured graph) included; then trained on to the same step count and '
                     'learning-rate schedule as the dense leg' % (args.steps, args.warmup)}
@@ -427,7 +443,7 @@ def main():
         if render_roof:
             res['roofline_render'] = render_roof
         if not args.no_march and world == 1:
-            res['marching'] = marching_leg(args, scene, train, test, bound, device, B)
+            res['marching'] = marching_leg(args, scene, train, test, bound, device, B, full)
         if not args.no_cpu_baseline and world == 1:
             train_ids, _ = split_heldout(args.frames)
             res['cpu_baseline'] = cpu_baseline(half, train_ids, args.feature_dim, scene['n_classes'], bound)
