@@ -244,7 +244,9 @@ __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
   float* zin = T + S;      // unsorted z [S]
   uint16_t* lid = (uint16_t*)(zin + S);  // [S]
   for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
-    for (int i = lane; i < S; i += 64) zin[i] = p.z[row_of(ray, i, p.N, p.S1, p.S2)];
+    // (a NaN distance -- a diverged field -- would make the two rank rules below inconsistent and leave slots of the
+    //  permutation unwritten; it is ordered like +inf instead.  Finite inputs are untouched.)
+    for (int i = lane; i < S; i += 64) { const float zz = p.z[row_of(ray, i, p.N, p.S1, p.S2)]; zin[i] = zz == zz ? zz : 3.0e38f; }
     __syncthreads();
     const float* zc = zin; const float* zf = zin + p.S1;
     for (int i = lane; i < S; i += 64) {

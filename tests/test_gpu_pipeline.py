@@ -315,3 +315,26 @@ def test_inference_and_training_forward_agree_bitwise():
     b, _ = pipe.forward(od, dd, nd, 64, 32, False, train=False)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_diverged_field_does_not_corrupt_memory():
+    """NaN / inf parameters (a diverged run) must give NaN outputs, not out-of-range indices: the sample merge orders NaN
+    distances like +inf, positions are clamped, so every index stays inside its buffer (canary rows around the workspaces)."""
+    oracle, pipe, cfg = build_pair(L=16, D=64, C_=3)
+    with torch.no_grad():
+        pipe.P.flat[pipe.L.n_grid:pipe.L.n_grid + 2000] = float('nan')
+        pipe.P.flat[pipe.L.n_grid + 2000:pipe.L.n_grid + 4000] = float('inf')
+    pipe.P.refresh_shadows()
+    N, S1, S2 = 256, 64, 64
+    o, d, norms = make_rays(N, seed=5)
+    canary = torch.full((1 << 20,), 7.0, device='cuda')      # allocated after the workspaces of earlier tests, before this pipe's
+    out, ctx = pipe.forward(o.cuda(), d.cuda(), norms.cuda().reshape(-1), S1, S2, True, train=True, seed=1, step=0)
+    gi = torch.ones(N, 3, device='cuda'); gd = torch.ones(N, device='cuda')
+    gs = torch.zeros(N, 3, device='cuda'); gf = torch.zeros(N, 64, device='cuda')
+    pipe.P.grad.zero_()
+    pipe.backward(ctx, gi, gd, gs, gf)
+    torch.cuda.synchronize()
+    perm = ctx['perm'].view(N, S1 + S2).long().cpu()
+    assert ((perm >= 0) & (perm < S1 + S2)).all() and (perm.sort(dim=1).values == torch.arange(S1 + S2)[None]).all(), 'merge must stay a permutation'
+    assert (canary == 7.0).all()
+    assert pipe.found_inf.item() == 1
