@@ -91,12 +91,15 @@ def model_dir(scene_path, flags):
     return os.path.join(flags.workspace, scene_name, model_hash(flags))
 
 
-def create_model(min_bounds, max_bounds, n_classes, flags):
+def create_model(min_bounds, max_bounds, n_classes, flags, cuda_ray=False, **renderer_kwargs):
+    """autolabel/model_utils.py:61-74 (which hard-codes cuda_ray=False).  cuda_ray=True switches the renderer to occupancy-grid
+    marching (csrc/march.hip); renderer_kwargs: march_samples, max_steps, grid_size, density_thresh."""
     extents = max_bounds - min_bounds
     bound = (extents - (min_bounds + max_bounds) * 0.5).max()
     return ALNetwork(num_layers=2, num_layers_color=2, hidden_dim_color=128, hidden_dim=128,
                      geo_feat_dim=flags.geometric_features, encoding=flags.encoding, bound=float(bound),
-                     hidden_dim_semantic=flags.feature_dim, cuda_ray=False, density_scale=1, semantic_classes=n_classes)
+                     hidden_dim_semantic=flags.feature_dim, cuda_ray=bool(cuda_ray), density_scale=1, semantic_classes=n_classes,
+                     **renderer_kwargs)
 
 
 def read_params(workspace):

@@ -376,7 +376,7 @@ def main():
             'ms_per_step': 1000 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': "S1 synthetic room standing in for the 'bench' scene: 200 frames 640x480 trained at factor 2, "
+            'config': {'workload': "S1 synthetic room standing in for the 'bench' scene: %d frames 640x480 trained at factor 2, " % args.frames +
                                    'DINO-like 64-d features, hg+freq L=16 T=2^19, 128+128 samples/ray',
                        'rays_per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'feature_dim': args.feature_dim,
                        'hip_graph': bool(use_graph)},

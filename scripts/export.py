@@ -66,7 +66,8 @@ def export_labels(flags, scene):
     params = model_utils.read_params(model_dir)
     dataset = SceneDataset('train', scene, size=lookup_frame_size(scene), batch_size=16384, features=params.features, load_semantic=False)
     n_classes = dataset.n_classes if dataset.n_classes is not None else 2
-    model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, n_classes, params).cuda().eval()
+    kw = dict(cuda_ray=True, march_samples=getattr(params, 'march_samples', 96)) if getattr(params, 'cuda_ray', False) else {}
+    model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, n_classes, params, **kw).cuda().eval()
     model_utils.load_checkpoint(model, os.path.join(model_dir, 'checkpoints'))
     output_path = os.path.join(scene, 'output', 'semantic')
     os.makedirs(output_path, exist_ok=True)

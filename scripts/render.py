@@ -55,7 +55,8 @@ def main():
     params = model_utils.read_params(flags.model_dir)
     dataset = SceneDataset('test', flags.scene, size=(480, 360), batch_size=16384, features=params.features, load_semantic=False, lazy=True)
     n_classes = dataset.n_classes if dataset.n_classes is not None else 2
-    model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, n_classes, params).cuda().eval()
+    kw = dict(cuda_ray=True, march_samples=getattr(params, 'march_samples', 96)) if getattr(params, 'cuda_ray', False) else {}
+    model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, n_classes, params, **kw).cuda().eval()
     model_utils.load_checkpoint(model, os.path.join(flags.model_dir, 'checkpoints'))
     try:
         from skvideo.io.ffmpeg import FFmpegWriter

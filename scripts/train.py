@@ -35,6 +35,8 @@ def read_args():
     parser.add_argument('--synthetic', choices=['room', 'cube'], default=None)
     parser.add_argument('--device-data', action='store_true', help='device-resident frames + HIP batch assembly')
     parser.add_argument('--global-batch', type=int, default=0, help='data parallel: fixed global batch (overrides --batch-size)')
+    parser.add_argument('--cuda-ray', action='store_true', help='occupancy-grid marching (the reference hard-codes cuda_ray=False)')
+    parser.add_argument('--march-samples', type=int, default=96, help='sample rows per ray with --cuda-ray')
     return parser.parse_args()
 
 
@@ -56,7 +58,8 @@ def main():
     else:
         dataset = SceneDataset('train', flags.scene, factor=flags.factor_train, batch_size=flags.batch_size, features=flags.features)
     n_classes = dataset.n_classes if dataset.n_classes is not None else 2
-    model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, n_classes, flags)
+    kw = dict(cuda_ray=True, march_samples=flags.march_samples) if flags.cuda_ray else {}
+    model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, n_classes, flags, **kw)
     opt = Namespace(rand_pose=-1, color_space='srgb', feature_loss=flags.features is not None, rgb_weight=flags.rgb_weight,
                     depth_weight=flags.depth_weight, semantic_weight=flags.semantic_weight, feature_weight=flags.feature_weight)
     optimizer = lambda model: torch.optim.Adam([

@@ -270,6 +270,27 @@ def test_scripts_train_export_on_written_scene(tmp_path):
     assert len(outs) == 6
 
 
+def test_scripts_train_with_marching_and_device_data(tmp_path):
+    """scripts/train.py --cuda-ray --device-data: frames in HBM, occupancy-grid marching, the step replayed from the two
+    hipGraphs (plain / with grid refresh); export.py rebuilds the marching model from params.pkl and loads grid + bitfield."""
+    from autolabel_amd import synthetic
+    from autolabel_amd.utils import write_scene
+    scene_dir = str(tmp_path / 'scene2')
+    write_scene(synthetic.make_cube_scene(n_frames=6), scene_dir)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train.py'), scene_dir, '--iters', '1000', '--batch-size', '1024',
+                        '--factor-train', '1', '--workers', '0', '--cuda-ray', '--march-samples', '64', '--device-data'],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mdir = os.path.join(scene_dir, 'nerf', 'g15_hg+freq_plain_rgb1.0_d0.1_s1.0_f0.5')
+    ck = sorted(os.listdir(os.path.join(mdir, 'checkpoints')))
+    sd = torch.load(os.path.join(mdir, 'checkpoints', ck[-1]), map_location='cpu', weights_only=False)['model']
+    assert 'density_grid' in sd and (sd['density_grid'] > 0).any() and (sd['density_bitfield'] != 0).any()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'export.py'), scene_dir], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(os.listdir(os.path.join(scene_dir, 'output', 'semantic'))) == 6
+
+
 @pytest.mark.parametrize('encoding', ['freq', 'hg'])
 def test_other_encodings_train_one_step_like_the_oracle(encoding):
     """--encoding freq / hg (autolabel/model_utils.py:25-29): forward + gradients vs the oracle, then one fused step."""
