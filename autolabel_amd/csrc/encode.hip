@@ -477,7 +477,14 @@ extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const fl
 //   phase 2 (k_encode_bwd_accum): a block owns one (level, slice); it streams that slice's runs of every tile, accumulates
 //     them with LDS atomics in fp32 and adds the slice to the gradient table with plain coalesced stores.
 // HBM traffic: 8 B written + 8 B read per record (<= 8 x 16 records per sample) instead of 4 atomic requests per (sample, level).
-#define BIN_TILE 512            // sample rows per phase-1 block (= threads: lane = sample, so runs along a ray dedupe in-wave)
+#ifndef BIN_TILE
+#define BIN_TILE 512            // sample rows per phase-1 block (= threads: lane = sample, so runs along a ray dedupe in-wave); -DBIN_TILE=1024
+                                // (1 KB runs for phase 2) measured: dense pair 771 -> 806 us, marching 265 -> 260 us: no gain
+#endif
+// descriptor word: start (13 bits) | count << 13 (14 bits) | shift << 27
+#define DESC_START(q) ((q) & 0x1FFFu)
+#define DESC_COUNT(q) (((q) >> 13) & 0x3FFFu)
+#define DESC_SHIFT(q) ((q) >> 27)
 #define BIN_SLICE_LOG2 13       // table entries per slice (x 2 features x 4 B = 64 KB LDS in phase 2)
 #define BIN_SLICE (1 << BIN_SLICE_LOG2)
 #define BIN_MAX_SLICES 64       // 2^19 entries / 8192
@@ -488,7 +495,7 @@ struct BinParams {
   EncParams p;
   const h16* d_enc;
   uint2* pool;        // [n_levels][ntiles][BIN_CHUNK] records
-  uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  start | count << 13 | shift << 26
+  uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  DESC_START | DESC_COUNT | DESC_SHIFT
   int ntiles;
   int rows1, stride2; // rows [0, rows1) use p.rays_stride samples per ray, the rest stride2 (coarse + fine pass in one launch)
 };
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
       const int ex = (int)((vmax_s[par] >> 23) & 0xFFu) - 127;          // floor(log2(max)); inf / huge -> large -> shift 0
       const int sh = min(max(14 - ex, 0), BIN_MAX_SHIFT);
       if (lane == 63) { total_s = inc; shift_s = sh; }
-      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - np) | (n << 13) | ((uint32_t)sh << 26);
+      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - np) | (n << 13) | ((uint32_t)sh << 27);
     }
     __syncthreads();
     if (tid == 0) vmax_s[par] = 0u;    // next use: level l + 2, two barriers away from any reader
@@ -616,7 +623,8 @@ __device__ inline long long fx_from_half(h16 h) {
 #define FX_UNIT (1.0 / 68719476736.0)   // 2^-36
 
 #define ACC_THREADS 1024
-#define ACC_RB 6                // runs per batch in the accumulate loop (8 spills at the 128-VGPR budget of 16 waves per CU)
+#define ACC_LPR (BIN_TILE / 256)  // 8-byte loads per lane and run held in registers: covers the average run of a hashed level twice
+#define ACC_RB (12 / ACC_LPR)    // runs per batch in the accumulate loop (12 loads per batch: 16 spill at the 128-VGPR budget of 16 waves per CU)
 __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
   long long* acc = (long long*)acc_smem;   // [BIN_SLICE][2] = 128 KB
@@ -643,7 +651,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     // in flight; the tiles of the slice are dealt out over the K blocks
     for (int t = part * nw + wave; t < a.ntiles; t += K * nw) {
       const uint32_t q = d[t];
-      const uint32_t st0 = q & 0x1FFFu, n0 = (q >> 13) & 0x1FFFu, up0 = BIN_MAX_SHIFT - (q >> 26);
+      const uint32_t st0 = DESC_START(q), n0 = DESC_COUNT(q), up0 = BIN_MAX_SHIFT - DESC_SHIFT(q);
       const uint2* src = pool + (size_t)t * BIN_CHUNK + st0;
       for (uint32_t k = lane; k < n0; k += 256) {
         uint2 rr[4];
@@ -657,31 +665,34 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   {
     // the tiles are dealt out to the 16 waves in equal contiguous shares (all waves busy for any tile count); a wave walks its
     // share in rounds of <= 64 tiles (one descriptor per lane) and batches of ACC_RB runs: the first 128 records of each run in
-    // two 8-byte loads per lane (16-byte loads, two records per lane, were slower: half the lanes idle through the conversions),
+    // ACC_LPR 8-byte loads per lane (16-byte loads, two records per lane, were slower: half the lanes idle through the conversions),
     // the next batch requested before the current one is consumed (2 x ACC_RB KB in flight per wave)
     const int share = ((a.ntiles + nw - 1) / nw + ACC_RB - 1) / ACC_RB * ACC_RB;
     const int tlo = min(wave * share, a.ntiles), thi = min(tlo + share, a.ntiles);
     for (int t0 = tlo; t0 < thi; t0 += 64) {
       const int nt = min(64, thi - t0);
       const uint32_t dd = (lane < nt) ? d[t0 + lane] : 0u;
-      uint2 r[2][2 * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB], up[2][ACC_RB];
+      uint2 r[2][ACC_LPR * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB], up[2][ACC_RB];
       auto request = [&](int buf, int j0) {
 #pragma unroll
         for (int u = 0; u < ACC_RB; ++u) {
           const uint32_t q = __builtin_amdgcn_readlane(dd, (j0 + u) & 63);
-          st[buf][u] = q & 0x1FFFu; n[buf][u] = (j0 + u < nt) ? ((q >> 13) & 0x1FFFu) : 0u; up[buf][u] = BIN_MAX_SHIFT - (q >> 26);
+          st[buf][u] = DESC_START(q); n[buf][u] = (j0 + u < nt) ? DESC_COUNT(q) : 0u; up[buf][u] = BIN_MAX_SHIFT - DESC_SHIFT(q);
           const uint2* src = pool + (size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u];
-          r[buf][2 * u] = r[buf][2 * u + 1] = make_uint2(0u, 0u);
-          if ((uint32_t)lane < n[buf][u]) r[buf][2 * u] = src[lane];
-          if ((uint32_t)lane + 64u < n[buf][u]) r[buf][2 * u + 1] = src[lane + 64];
+#pragma unroll
+          for (int v = 0; v < ACC_LPR; ++v) {
+            r[buf][ACC_LPR * u + v] = make_uint2(0u, 0u);
+            if ((uint32_t)lane + 64u * v < n[buf][u]) r[buf][ACC_LPR * u + v] = src[lane + 64 * v];
+          }
         }
       };
       auto consume = [&](int buf, int j0) {
 #pragma unroll
         for (int u = 0; u < ACC_RB; ++u) {
-          if ((uint32_t)lane < n[buf][u]) add(r[buf][2 * u], up[buf][u]);
-          if ((uint32_t)lane + 64u < n[buf][u]) add(r[buf][2 * u + 1], up[buf][u]);
-          for (uint32_t k = 128 + lane; k < n[buf][u]; k += 64)   // long runs
+#pragma unroll
+          for (int v = 0; v < ACC_LPR; ++v)
+            if ((uint32_t)lane + 64u * v < n[buf][u]) add(r[buf][ACC_LPR * u + v], up[buf][u]);
+          for (uint32_t k = 64 * ACC_LPR + lane; k < n[buf][u]; k += 64)   // long runs
             add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], up[buf][u]);
         }
       };
@@ -711,6 +722,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   }
 }
 
+extern "C" int32_t aln_encode_bwd_binned_tile_rows(void) { return BIN_TILE; }
 extern "C" int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows) {
   if (!e || !e->use_grid || rows <= 0) return 0;
   const int64_t ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;

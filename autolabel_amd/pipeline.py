@@ -261,9 +261,11 @@ class HipPipeline:
         t = self.ws.bufs.get('enc_bwd_bins')
         if t is None or not self.binned_bwd:
             return None
-        nl, nt = int(self.L.enc.grid.n_levels), (M + 511) // 512
-        desc = t[1][nl * nt * 4096 * 8:nl * nt * 4096 * 8 + nl * 64 * nt * 4].view(torch.int32)
-        return int(((desc >> 13) & 0x1FFF).sum().item())
+        tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
+        nl, nt = int(self.L.enc.grid.n_levels), (M + tile - 1) // tile
+        pool = nl * nt * tile * 8 * 8
+        desc = t[1][pool:pool + nl * 64 * nt * 4].view(torch.int32)
+        return int(((desc >> 13) & 0x3FFF).sum().item())
 
     # ---- wide semantic heads on the hand-written MFMA GEMMs of wide.hip (models.py:248-256 at LSeg width)
     def _nt(self, M, N, w, y, a1=None, K1=0, relu1=0, geo=None, relu=0, mask=None, add=None, watch=False, tag=None):

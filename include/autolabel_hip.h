@@ -153,6 +153,7 @@ int aln_encode_bwd_levels(const AlnEncDesc* e, const float* rays_o, const float*
  * the importance pass of autolabel/trainer.py:64-70 in one launch).  ws = aln_encode_bwd_binned_ws_bytes(e, rows) bytes of
  * caller-owned scratch.  *found_inf is set when a gradient entry is not finite (record values travel as fp16). */
 int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows);
+int32_t aln_encode_bwd_binned_tile_rows(void);   /* sample rows per phase-1 tile (layout of ws: pool chunks of 8 x tile records, then descriptors) */
 int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
                           int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2, const void* d_enc,
                           float* grad_table, void* ws, int32_t level_lo, int32_t level_hi, int32_t* found_inf, void* stream);

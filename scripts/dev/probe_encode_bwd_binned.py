@@ -39,8 +39,9 @@ for l in range(16):
 for lo, hi in ((0, 4), (4, 8), (8, 12), (12, 16)):
     print(f'levels {lo}-{hi}: atomic {timeit(lambda: atomic(lo, hi)):.0f} us   binned {timeit(lambda: binned(lo, hi)):.0f} us')
 # records actually written (descriptor counts)
-nt = (M + 511) // 512
-desc = ws[16 * nt * 4096 * 8:].view(torch.int32).view(16, 64, nt)
+tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
+nt = (M + tile - 1) // tile
+desc = ws[16 * nt * tile * 8 * 8:].view(torch.int32).view(16, 64, nt)
 binned(0, 16); torch.cuda.synchronize()
-cnt = ((desc >> 13) & 0x1FFF).sum(dim=(1, 2)).tolist()
+cnt = ((desc >> 13) & 0x3FFF).sum(dim=(1, 2)).tolist()
 print('records per level:', cnt, ' total %.1f M of %.1f M undeduped' % (sum(cnt) / 1e6, M * 8 * 16 / 1e6))
