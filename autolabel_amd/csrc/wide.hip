@@ -70,10 +70,19 @@ struct WideNT {
 template <int BN, int MT>
 __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
   constexpr int BM = 128 * MT, NB = BN / 32, XC = BM * (WNT_BK / 8) / 256, WC = (BN * (WNT_BK / 8) + 255) / 256;
-  __shared__ __attribute__((aligned(16))) h16 Xs[BM * WNT_PITCH];
-  __shared__ __attribute__((aligned(16))) h16 Ws[BN * WNT_PITCH];
+  constexpr int CG = BN < 64 ? BN : 64, EP = CG + 4;      // epilogue: column groups of CG fp32 values per row, pitch EP floats
+  constexpr int OPER = (BM + BN) * WNT_PITCH * 2, EPIL = 4 * 32 * EP * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_w[OPER > EPIL ? OPER : EPIL];
+  h16* Xs = (h16*)smem_w;
+  h16* Ws = Xs + BM * WNT_PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order (block b runs on XCD b % 8, each XCD has its own L2): the N / BN column tiles of one row tile get ids
+  // that differ by multiples of 8, so they land on the SAME XCD back to back and the row tile of A is fetched from HBM once
+  // (with a plain 2-D grid every column tile re-read its 128 x K slice of A: 4 GB instead of 1 GB for the 512-wide layers)
+  const int ntn = (p.N + BN - 1) / BN, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mt_i = (jj / ntn) * 8 + xcd;
+  if (mt_i * BM >= p.M) return;
+  const int m0 = mt_i * BM, n0 = (jj % ntn) * BN;
   f32x16 acc[MT][NB];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
@@ -134,40 +143,62 @@ __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
       }
     }
   }
-  // epilogue: lane holds sample row m; register r of block b is output column 32 b + 8 (r / 4) + 4 hf + r % 4
+  // epilogue.  In the accumulators a lane holds ONE sample row (register r of block b = output column 32 b + 8 (r / 4) + 4 hf +
+  // r % 4): storing from there writes 8-byte pieces to 32 different rows per instruction (measured: the 1M x 512 output cost
+  // more than the GEMM).  Each wave therefore turns its 32 x CG fp32 block through LDS and then works row-contiguously: 8 lanes
+  // cover 64 columns of a row, so mask / addend loads and the fp16 stores are 16 bytes per lane, 128 bytes per row segment.
   bool bad = false;
+  __syncthreads();                       // every wave is done with the operand tiles: the space becomes the transpose buffer
+  float* ep = (float*)smem_w + wave * (32 * EP);
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int m = m0 + (wave * MT + t) * 32 + c;
-    if (m >= p.M) continue;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int cg = 0; cg < BN / CG; ++cg) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + b * 32 + rg * 8 + hf * 4;
-        if (n >= p.N) continue;
-        float v[4];
+      for (int bb = 0; bb < CG / 32; ++bb) {
+        const int b = cg * (CG / 32) + bb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[t][b][rg * 4 + j];
-        if (p.mask) {
-          const h16x4 mk = *(const h16x4*)(p.mask + (size_t)m * p.ldm + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = mk[j] > (h16)0.f ? v[j] : 0.f;
-        }
-        if (p.add) {
-          const h16x4 ad = *(const h16x4*)(p.add + (size_t)m * p.lda + n);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)ad[j];
-        }
-        h16x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (p.relu) v[j] = fmaxf(v[j], 0.f);
-          o[j] = (h16)v[j];
-          bad |= !(fabsf(v[j]) <= 65504.f);
-        }
-        *(h16x4*)(p.y + (size_t)m * p.ldy + n) = o;
+        for (int rg = 0; rg < 4; ++rg)
+          *(f32x4*)(ep + c * EP + bb * 32 + rg * 8 + hf * 4) = (f32x4){acc[t][b][rg * 4], acc[t][b][rg * 4 + 1], acc[t][b][rg * 4 + 2], acc[t][b][rg * 4 + 3]};
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int LPR = CG / 8;          // lanes per row (8 columns each)
+#pragma unroll
+      for (int it = 0; it < 32 / (64 / LPR); ++it) {
+        const int r = it * (64 / LPR) + lane / LPR, col = (lane % LPR) * 8;
+        const int m = m0 + (wave * MT + t) * 32 + r, n = n0 + cg * CG + col;
+        if (m < p.M && n < p.N) {
+          float v[8];
+          const f32x4 v0 = *(const f32x4*)(ep + r * EP + col), v1 = *(const f32x4*)(ep + r * EP + col + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+          const bool full = n + 8 <= p.N;     // N is a multiple of 4: a row ends on a full or a half chunk
+          if (p.mask) {
+            const h16* mp = p.mask + (size_t)m * p.ldm + n;
+            h16x4 m0v = *(const h16x4*)mp, m1v = full ? *(const h16x4*)(mp + 4) : (h16x4){0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = m0v[j] > (h16)0.f ? v[j] : 0.f; v[4 + j] = m1v[j] > (h16)0.f ? v[4 + j] : 0.f; }
+          }
+          if (p.add) {
+            const h16* ap = p.add + (size_t)m * p.lda + n;
+            h16x4 a0 = *(const h16x4*)ap, a1 = full ? *(const h16x4*)(ap + 4) : (h16x4){0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += (float)a0[j]; v[4 + j] += (float)a1[j]; }
+          }
+          h16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (p.relu) v[j] = fmaxf(v[j], 0.f);
+            if (j < 4 || full) bad |= !(fabsf(v[j]) <= 65504.f);
+            o[j] = (h16)v[j];
+          }
+          h16* yp = p.y + (size_t)m * p.ldy + n;
+          if (full && (p.ldy & 7) == 0) *(h16x8*)yp = o;               // one 16-byte store per lane
+          else { *(h16x4*)yp = (h16x4){o[0], o[1], o[2], o[3]}; if (full) *(h16x4*)(yp + 4) = (h16x4){o[4], o[5], o[6], o[7]}; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (bad && p.found_inf) *p.found_inf = 1;
@@ -190,14 +221,15 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
   // (measured on the 1M x 512 x 512 layers: wave tile 32 x 128 at 2 waves/SIMD 1.3 ms; 64 x 128 needs > 256 VGPRs, one wave per
   //  SIMD: 1.5 ms)
   static const int mt = getenv("ALN_WIDE_MT") ? atoi(getenv("ALN_WIDE_MT")) : 1;
+  auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm + 7) / 8 * 8 * ((N + bn - 1) / bn))); };
   if (mt == 2) {
-    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 2>), dim3((M + 255) / 256, (N + 127) / 128), dim3(256), 0, s, p);
-    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 2>), dim3((M + 255) / 256, 1), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_wide_nt<32, 2>), dim3((M + 255) / 256, 1), dim3(256), 0, s, p);
+    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 2>), grid(256, 128), dim3(256), 0, s, p);
+    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 2>), grid(256, 64), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wide_nt<32, 2>), grid(256, 32), dim3(256), 0, s, p);
   } else {
-    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 1>), dim3((M + 127) / 128, (N + 127) / 128), dim3(256), 0, s, p);
-    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 1>), dim3((M + 127) / 128, 1), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_wide_nt<32, 1>), dim3((M + 127) / 128, 1), dim3(256), 0, s, p);
+    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 1>), grid(128, 128), dim3(256), 0, s, p);
+    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 1>), grid(128, 64), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wide_nt<32, 1>), grid(128, 32), dim3(256), 0, s, p);
   }
   ALN_CHECK_LAUNCH("wide_nt");
   return 0;
@@ -209,6 +241,7 @@ struct WideTN {
   const h16* g; int ldg;     // [M, ldg], N columns used
   float* dw; int lddw;       // [N, lddw] fp32, accumulated with atomics
   int slab;                  // sample rows per block
+  int tn, tk;                // output tiles in n and k
 };
 
 #define WTN_BM 64            // sample rows per LDS tile
@@ -239,8 +272,13 @@ __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
   __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PG];
   __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * WTN_PA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
-  const int n0 = blockIdx.x * WTN_TN, k0 = blockIdx.y * WTN_TK;
-  const int mlo = blockIdx.z * p.slab, mhi = min(p.M, mlo + p.slab);
+  // XCD-aware order (see k_wide_nt): the tn x tk output tiles of one sample slab share an XCD, so the slab's rows of G and A
+  // come from HBM once
+  const int ntile = p.tn * p.tk, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int slab_i = (jj / ntile) * 8 + xcd, tile_i = jj % ntile;
+  if (slab_i * p.slab >= p.M) return;
+  const int n0 = (tile_i % p.tn) * WTN_TN, k0 = (tile_i / p.tn) * WTN_TK;
+  const int mlo = slab_i * p.slab, mhi = min(p.M, mlo + p.slab);
   const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;   // wave tile 64 (n) x 128 (k): 6 fragment reads per 8 MFMAs
   f32x16 acc[2][4];
 #pragma unroll
@@ -323,8 +361,8 @@ extern "C" int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t l
   int slab = ((M + slabs - 1) / slabs + WTN_BM - 1) / WTN_BM * WTN_BM;
   if (slab < WTN_BM) slab = WTN_BM;
   slabs = (M + slab - 1) / slab;
-  p.slab = slab;
-  hipLaunchKernelGGL(k_wide_tn, dim3(tn, tk, slabs), dim3(256), 0, (hipStream_t)stream, p);
+  p.slab = slab; p.tn = tn; p.tk = tk;
+  hipLaunchKernelGGL(k_wide_tn, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p);
   ALN_CHECK_LAUNCH("wide_tn");
   return 0;
 }
