@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--iters', type=int, default=3000)
     ap.add_argument('--frames', type=int, default=100)
     ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--cuda-ray', action='store_true', help='occupancy-grid marching (csrc/march.hip)')
+    ap.add_argument('--march-samples', type=int, default=64)
     args = ap.parse_args()
     from autolabel_amd import synthetic
     from autolabel_amd.dataset import DeviceFrames
@@ -39,7 +41,11 @@ def main():
     lo, hi = scene['min_bounds'], scene['max_bounds']
     bound = float(((hi - lo) - (lo + hi) * 0.5).max())
     model = ALNetwork(encoding='hg+freq', num_layers=2, hidden_dim=128, geo_feat_dim=15, num_layers_color=2, hidden_dim_color=128,
-                      hidden_dim_semantic=64, semantic_classes=scene['n_classes'], bound=bound, cuda_ray=False, density_scale=1).cuda()
+                      hidden_dim_semantic=64, semantic_classes=scene['n_classes'], bound=bound, cuda_ray=args.cuda_ray, density_scale=1,
+                      march_samples=args.march_samples).cuda()
+    if args.cuda_ray:
+        model._ensure_device().mark_untrained_grid(frames.world_to_camera(), (frames.desc.fx, frames.desc.fy, frames.desc.cx, frames.desc.cy),
+                                                   size=(frames.w, frames.h))
     eng = TrainEngine(model._ensure_device(), feature_loss=True)
     batch = frames.alloc_batch(args.batch)
     gamma, steps = 0.5, math.log(1e-4 / 5e-3, 0.5)
@@ -55,6 +61,8 @@ def main():
     with torch.inference_mode():
         for f in range(len(held)):
             t = test.get_test(f)
+            if args.cuda_ray:
+                model.march_samples = 128
             out = model.render(t['rays_o'], t['rays_d'], t['direction_norms'], staged=True, perturb=False, num_steps=256,
                                upsample_steps=0, max_ray_batch=16384)
             mse = ((out['image'] - t['pixels']) ** 2).mean().item()
@@ -67,7 +75,7 @@ def main():
                 inter[c] += ((pred == c) & (gt == c)).sum(); union[c] += ((pred == c) | (gt == c)).sum()
     iou = inter[union > 0] / union[union > 0]
     print('per-class IoU', np.round(inter / np.maximum(union, 1), 3).tolist(), 'pred hist', np.bincount(pred.ravel(), minlength=8).tolist(), 'gt hist', np.bincount(gt.ravel(), minlength=8).tolist(), file=sys.stderr)
-    print(json.dumps({'iters': args.iters, 'train_rays_per_s': args.batch * args.iters / dt, 'psnr_heldout': float(np.mean(psnrs)),
+    print(json.dumps({'iters': args.iters, 'cuda_ray': args.cuda_ray, 'samples_per_ray': args.march_samples if args.cuda_ray else 256, 'train_rays_per_s': args.batch * args.iters / dt, 'psnr_heldout': float(np.mean(psnrs)),
                       'depth_l1_m': float(np.mean(depth_err)), 'miou_heldout': float(iou.mean()), 'loss_terms': eng.terms.tolist(),
                       'loss_scale': eng.state_f[0].item(), 'adam_steps': int(eng.state_i[0].item())}))
 
