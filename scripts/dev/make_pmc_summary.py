@@ -50,6 +50,18 @@ else:
         out['atomic_kernel_note'] = ('round-1 fp32-atomic scatter (k_encode_bwd, one launch per renderer pass = 524288 rows): L2 atomic '
                                      'requests per launch; at 1.47 ms per launch (profiles/r01_kernel_stats_rocprofv3.csv) that is the '
                                      'request rate the atomic units deliver (profiles/r02_probe_atomics4.txt: 21 G/s)')
+lseg = os.path.join(ROOT, 'gpurun_out', prefix + 'lseg512_mfma.txt')
+if os.path.exists(lseg):   # bench.py --feature-dim 512 under --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (wide.hip kernels)
+    wk, k = {}, None
+    for line in open(lseg):
+        if not line.startswith(' '):
+            k = line.strip()
+        else:
+            m = re.match(r'\s+(\S+)\s+n=\s*(\d+) avg=(\S+)', line)
+            wk.setdefault(k, {})[m.group(1)] = float(m.group(3))
+    for k, e in wk.items():
+        e['mfma_util'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (e['GRBM_GUI_ACTIVE'] / 8 * 1024)
+    out['lseg512_wide_kernels'] = wk
 json.dump(out, open(os.path.join(ROOT, 'profiles', rnd + '_pmc_summary.json'), 'w'), indent=1)
 for k, e in out['kernels'].items():
     if 'mfma_util' in e and e['mfma_util'] > 0:
