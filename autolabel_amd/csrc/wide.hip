@@ -62,6 +62,71 @@ struct WideNT {
   int* found_inf;               // raised when an output is not finite in fp16
 };
 
+// Epilogue shared by the two NT kernels.  In the accumulators a lane holds ONE sample row (register r of block b = output column
+// 32 b + 8 (r / 4) + 4 hf + r % 4): storing from there writes 8-byte pieces to 32 different rows per instruction (measured: the
+// 1M x 512 output cost more than the GEMM).  Each wave therefore turns its 32 x CG fp32 block through LDS and then works
+// row-contiguously: 8 lanes cover 64 columns of a row, so mask / addend loads and the fp16 stores are 16 bytes per lane.
+template <int BN, int MT>
+__device__ inline bool wide_epilogue(const WideNT& p, f32x16 (&acc)[MT][BN / 32], unsigned char* smem_w, int m0, int n0, int wave, int lane) {
+  constexpr int CG = BN < 64 ? BN : 64, EP = CG + 4;
+  const int hf = lane >> 5, c = lane & 31;
+  bool bad = false;
+  __syncthreads();                       // every wave is done with the operand tiles: the space becomes the transpose buffer
+  float* ep = (float*)smem_w + wave * (32 * EP);
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int cg = 0; cg < BN / CG; ++cg) {
+#pragma unroll
+      for (int bb = 0; bb < CG / 32; ++bb) {
+        const int b = cg * (CG / 32) + bb;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *(f32x4*)(ep + c * EP + bb * 32 + rg * 8 + hf * 4) = (f32x4){acc[t][b][rg * 4], acc[t][b][rg * 4 + 1], acc[t][b][rg * 4 + 2], acc[t][b][rg * 4 + 3]};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int LPR = CG / 8;          // lanes per row (8 columns each)
+#pragma unroll
+      for (int it = 0; it < 32 / (64 / LPR); ++it) {
+        const int r = it * (64 / LPR) + lane / LPR, col = (lane % LPR) * 8;
+        const int m = m0 + (wave * MT + t) * 32 + r, n = n0 + cg * CG + col;
+        if (m < p.M && n < p.N) {
+          float v[8];
+          const f32x4 v0 = *(const f32x4*)(ep + r * EP + col), v1 = *(const f32x4*)(ep + r * EP + col + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+          const bool full = n + 8 <= p.N;     // N is a multiple of 4: a row ends on a full or a half chunk
+          if (p.mask) {
+            const h16* mp = p.mask + (size_t)m * p.ldm + n;
+            h16x4 m0v = *(const h16x4*)mp, m1v = full ? *(const h16x4*)(mp + 4) : (h16x4){0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = m0v[j] > (h16)0.f ? v[j] : 0.f; v[4 + j] = m1v[j] > (h16)0.f ? v[4 + j] : 0.f; }
+          }
+          if (p.add) {
+            const h16* ap = p.add + (size_t)m * p.lda + n;
+            h16x4 a0 = *(const h16x4*)ap, a1 = full ? *(const h16x4*)(ap + 4) : (h16x4){0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += (float)a0[j]; v[4 + j] += (float)a1[j]; }
+          }
+          h16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (p.relu) v[j] = fmaxf(v[j], 0.f);
+            if (j < 4 || full) bad |= !(fabsf(v[j]) <= 65504.f);
+            o[j] = (h16)v[j];
+          }
+          h16* yp = p.y + (size_t)m * p.ldy + n;
+          if (full && (p.ldy & 7) == 0) *(h16x8*)yp = o;               // one 16-byte store per lane
+          else { *(h16x4*)yp = (h16x4){o[0], o[1], o[2], o[3]}; if (full) *(h16x4*)(yp + 4) = (h16x4){o[4], o[5], o[6], o[7]}; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  return bad;
+}
+
 #define WNT_BK 64
 #define WNT_PITCH (WNT_BK + 8)   // 144-byte rows: the 16-byte fragment reads of 16 consecutive rows fall into distinct 16-byte bank groups
 
@@ -143,64 +208,71 @@ __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
       }
     }
   }
-  // epilogue.  In the accumulators a lane holds ONE sample row (register r of block b = output column 32 b + 8 (r / 4) + 4 hf +
-  // r % 4): storing from there writes 8-byte pieces to 32 different rows per instruction (measured: the 1M x 512 output cost
-  // more than the GEMM).  Each wave therefore turns its 32 x CG fp32 block through LDS and then works row-contiguously: 8 lanes
-  // cover 64 columns of a row, so mask / addend loads and the fp16 stores are 16 bytes per lane, 128 bytes per row segment.
-  bool bad = false;
-  __syncthreads();                       // every wave is done with the operand tiles: the space becomes the transpose buffer
-  float* ep = (float*)smem_w + wave * (32 * EP);
+  const bool bad = wide_epilogue<BN, MT>(p, acc, smem_w, m0, n0, wave, lane);
+  if (bad && p.found_inf) *p.found_inf = 1;
+}
+
+// ---- plain-source variant with direct global -> LDS loads (global_load_lds_dwordx4: no staging registers, no ds_write pass).
+// The DMA writes lane i of an instruction at (wave-uniform base + 16 i), so a tile is stored LINEAR, [rows][64 halves], and the
+// bank-conflict swizzle sits on both sides instead: logical 16-byte chunk c of row r lives in slot c ^ (r & 7) -- the lane that
+// fills slot s of row r fetches chunk s ^ (r & 7) from global memory, the fragment read of chunk c goes to slot c ^ (r & 7).
+// Rows beyond M / N are clamped to the last valid row (their results are never stored).  Needs K % 64 == 0 and a plain A operand.
+template <int BN>
+__global__ __launch_bounds__(256) void k_wide_nt_dma(WideNT p) {
+  constexpr int BM = 128, NB = BN / 32, BK = 64, CG = BN < 64 ? BN : 64, EP = CG + 4;
+  constexpr int OPER = (BM + BN) * BK * 2, EPIL = 4 * 32 * EP * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_w[OPER > EPIL ? OPER : EPIL];
+  h16* Xs = (h16*)smem_w;
+  h16* Ws = Xs + BM * BK;
+  const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = (p.N + BN - 1) / BN, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mt_i = (jj / ntn) * 8 + xcd;
+  if (mt_i * BM >= p.M) return;
+  const int m0 = mt_i * BM, n0 = (jj % ntn) * BN;
+  f32x16 acc[1][NB];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int cg = 0; cg < BN / CG; ++cg) {
+    for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+  // per-lane source rows of this wave's DMA instructions (8 rows x 8 slots per instruction)
+  const int sub = lane >> 3, slot = lane & 7;
+  const h16* xsrc[4]; const h16* wsrc[NB];
 #pragma unroll
-      for (int bb = 0; bb < CG / 32; ++bb) {
-        const int b = cg * (CG / 32) + bb;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          *(f32x4*)(ep + c * EP + bb * 32 + rg * 8 + hf * 4) = (f32x4){acc[t][b][rg * 4], acc[t][b][rg * 4 + 1], acc[t][b][rg * 4 + 2], acc[t][b][rg * 4 + 3]};
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      constexpr int LPR = CG / 8;          // lanes per row (8 columns each)
-#pragma unroll
-      for (int it = 0; it < 32 / (64 / LPR); ++it) {
-        const int r = it * (64 / LPR) + lane / LPR, col = (lane % LPR) * 8;
-        const int m = m0 + (wave * MT + t) * 32 + r, n = n0 + cg * CG + col;
-        if (m < p.M && n < p.N) {
-          float v[8];
-          const f32x4 v0 = *(const f32x4*)(ep + r * EP + col), v1 = *(const f32x4*)(ep + r * EP + col + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
-          const bool full = n + 8 <= p.N;     // N is a multiple of 4: a row ends on a full or a half chunk
-          if (p.mask) {
-            const h16* mp = p.mask + (size_t)m * p.ldm + n;
-            h16x4 m0v = *(const h16x4*)mp, m1v = full ? *(const h16x4*)(mp + 4) : (h16x4){0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = m0v[j] > (h16)0.f ? v[j] : 0.f; v[4 + j] = m1v[j] > (h16)0.f ? v[4 + j] : 0.f; }
-          }
-          if (p.add) {
-            const h16* ap = p.add + (size_t)m * p.lda + n;
-            h16x4 a0 = *(const h16x4*)ap, a1 = full ? *(const h16x4*)(ap + 4) : (h16x4){0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] += (float)a0[j]; v[4 + j] += (float)a1[j]; }
-          }
-          h16x8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (p.relu) v[j] = fmaxf(v[j], 0.f);
-            if (j < 4 || full) bad |= !(fabsf(v[j]) <= 65504.f);
-            o[j] = (h16)v[j];
-          }
-          h16* yp = p.y + (size_t)m * p.ldy + n;
-          if (full && (p.ldy & 7) == 0) *(h16x8*)yp = o;               // one 16-byte store per lane
-          else { *(h16x4*)yp = (h16x4){o[0], o[1], o[2], o[3]}; if (full) *(h16x4*)(yp + 4) = (h16x4){o[4], o[5], o[6], o[7]}; }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + sub;
+    xsrc[i] = p.a.a1 + (size_t)min(m0 + row, p.M - 1) * p.a.lda1 + ((slot ^ (row & 7)) * 8);
   }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (wave * NB + i) * 8 + sub;
+    wsrc[i] = p.w + (size_t)min(n0 + row, p.N - 1) * p.ldw + ((slot ^ (row & 7)) * 8);
+  }
+  const int nkt = p.K / BK;
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(Xs + (wave * 4 + i) * 512), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(Ws + (wave * NB + i) * 512), 16, 0, 0);
+    __syncthreads();            // (the compiler drains vmcnt before the barrier: the tile has landed)
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int xr = wave * 32 + c;
+      const h16x8 xb = *(const h16x8*)(Xs + xr * BK + (((ks * 2 + hf) ^ (xr & 7)) * 8));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int wr_ = b * 32 + c;
+        const h16x8 wa = *(const h16x8*)(Ws + wr_ * BK + (((ks * 2 + hf) ^ (wr_ & 7)) * 8));
+        acc[0][b] = wmfma(wa, xb, acc[0][b]);
+      }
+    }
+    __syncthreads();            // the tile has been consumed
+  }
+  const bool bad = wide_epilogue<BN, 1>(p, acc, smem_w, m0, n0, wave, lane);
   if (bad && p.found_inf) *p.found_inf = 1;
 }
 
@@ -222,6 +294,14 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
   //  SIMD: 1.5 ms)
   static const int mt = getenv("ALN_WIDE_MT") ? atoi(getenv("ALN_WIDE_MT")) : 1;
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm + 7) / 8 * 8 * ((N + bn - 1) / bn))); };
+  static const bool no_dma = getenv("ALN_WIDE_NODMA") != nullptr;
+  if (!no_dma && a1 && !geo && !relu1 && p.K % 64 == 0 && ((uintptr_t)a1 & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+    if (N > 64) hipLaunchKernelGGL((k_wide_nt_dma<128>), grid(128, 128), dim3(256), 0, s, p);
+    else if (N > 32) hipLaunchKernelGGL((k_wide_nt_dma<64>), grid(128, 64), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wide_nt_dma<32>), grid(128, 32), dim3(256), 0, s, p);
+    ALN_CHECK_LAUNCH("wide_nt_dma");
+    return 0;
+  }
   if (mt == 2) {
     if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 2>), grid(256, 128), dim3(256), 0, s, p);
     else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 2>), grid(256, 64), dim3(256), 0, s, p);
