@@ -69,7 +69,9 @@ class TrainEngine:
         value = float(value)
         if value != self._lr:
             self._lr = value
-            self.state_f[1:2].fill_(value)
+            # a copy (DMA), not a kernel: harmless between graph replays even where autolabel_amd/__init__.py's workaround for the
+            # ROCm 7.2 packet-capture hazard is overridden
+            self.state_f[1:2].copy_(torch.tensor([value], dtype=torch.float32))
 
     def _gbuf(self, name, shape):
         t = self._g.get(name)
@@ -181,7 +183,7 @@ class TrainEngine:
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.state_i.copy_(sd['state_i']); self.state_f.copy_(sd['state_f'])
         self._lr = float(sd.get('lr', self._lr))
-        self.state_f[1:2].fill_(self._lr)
+        self.state_f[1:2].copy_(torch.tensor([self._lr], dtype=torch.float32))
 
 
 class GraphedStep:
