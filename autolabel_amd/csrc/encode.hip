@@ -498,6 +498,7 @@ struct BinParams {
   uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  DESC_START | DESC_COUNT | DESC_SHIFT
   int ntiles;
   int rows1, stride2; // rows [0, rows1) use p.rays_stride samples per ray, the rest stride2 (coarse + fine pass in one launch)
+  int dedupe_levels;  // levels below this run the in-wave run-dedupe
 };
 
 __device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
@@ -537,9 +538,13 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     uint32_t idx[8]; float w[8]; uint32_t cell[3];
     grid_corners(p.e.grid, l, xn, idx, w, cell);
     // run-dedupe along the ray (as in k_encode_bwd): adjacent lanes in the same cell are summed into the run head
-    uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
-    const bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
-    const unsigned long long hm = __ballot(head);
+    // (levels finer than b.dedupe_levels skip it: at 4096 cells per axis and beyond consecutive samples practically never share
+    //  a cell -- 8.1-8.3 of 8.4 M records survive -- so the compare / ballot / ladder step costs more than the records it saves)
+    const bool dd = l < b.dedupe_levels;
+    uint32_t q0 = cell[0], q1 = cell[1], q2 = cell[2];
+    if (dd) { q0 = __shfl_up(cell[0], 1); q1 = __shfl_up(cell[1], 1); q2 = __shfl_up(cell[2], 1); }
+    const bool head = !dd | (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
+    const unsigned long long hm = dd ? __ballot(head) : ~0ull;
     const int rid = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
     float v[16];
 #pragma unroll
@@ -745,6 +750,8 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
   const int ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
   b.p.level_lo = level_lo; b.p.level_hi = level_hi;
   b.d_enc = (const h16*)d_enc; b.ntiles = ntiles; b.rows1 = rows_pass1; b.stride2 = stride2 > 0 ? stride2 : 1;
+  static const int dedupe_levels = getenv("ALN_BIN_DEDUPE_LEVELS") ? atoi(getenv("ALN_BIN_DEDUPE_LEVELS")) : 8;
+  b.dedupe_levels = dedupe_levels;
   b.pool = (uint2*)ws;
   b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * BIN_CHUNK * sizeof(uint2));
   hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
