@@ -409,12 +409,16 @@ def main():
                 'traffic': pmc.get('encode_bwd_traffic_bytes_per_launch'), 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
                 'algorithmic_bytes_per_launch': sum(per_launch) / len(per_launch),
                 'records_per_launch': eng.pipe.binned_record_count(B * (eng.S1 + eng.S2)), 'record_bytes': 8,
+                'per_level_split': 'profiles/r02_probe_encode_bwd_binned.txt (scripts/dev/probe_encode_bwd_binned.py: per level and per level group, binned vs atomic)',
                 'atomic_requests_per_launch_round1_kernel': (pmc.get('atomic_kernel_requests_per_launch') or {}).get('TCC_ATOMIC_sum'),
                 'note': 'HIP events around the launch pair over %d launch-by-launch steps right after the timed region (the timed '
                         'region itself replays a hipGraph, which cannot carry events); phase 1 sorts fp16x2 (index, value) records '
                         'by 64 KB table slice in LDS and streams them out (8 B/record), phase 2 streams them back and accumulates '
                         'in 64-bit fixed point in LDS: no global atomics; traffic = FETCH_SIZE + WRITE_SIZE of both kernels from '
                         'profiles/r02_pmc_summary.json' % args.event_steps}
+            if res['roofline']['records_per_launch']:
+                res['roofline']['records_per_s'] = res['roofline']['records_per_launch'] / avg_s
+                res['roofline']['record_traffic_bytes_per_launch'] = 2 * 8 * res['roofline']['records_per_launch']   # written once, read once
         # second regime: the MLP heads against the dense fp16 MFMA peak.  Algorithmic FLOPs = 2 x MAC per
         # evaluated sample forward, 4 x MAC backward (data + weight gradients), unpadded widths; the forward recompute
         # inside the backward kernels is extra work, not counted.  Live rows of the color head are the device counter.
