@@ -318,6 +318,7 @@ def main():
         sync()
         eng.pipe.kernel_events = None
     live_rows = float(eng.pipe.ws.get('n_live', (1,), torch.int32).item())   # color-head rows of the last step (w > 1e-4)
+    records_evt = eng.pipe.binned_record_count(B * (eng.S1 + eng.S2))          # records of the last hash-grid backward (same state as the events)
 
     # render throughput: full 640x480 frames, 512 coarse steps, no upsampling (scripts/render.py:96-102)
     render_mrays, render_roof = None, None
@@ -408,7 +409,7 @@ def main():
                 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                 'traffic': pmc.get('encode_bwd_traffic_bytes_per_launch'), 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
                 'algorithmic_bytes_per_launch': sum(per_launch) / len(per_launch),
-                'records_per_launch': eng.pipe.binned_record_count(B * (eng.S1 + eng.S2)), 'record_bytes': 8,
+                'records_per_launch': records_evt, 'record_bytes': 8,
                 'per_level_split': 'profiles/r02_probe_encode_bwd_binned.txt (scripts/dev/probe_encode_bwd_binned.py: per level and per level group, binned vs atomic)',
                 'atomic_requests_per_launch_round1_kernel': (pmc.get('atomic_kernel_requests_per_launch') or {}).get('TCC_ATOMIC_sum'),
                 'note': 'HIP events around the launch pair over %d launch-by-launch steps right after the timed region (the timed '
