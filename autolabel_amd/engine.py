@@ -124,6 +124,12 @@ class TrainEngine:
                 allreduce_bucket(self.P.grad, a, b, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts)
             else:
                 allreduce_bucket(self.P.grad, a, b, self.pg)
+                if a == 0:
+                    # last bucket.  The binned scatter can still raise the overflow flag (a non-finite record) AFTER the flag
+                    # travelled with the MLP bucket: one more 4-byte MAX all-reduce keeps the ranks' skip decisions identical
+                    flag = self.state_i[2:3].to(torch.float32)
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+                    self.state_i[2:3] = (flag > 0).to(self.state_i.dtype)
 
     def all_reduce_grads(self):
         """Average every gradient over the ranks.  With overlap the buckets are already in flight on the communication
