@@ -312,14 +312,15 @@ class SceneDataset(BaseDataset):
         self.index_sampler.update(self.semantics)
 
     def _load_features(self, name):
-        """features.hdf 'features/<name>' [N,Hf,Wf,C] f16 (scripts/compute_feature_maps.py:82-118).  h5py is optional:
-        a sibling ``features_<name>.npy`` with the same array is accepted when it is absent."""
+        """features.hdf 'features/<name>' [N,Hf,Wf,C] f16 (autolabel/dataset.py:438-449; written by
+        scripts/compute_feature_maps.py:82-118).  Read by `utils.hdf5` (own HDF5 reader, pinned against h5py-written files);
+        a sibling ``features_<name>.npy`` with the same array takes precedence when present."""
         npy = os.path.join(self.scene.path, f'features_{name}.npy')
         if os.path.exists(npy):
             self._set_feature_maps(np.load(npy))
             return
-        import h5py
-        with h5py.File(os.path.join(self.scene.path, 'features.hdf'), 'r') as hdf:
+        from .utils import hdf5
+        with hdf5.File(os.path.join(self.scene.path, 'features.hdf'), 'r') as hdf:
             self._set_feature_maps(hdf[f'features/{name}'][:])
 
 

@@ -17,6 +17,7 @@
  */
 #ifndef AUTOLABEL_HIP_H
 #define AUTOLABEL_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -283,6 +284,10 @@ int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f
                   const int32_t* block_kind /*host*/, int32_t feature_loss, const int32_t* counts /*device, optional*/,
                   void* stream);
 int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
+
+/* ---- feature-map file: autolabel/dataset.py:438-441 reads features.hdf through h5py, whose LZF filter (id 32000,
+ * scripts/compute_feature_maps.py:85) wraps liblzf.  HOST pointers; returns the number of bytes produced or -1. */
+int64_t aln_lzf_decompress(const void* src /*host*/, size_t n_in, void* dst /*host*/, size_t n_out);
 
 #ifdef __cplusplus
 }
