@@ -227,10 +227,16 @@ __global__ void k_assemble_dsigma_out(const float* __restrict__ d_h0, const h16*
 #pragma unroll
     for (int j = 0; j < 16; ++j) g[j] = 0.f;
     if (d_semf_in) {
-      const h16* pf = d_semf_in + (size_t)r * semf_in_pad; const h16* po = d_semo_in + (size_t)r * semo_in_pad + D;
-      const h16x8 f0 = *(const h16x8*)pf, f1 = *(const h16x8*)(pf + 8), o0 = *(const h16x8*)po, o1 = *(const h16x8*)(po + 8);
+      const h16* pf = d_semf_in + (size_t)r * semf_in_pad;
+      const h16x8 f0 = *(const h16x8*)pf, f1 = *(const h16x8*)(pf + 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { g[j] = (float)f0[j] + (float)o0[j]; g[8 + j] = (float)f1[j] + (float)o1[j]; }
+      for (int j = 0; j < 8; ++j) { g[j] = (float)f0[j]; g[8 + j] = (float)f1[j]; }
+      if (d_semo_in) {   // (NULL: the fused semantic backward has already added the skip-connection part into d_semf_in)
+        const h16* po = d_semo_in + (size_t)r * semo_in_pad + D;
+        const h16x8 o0 = *(const h16x8*)po, o1 = *(const h16x8*)(po + 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g[j] += (float)o0[j]; g[8 + j] += (float)o1[j]; }
+      }
     }
     const int ci = cidx_row ? cidx_row[r] : r;
     if (ci >= 0) {
@@ -253,9 +259,9 @@ extern "C" int aln_assemble_grads(const float* d_h0, const void* d_semf_in, int3
                                   int32_t semo_in_pad, int32_t D, const void* d_color_in, int32_t color_in_pad,
                                   const int32_t* cidx_row, int32_t rows, int32_t G, void* d_sigma_out, int32_t* found_inf,
                                   void* stream) {
-  ALN_REQUIRE(d_h0 && d_color_in && d_sigma_out && (!d_semf_in || d_semo_in), "assemble_grads: NULL pointer");
+  ALN_REQUIRE(d_h0 && d_color_in && d_sigma_out && (d_semf_in || !d_semo_in), "assemble_grads: NULL pointer");
   if (rows <= 0) return 0;
-  ALN_REQUIRE(G <= 15 && color_in_pad >= 32 && color_in_pad % 8 == 0 && (!d_semf_in || (semf_in_pad == 16 && D % 8 == 0 && semo_in_pad >= D + 16)),
+  ALN_REQUIRE(G <= 15 && color_in_pad >= 32 && color_in_pad % 8 == 0 && (!d_semf_in || (semf_in_pad == 16 && (!d_semo_in || (D % 8 == 0 && semo_in_pad >= D + 16)))),
               "assemble_grads: unsupported widths");
   hipLaunchKernelGGL(k_assemble_dsigma_out, dim3(aln_grid_for((int64_t)rows, 256)), dim3(256), 0, (hipStream_t)stream, d_h0,
                      (const h16*)d_semf_in, semf_in_pad, (const h16*)d_semo_in, semo_in_pad, D, (const h16*)d_color_in,

@@ -27,7 +27,8 @@ class AlnEncDesc(C.Structure):
 
 
 class AlnMlpDesc(C.Structure):
-    _fields_ = [('in_pad', i32), ('hidden', i32), ('out_pad', i32), ('n_hidden', i32), ('wf', vp), ('wb', vp), ('wr', vp)]
+    _fields_ = [('in_pad', i32), ('hidden', i32), ('out_pad', i32), ('n_hidden', i32), ('wf', vp), ('wb', vp), ('wr', vp), ('dw_ws', vp),
+                ('dw_ws_bytes', i64)]
 
 
 class AlnFrames(C.Structure):
@@ -69,11 +70,14 @@ _SIGS = {
     'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),
     'aln_mlp_repack_all': (i32, [i32, vp, vp, vp]),
     'aln_mlp_has_recompute': (i32, [i32, i32, i32, i32]),
+    'aln_mlp_dw_ws_bytes': (i64, [i32, i32, i32, i32]),
     'aln_mlp_frag_halves': (i64, [i32, i32, i32, i32, i32]),
     'aln_mlp_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     'aln_sem_heads_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 6),
+    'aln_sem_heads_bwd_fused_ok': (i32, [vp, vp, i32]),
+    'aln_sem_heads_bwd_fused': (i32, [vp] * 6 + [i32] * 7 + [vp] * 5),
     'aln_sigma_act': (i32, [vp, i32, vp, vp]),
     'aln_compact_live': (i32, [vp, i32, f32, vp, vp, vp, vp]),
     'aln_color_fwd': (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),

@@ -90,8 +90,12 @@ class Params:
             wf = torch.zeros(nf, dtype=torch.float16, device=device)
             wb = torch.zeros(nb, dtype=torch.float16, device=device)
             wr = torch.zeros((nr + 7) // 8 * 8, dtype=torch.float16, device=device)
-            self.frags[k] = (wf, wb, wr)
-            self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr())
+            # per-block weight-gradient partial sums of the recompute backward (reduced in a fixed order: no atomics)
+            nws = H.lib().aln_mlp_dw_ws_bytes(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
+            ws = torch.empty(nws // 4, dtype=torch.float32, device=device)
+            self.frags[k] = (wf, wb, wr, ws)
+            self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(),
+                                         ws.data_ptr(), nws)
 
     def init_(self, seed=0):
         """tcnn default initialisation: grid U(-1e-4,1e-4), MLP weights xavier-uniform per padded [out,in] matrix."""
@@ -534,7 +538,13 @@ class HipPipeline:
         self._k('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), hp(c['ch1']), hp(c['ch2']), H.ptr(d_cout),
                 M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream(), tag=('color', c['n_live']))
         d_fin = d_oin = None
-        if sem_fused:
+        if sem_fused and H.lib().aln_sem_heads_bwd_fused_ok(C.byref(P.descs['semf']), C.byref(P.descs['semo']), L.D):
+            # both heads in ONE kernel; d_fin already holds the skip-connection (semantic_out input) part of d(geo_feat)
+            d_fin = g('d_semf_in', (M, nets['semf'].in_pad), f16)
+            self._k('aln_sem_heads_bwd_fused', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']),
+                    H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_fin),
+                    gp('semf'), gp('semo'), fi, H.stream(), tag=('sem', M))
+        elif sem_fused:
             fs, os_ = nets['semf'], nets['semo']
             d_oin, d_fin = g('d_semo_in', (M, os_.in_pad), f16), g('d_semf_in', (M, fs.in_pad), f16)
             self._k('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 2
+#define ALN_ABI_VERSION 3
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -56,11 +56,15 @@ typedef struct {
   const void* wf;   /* forward fragments  */
   const void* wb;   /* backward (transposed) fragments */
   const void* wr;   /* row-major fp16 copy, pitch in+8 (recompute backward); may be NULL */
+  void* dw_ws;      /* ABI 3: scratch for the backward's per-block weight-gradient partial sums, >= aln_mlp_dw_ws_bytes();
+                       NULL (or too small): the blocks add into dW with fp32 atomics instead (slower, order-dependent) */
+  int64_t dw_ws_bytes;
 } AlnMlpDesc;
 
 const char* aln_last_error(void);
 int aln_abi_version(void);
 int aln_grid_desc_init(AlnGridDesc* g); /* host */
+int64_t aln_mlp_dw_ws_bytes(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden); /* host: size of AlnMlpDesc.dw_ws */
 
 /* ---- ray generation: autolabel/dataset.py:17-37 (_compute_direction), :182-242
  * (_next_train), :244-266 (_get_test), on device-resident frames. */
@@ -187,6 +191,14 @@ int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void
                       const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t rows,
                       int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf, float* dW_semo, int32_t* found_inf,
                       void* stream);
+/* The same backward as ONE kernel (ABI 3): five-layer register chain, f recomputed, nothing but sigma_out / w_row / the per-ray
+ * gradients read.  d_geo [rows, 16] fp16 = d(semantic_features input) + geo_feat columns of d(semantic_out input): pass it to
+ * aln_assemble_grads as d_semf_in with d_semo_in = NULL.  aln_sem_heads_bwd_fused_ok() tells whether the shapes are covered
+ * (D = 64, semantic_features 16->64->64->64, semantic_out 80->64->{16,32,48,64}). */
+int aln_sem_heads_bwd_fused_ok(const AlnMlpDesc* semf, const AlnMlpDesc* semo, int32_t D);
+int aln_sem_heads_bwd_fused(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const float* w_row,
+                            const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t rows,
+                            int32_t D, int32_t G, void* d_geo, float* dW_semf, float* dW_semo, int32_t* found_inf, void* stream);
 
 /* ---- head plumbing: autolabel/models.py:175-188 (sigma = trunc_exp(h0), geo_feat = h[1:]), :190-220 (boolean-mask
  * gather + SH(dir) ++ geo_feat), :248-256 (cat[relu(f), geo_feat]) and the matching gradient assembly */

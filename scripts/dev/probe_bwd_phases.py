@@ -46,7 +46,8 @@ buf = (C.c_longlong * 64)()
 lib.aln_debug_read_phases(buf, 0)
 us = e0.elapsed_time(e1) / reps * 1e3
 ntiles = rows // 128
-nblk = min(ntiles, torch.cuda.get_device_properties(0).multi_processor_count)
+occ = 2 if (m.hidden == 64 and os.environ.get('ALN_MLP_OCC2', '1') != '0') else 1   # 64-wide heads: two blocks per CU
+nblk = min(ntiles, occ * torch.cuda.get_device_properties(0).multi_processor_count)
 iters = (ntiles + nblk - 1) // nblk * reps
 print(f'{head}: {us:.0f} us per launch, {iters // reps} tiles per block')
 names = ['tail(d_in/dW_first)', 'wait B0', 'load issue', 'wait B1', 'fwd recompute', 'wait B2', 'last layer', 'wait B3',

@@ -329,7 +329,7 @@ MLP_SHAPES = [('sigma', 48, 128, 16, 2), ('color', 32, 128, 16, 2), ('semf', 16,
               ('semo_c32', 80, 64, 32, 1)]
 
 
-def _mlp_setup(H, n_in, hid, n_out, nh, seed=0):
+def _mlp_setup(H, n_in, hid, n_out, nh, seed=0, dw_ws=True):
     g = torch.Generator().manual_seed(seed)
     shapes = [(hid, n_in)] + [(hid, hid)] * (nh - 1) + [(n_out, hid)]
     Ws = [((torch.rand(o, i, generator=g) * 2 - 1) * (6.0 / (o + i)) ** 0.5) for o, i in shapes]
@@ -340,14 +340,17 @@ def _mlp_setup(H, n_in, hid, n_out, nh, seed=0):
     wb = torch.zeros(nb, dtype=torch.float16, device='cuda')
     wr = torch.zeros((H.lib().aln_mlp_rowmajor_halves(n_in, hid, n_out, nh) + 7) // 8 * 8, dtype=torch.float16, device='cuda')
     H.call('aln_mlp_repack', H.ptr(flat), n_in, hid, n_out, nh, H.ptr(wf), H.ptr(wb), H.ptr(wr), H.stream())
-    desc = H.AlnMlpDesc(n_in, hid, n_out, nh, wf.data_ptr(), wb.data_ptr(), wr.data_ptr())
-    return Ws, desc, (flat, wf, wb, wr)
+    nws = H.lib().aln_mlp_dw_ws_bytes(n_in, hid, n_out, nh) if dw_ws else 0
+    ws = torch.empty(max(nws // 4, 1), device='cuda')      # per-block weight-gradient partial sums (None: atomic flush)
+    desc = H.AlnMlpDesc(n_in, hid, n_out, nh, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(), ws.data_ptr() if dw_ws else None, nws)
+    return Ws, desc, (flat, wf, wb, wr, ws)
 
 
+@pytest.mark.parametrize('dw_ws', [True, False], ids=['dw_slabs', 'dw_atomics'])
 @pytest.mark.parametrize('name,n_in,hid,n_out,nh', MLP_SHAPES)
-def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh):
+def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh, dw_ws):
     rows = 1000  # ragged: not a multiple of 32
-    Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh)
+    Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh, dw_ws=dw_ws)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(rows, n_in, generator=g).half()
     xo = x.float().requires_grad_(True)
@@ -387,6 +390,32 @@ def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh):
     assert flag.item() == 0
     assert (d_in2.float() - d_in.float()).abs().max().item() <= 2e-3 * gi.abs().max().item() + 1e-5, name
     assert (dW2 - dW).abs().max().item() <= 2e-3 * dW.abs().max().item() + 1e-5, name
+    if dw_ws:   # slabs + fixed-order reduction: the weight gradient is bit-reproducible, and it accumulates into dW (+=)
+        dW3 = dW2.clone()
+        H.call('aln_mlp_bwd', C.byref(desc), H.ptr(xd), None, None, H.ptr(dod), rows, None, None, None, H.ptr(d_in2), H.ptr(dW3),
+               H.ptr(flag), H.stream())
+        assert torch.equal(dW3, 2 * dW2), name
+
+
+def test_mlp_recompute_backward_many_tiles_slabs_match_atomics(H):
+    """70 000 rows (547 tiles: every one of the 256 / 512 blocks owns tiles, ragged tail): slab flush vs atomic flush."""
+    rows = 70000
+    for (n_in, hid, n_out, nh) in [(48, 128, 16, 2), (16, 64, 64, 2), (80, 64, 16, 1)]:
+        res = []
+        for dw_ws in (True, False):
+            Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh, dw_ws=dw_ws)
+            g = torch.Generator().manual_seed(11)
+            x = torch.randn(rows, n_in, generator=g).half().cuda()
+            d_out = (torch.randn(rows, n_out, generator=g) * 0.05).half().cuda()
+            d_in = torch.zeros(rows, n_in, dtype=torch.float16, device='cuda')
+            dW = torch.zeros(sum(w.numel() for w in Ws), device='cuda')
+            flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+            H.call('aln_mlp_bwd', C.byref(desc), H.ptr(x), None, None, H.ptr(d_out), rows, None, None, None, H.ptr(d_in), H.ptr(dW),
+                   H.ptr(flag), H.stream())
+            assert flag.item() == 0
+            res.append((d_in.clone(), dW.clone()))
+        assert torch.equal(res[0][0], res[1][0])
+        assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-4 * res[1][1].abs().max().item()
 
 
 def test_mlp_device_row_count_and_inf_flag(H):
@@ -510,6 +539,78 @@ def test_fused_semantic_heads_forward_is_bit_identical_to_two_launches(H):
             os.environ.pop('ALN_SEM_FWD_UNFUSED', None)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0].abs().max() > 0 and outs[0][1].abs().max() > 0
+
+
+@pytest.mark.parametrize('N,S1,S2,Ccls,out_pad,G', [(37, 24, 20, 7, 16, 15), (41, 128, 0, 20, 32, 15), (300, 64, 64, 40, 48, 7),
+                                                     (64, 128, 128, 64, 64, 15)])
+def test_fused_semantic_heads_backward_matches_two_launches_and_fp32(H, N, S1, S2, Ccls, out_pad, G):
+    """k_sem_bwd_fused5 (both heads, one five-layer chain, f recomputed) against the two-launch recompute path on the same
+    inputs, and against fp32 autograd of models.py:248-256 (half_sim oracle MLPs): d(geo_feat), all five weight gradients."""
+    Wf, dF, keepF = _mlp_setup(H, 16, 64, 64, 2, seed=3)
+    Wo, dO, keepO = _mlp_setup(H, 80, 64, out_pad, 1, seed=4)
+    assert H.lib().aln_sem_heads_bwd_fused_ok(C.byref(dF), C.byref(dO), 64) == 0      # off by default (slower than two launches)
+    os.environ['ALN_SEM_BWD_FUSED5'] = '1'
+    try:
+        assert H.lib().aln_sem_heads_bwd_fused_ok(C.byref(dF), C.byref(dO), 64) == 1
+        _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G)
+    finally:
+        os.environ.pop('ALN_SEM_BWD_FUSED5', None)
+
+
+def _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G):
+    rows = N * (S1 + S2)
+    g = torch.Generator().manual_seed(9)
+    sigma_out = torch.randn(rows, 16, generator=g).half().cuda()
+    w_row = (torch.rand(rows, generator=g) * (torch.rand(rows, generator=g) > 0.3)).cuda()          # 30 % dead samples
+    g_sem = (torch.randn(N, Ccls, generator=g) * 0.1).cuda()
+    g_feat = (torch.randn(N, 64, generator=g) * 0.1).cuda()
+    feat = torch.zeros(rows, 64, dtype=torch.float16, device='cuda')
+    logits = torch.zeros(rows, out_pad, dtype=torch.float16, device='cuda')
+    H.call('aln_sem_heads_fwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, G, H.ptr(feat), H.ptr(logits), H.stream())
+    nf, no = sum(w.numel() for w in Wf), sum(w.numel() for w in Wo)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    # two launches
+    d_oin = torch.zeros(rows, 80, dtype=torch.float16, device='cuda')
+    d_fin = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
+    dWf2, dWo2 = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
+    H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf2), H.ptr(dWo2), H.ptr(flag), H.stream())
+    want_geo = d_fin.float() + d_oin[:, 64:80].float()
+    # one launch
+    d_geo = torch.full((rows, 16), 7.0, dtype=torch.float16, device='cuda')
+    dWf, dWo = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
+    H.call('aln_sem_heads_bwd_fused', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_geo), H.ptr(dWf), H.ptr(dWo), H.ptr(flag), H.stream())
+    assert flag.item() == 0
+    tol = lambda a: 4e-3 * a.abs().max().item() + 1e-6      # fp16 intermediates rounded at different points
+    assert (d_geo.float() - want_geo).abs().max().item() <= tol(want_geo)
+    assert (dWf - dWf2).abs().max().item() <= tol(dWf2) and (dWo - dWo2).abs().max().item() <= tol(dWo2)
+    # fp32 autograd through the half_sim oracle MLPs
+    x = sigma_out.cpu().float()
+    geo = torch.cat([x[:, 1:1 + G], torch.ones(rows, 16 - G)], 1).requires_grad_(True)
+    Wfo = [w.clone().requires_grad_(True) for w in Wf]
+    Woo = [w.clone().requires_grad_(True) for w in Wo]
+    f = O.mlp_forward(geo, Wfo, half_sim=True)
+    lo = O.mlp_forward(torch.cat([torch.relu(f), geo], 1), Woo, half_sim=True)
+    ray = torch.cat([torch.arange(N).repeat_interleave(S1), torch.arange(N).repeat_interleave(S2)])
+    wr = w_row.cpu()
+    loss = (lo[:, :Ccls] * (wr[:, None] * g_sem.cpu()[ray])).sum() + (f * (wr[:, None] * g_feat.cpu()[ray])).sum()
+    loss.backward()
+    assert (d_geo.cpu().float() - geo.grad).abs().max().item() <= 1e-2 * geo.grad.abs().max().item() + 1e-5
+    o = 0
+    for w in Wfo:
+        assert (dWf[o:o + w.numel()].cpu().view_as(w) - w.grad).abs().max().item() <= 1e-2 * w.grad.abs().max().item() + 1e-5
+        o += w.numel()
+    o = 0
+    for w in Woo:
+        assert (dWo[o:o + w.numel()].cpu().view_as(w) - w.grad).abs().max().item() <= 1e-2 * w.grad.abs().max().item() + 1e-5
+        o += w.numel()
+    # overflow watch: an inf per-ray gradient must raise the flag
+    g_bad = g_feat.clone(); g_bad[0, 3] = float('inf')
+    w2 = w_row.clone(); w2[0] = 1.0
+    H.call('aln_sem_heads_bwd_fused', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(w2), H.ptr(g_sem), H.ptr(g_bad),
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_geo), H.ptr(dWf), H.ptr(dWo), H.ptr(flag), H.stream())
+    assert flag.item() == 1
 
 
 # ------------------------------------------------------------------ occupancy-grid marching (csrc/march.hip vs oracle/march_oracle.py)
