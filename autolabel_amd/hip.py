@@ -10,6 +10,8 @@ import torch
 
 from .build import LIB
 
+LIB = os.environ.get('ALN_HIP_LIB') or LIB   # (dev builds of scripts/dev/ only; the product library is the in-tree one)
+
 ALN_MAX_LEVELS = 16
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
