@@ -243,7 +243,8 @@ struct RowSrc {
   const float* w_row; const float* g;   // DLOGITS / DSEMF_OUT: per-row weight, per-ray output gradient [N, gw]
   int N, S1, S2, D, G, gw;
   const int* idx;             // COLOR_IN: live_idx (compact row -> sample row) or NULL; b = sigma_out, g = directions
-};                            //           (gw = 0: one per ray [N,3], gw = 1: one per sample row [rows,3])
+  int fold_geo;               // DSEMF_OUT (as dL/dout of semantic_features): the backward adds b[row][D .. D+16) -- the geo_feat
+};                            //           columns of d(semantic_out input) -- into its d_in rows (one d(geo_feat) tensor leaves)                            //           (gw = 0: one per ray [N,3], gw = 1: one per sample row [rows,3])
 __device__ inline h16x8 geo_chunk(const h16* sigma_out, size_t row, int j0, int G) {
   // [geo_feat (G), 1, 1, ...] features j0..j0+7 ; geo_feat[g] = sigma_out[row][1 + g].  j0 is 0 or 8: both cases use
   // compile-time element indices (a runtime-indexed local array would live in scratch memory)
@@ -1214,6 +1215,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
       PT_STAMP(12) __syncthreads(); PT_STAMP(13)   // B6
       if (d_in) {
         constexpr int UJ = (IB > 1) ? 1 : RPW;     // wide inputs: one sub-tile at a time (RPW x IB x 16 accumulators would not fit)
+        constexpr bool FOLD = DM == SRC_DSEMF_OUT && IN == 16;
+        h16x4 skip[RPW][2] = {};
+        if constexpr (FOLD) {   // requested ahead of the MFMAs below: the lines were just read by the tile load, L2 hits
+          if (ds.fold_geo) {
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) {
+              const int row = r0 + srow0 + 32 * u;
+              if (row < rows) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) skip[u][q] = *(const h16x4*)(ds.b + (size_t)row * ds.ldb + ds.D + 8 * q + 4 * hf);
+              }
+            }
+          }
+        }
         f32x16 o[UJ][IB];
         if constexpr (UJ == RPW) chain_layer_m<RPW, IB, KS>(o, [&](int ib, int ks) { return tr_frag_chained(vW0, 32 * ib, ks, lane); }, [&](int u, int ks) { return p[u][ks]; });
 #pragma unroll
@@ -1229,7 +1244,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
                 if (f < IN) {
                   h16x4 v;
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) v[r] = (h16)o[UJ == RPW ? u : 0][ib][4 * q + r];
+                  for (int r = 0; r < 4; ++r) {
+                    float ov = o[UJ == RPW ? u : 0][ib][4 * q + r];
+                    if constexpr (FOLD) ov += (float)skip[u][q < 2 ? q : 0][r];
+                    v[r] = (h16)ov;
+                  }
                   nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
                   *(h16x4*)(d_in + (size_t)row * IN + f) = v;
                 }
@@ -1823,16 +1842,18 @@ extern "C" int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
 extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat,
                                  const float* w_row, const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2,
                                  int32_t C, int32_t rows, int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf,
-                                 float* dW_semo, int32_t* found_inf, void* stream) {
+                                 float* dW_semo, int32_t fold_geo, int32_t* found_inf, void* stream) {
   ALN_REQUIRE(semf && semo && sigma_out && feat && w_row && g_sem && g_feat && d_semo_in && d_semf_in,
               "sem_heads_bwd: NULL pointer");
+  ALN_REQUIRE(!fold_geo || (semf->in_pad == 16 && aln_mlp_has_recompute(semf->in_pad, semf->hidden, semf->out_pad, semf->n_hidden)),
+              "sem_heads_bwd: fold_geo needs the 16-wide recompute backward of semantic_features");
   hipStream_t s = (hipStream_t)stream;
   RowSrc xo{}; xo.mode = SRC_SEMO_IN; xo.a = (const h16*)feat; xo.lda = D; xo.b = (const h16*)sigma_out; xo.ldb = 16; xo.G = G; xo.D = D;
   RowSrc go{}; go.mode = SRC_DLOGITS; go.w_row = w_row; go.g = g_sem; go.gw = C; go.N = N; go.S1 = S1; go.S2 = S2 > 0 ? S2 : 1;
   if (int rc = mlp_bwd_recomp_src(semo, xo, go, rows, nullptr, d_semo_in, dW_semo, found_inf, s)) return rc;
   RowSrc xf{}; xf.mode = SRC_SEMF_IN; xf.a = (const h16*)sigma_out; xf.lda = 16; xf.G = G; xf.D = D;
   RowSrc gf{}; gf.mode = SRC_DSEMF_OUT; gf.a = (const h16*)feat; gf.lda = D; gf.b = (const h16*)d_semo_in; gf.ldb = semo->in_pad;
-  gf.w_row = w_row; gf.g = g_feat; gf.gw = D; gf.N = N; gf.S1 = S1; gf.S2 = S2 > 0 ? S2 : 1;
+  gf.w_row = w_row; gf.g = g_feat; gf.gw = D; gf.N = N; gf.S1 = S1; gf.S2 = S2 > 0 ? S2 : 1; gf.D = D; gf.fold_geo = fold_geo;
   return mlp_bwd_recomp_src(semf, xf, gf, rows, nullptr, d_semf_in, dW_semf, found_inf, s);
 }
 

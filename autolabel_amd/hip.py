@@ -77,7 +77,7 @@ _SIGS = {
     'aln_mlp_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     'aln_sem_heads_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
-    'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 6),
+    'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 4 + [i32] + [vp] * 2),
     'aln_sem_heads_bwd_fused_ok': (i32, [vp, vp, i32]),
     'aln_sem_heads_bwd_fused': (i32, [vp] * 6 + [i32] * 7 + [vp] * 5),
     'aln_sigma_act': (i32, [vp, i32, vp, vp]),

@@ -549,7 +549,8 @@ class HipPipeline:
             d_oin, d_fin = g('d_semo_in', (M, os_.in_pad), f16), g('d_semf_in', (M, fs.in_pad), f16)
             self._k('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),
                     H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_oin), H.ptr(d_fin),
-                    gp('semf'), gp('semo'), fi, H.stream(), tag=('sem', M))
+                    gp('semf'), gp('semo'), 1, fi, H.stream(), tag=('sem', M))
+            d_oin = None     # fold_geo = 1: its geo_feat columns are already inside d_fin
         elif sem and c.get('sem_wide'):
             d_fin, d_oin = self.wide_sem_bwd(c['sigma_out'], M, c['feat'], c['wide_saved'], d_logits, d_feat, lambda n, shp: g(n, shp, f16))
         elif sem:

@@ -189,8 +189,10 @@ int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void
                       void* feat, void* logits, void* stream);
 int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat, const float* w_row,
                       const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t rows,
-                      int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf, float* dW_semo, int32_t* found_inf,
-                      void* stream);
+                      int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf, float* dW_semo,
+                      int32_t fold_geo /* ABI 3: 1 = d_semf_in rows also take the geo_feat columns of d_semo_in, so that
+                                          aln_assemble_grads needs d_semf_in only (d_semo_in = NULL there) */,
+                      int32_t* found_inf, void* stream);
 /* The same backward as ONE kernel (ABI 3): five-layer register chain, f recomputed, nothing but sigma_out / w_row / the per-ray
  * gradients read.  d_geo [rows, 16] fp16 = d(semantic_features input) + geo_feat columns of d(semantic_out input): pass it to
  * aln_assemble_grads as d_semf_in with d_semo_in = NULL.  aln_sem_heads_bwd_fused_ok() tells whether the shapes are covered

@@ -574,8 +574,14 @@ def _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G):
     d_fin = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
     dWf2, dWo2 = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
     H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf2), H.ptr(dWo2), H.ptr(flag), H.stream())
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf2), H.ptr(dWo2), 0, H.ptr(flag), H.stream())
     want_geo = d_fin.float() + d_oin[:, 64:80].float()
+    # fold_geo = 1: the same sum leaves the second launch directly (one rounding instead of two)
+    d_fin_f = torch.zeros_like(d_fin); dWf3, dWo3 = torch.zeros_like(dWf2), torch.zeros_like(dWo2)
+    H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, H.ptr(flag), H.stream())
+    assert (d_fin_f.float() - want_geo).abs().max().item() <= 2e-3 * want_geo.abs().max().item() + 1e-6
+    assert torch.equal(dWf3, dWf2) and torch.equal(dWo3, dWo2)
     # one launch
     d_geo = torch.full((rows, 16), 7.0, dtype=torch.float16, device='cuda')
     dWf, dWo = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
