@@ -170,13 +170,20 @@ class _Object:
         else:
             raise Hdf5FormatError(f'no object header at {addr}')
 
+    MAX_BLOCKS = 4096      # continuation blocks followed per object header (a corrupt file can chain them in a cycle)
+
     def _read_v1(self, addr):
         r = self.f._r
         nmsg, size = r.u(addr + 2, 2), r.u(addr + 8, 4)
         blocks = [(addr + 16, size)]
+        seen = 0
         while blocks and len(self.messages) < nmsg:
+            seen += 1
+            if seen > self.MAX_BLOCKS:
+                raise Hdf5FormatError('object header: too many continuation blocks')
             p, n = blocks.pop(0)
             end = p + n
+            end = min(end, len(r.buf))
             while p + 8 <= end and len(self.messages) < nmsg:
                 mtype, msize, mflags = r.u(p, 2), r.u(p + 2, 2), r.u(p + 4, 1)
                 self._add(mtype, mflags, p + 8, msize, blocks)
@@ -197,9 +204,13 @@ class _Object:
         p += w
         hdr = 4 + (2 if flags & 0x04 else 0)
         blocks = [(p, size)]
+        seen = 0
         while blocks:
+            seen += 1
+            if seen > self.MAX_BLOCKS:
+                raise Hdf5FormatError('object header: too many continuation blocks')
             p, n = blocks.pop(0)
-            end = p + n                                       # the chunk's checksum follows `end`
+            end = min(p + n, len(r.buf))                      # the chunk's checksum follows `end`
             while p + hdr <= end:
                 mtype, msize, mflags = r.u(p, 1), r.u(p + 1, 2), r.u(p + 3, 1)
                 self._add(mtype, mflags, p + hdr, msize, blocks, v2=True)
@@ -262,7 +273,9 @@ class _Object:
         def name(o):
             return bytes(r.buf[data + o:r.buf.find(b'\0', data + o)]).decode('utf-8')
 
-        def walk(node):
+        def walk(node, depth=0):
+            if depth > 32 or len(out) > 1 << 20:
+                raise Hdf5FormatError('group B-tree: too deep / too many entries')
             if r.buf[node:node + 4] == b'SNOD':
                 n = r.u(node + 6, 2)
                 p = node + 8
@@ -275,7 +288,7 @@ class _Object:
             n = r.u(node + 6, 2)
             p = node + 8 + 2 * r.O + r.L                     # past key 0
             for _ in range(n):
-                walk(r.off(p))
+                walk(r.off(p), depth + 1)
                 p += r.O + r.L
 
         walk(btree)
@@ -489,8 +502,10 @@ class Dataset:
                     element(p + i * esize, coords[pg * per_page + i])
             p += n * esize + 4                               # each page carries its own checksum
 
-    def _btree1(self, node, out):
+    def _btree1(self, node, out, depth=0):
         r = self.file._r
+        if depth > 32:
+            raise Hdf5FormatError('chunk B-tree: too deep')
         if r.buf[node:node + 4] != b'TREE' or r.u(node + 4, 1) != 1:
             raise Hdf5FormatError('chunk B-tree node')
         level, n = r.u(node + 5, 1), r.u(node + 6, 2)
@@ -504,14 +519,16 @@ class Dataset:
             if level == 0:
                 out[tuple(o // c for o, c in zip(offs, self.chunks))] = (child, size, mask)
             else:
-                self._btree1(child, out)
+                self._btree1(child, out, depth + 1)
             p += ksize + r.O
 
     # -- data -----------------------------------------------------------------------------------------------------------
     def _decode_chunk(self, addr, size, mask):
         r = self.file._r
-        buf = bytes(r.buf[addr:addr + size])
         raw = self._chunk_bytes()
+        if addr + size > len(r.buf) or size > 64 * raw + 4096:
+            raise Hdf5FormatError(f'chunk at {addr} (+{size} B) lies outside the file')
+        buf = bytes(r.buf[addr:addr + size])
         for i in reversed(range(len(self._filters))):
             if mask & (1 << i):
                 continue
@@ -533,6 +550,11 @@ class Dataset:
     def read(self, start=0, stop=None):
         """Rows ``start:stop`` of the leading axis as a new native-endian array."""
         r = self.file._r
+        nbytes = int(np.prod(self.shape, dtype=np.float64)) * self._dt.size if self.shape else self._dt.size
+        if nbytes > 1024 * len(r.buf) + (1 << 20):            # (LZF / gzip of real feature maps: 1-3x; constant fill: < 1000x)
+            raise Hdf5FormatError(f'dataset shape {self.shape} cannot come from a {len(r.buf)}-byte file')
+        if self.chunks is not None and (len(self.chunks) != len(self.shape) or any(c <= 0 for c in self.chunks)):
+            raise Hdf5FormatError(f'chunk shape {self.chunks} does not fit dataset shape {self.shape}')
         if not self.shape:
             kind, a, n = self._layout
             return np.frombuffer(bytes(r.buf[a:a + self._dt.size]), self.dtype)[0]

@@ -137,3 +137,37 @@ def test_load_features_from_hdf(tmp_path):
     assert np.array_equal(h.features, want.reshape(N, H * W, C))
     assert (h.feature_width, h.feature_height, h.feature_dim) == (W, H, C)
     assert np.array_equal(h._scale_to_feature_xy(np.array([[31.0, 23.0]])), [[W * 31 // 32, H * 23 // 24]])
+
+
+def test_corrupt_files_raise_cleanly(tmp_path):
+    """Random byte damage in the metadata region: the reader returns the data, or raises an ordinary exception -- it must not hang,
+    loop, or allocate without bound (cycles of continuation blocks / B-tree nodes, absurd shapes)."""
+    import time
+    ok = (hdf5.Hdf5FormatError, KeyError, NotImplementedError, IndexError, ValueError, OverflowError, zlib_error(), TypeError,
+          AssertionError, MemoryError, UnicodeDecodeError)
+    rng = np.random.default_rng(7)
+    n_raised = n_read = 0
+    for name in ('ref_latest.hdf', 'ref_earliest.hdf', 'gzip_latest.hdf', 'paged_latest.hdf'):
+        data = bytearray(open(os.path.join(HERE, name), 'rb').read())
+        for trial in range(60):
+            bad = bytearray(data)
+            for _ in range(int(rng.integers(1, 6))):
+                pos = int(rng.integers(8, min(len(bad), 6000)))         # superblock tail, object headers, B-tree / index nodes
+                bad[pos] = int(rng.integers(0, 256))
+            p = tmp_path / f'{name}.{trial}'
+            p.write_bytes(bytes(bad))
+            t = time.time()
+            try:
+                with hdf5.File(str(p)) as f:
+                    for key in f['features'].keys():
+                        f['features'][key][:]
+                n_read += 1
+            except ok:
+                n_raised += 1
+            assert time.time() - t < 20.0
+    assert n_raised > 10 and n_read > 10
+
+
+def zlib_error():
+    import zlib
+    return zlib.error
