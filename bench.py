@@ -441,7 +441,7 @@ def main():
             flops += (2.0 if n.endswith('_fwd') else 4.0) * mac[head] * r
             t_mlp += e[0].elapsed_time(e[1]) * 1e-3
         if t_mlp > 0:
-            res['roofline_mlp'] = {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + k_mlp_bwd_recomp8 (all heads)' + (' + k_wide_nt / k_wide_tn' if L.sem_wide else ''), 'bound': 'mfma',
+            res['roofline_mlp'] = {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + k_mlp_bwd_recomp8 + k_dw_reduce (all heads)' + (' + k_wide_nt / k_wide_tn' if L.sem_wide else ''), 'bound': 'mfma',
                                    'achieved': flops / t_mlp / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
                                    'frac': flops / t_mlp / 1e12 / 2500.0, 'us_per_step': t_mlp * 1e6 / args.event_steps,
                                    'algorithmic_gflop_per_step': flops / 1e9 / args.event_steps, 'live_color_rows': live_rows}
