@@ -37,7 +37,7 @@ def parse():
     p.add_argument('--feature-dim', type=int, default=64)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
-    p.add_argument('--render-frames', type=int, default=2)
+    p.add_argument('--render-frames', type=int, default=6)
     p.add_argument('--event-steps', type=int, default=20, help='launch-by-launch steps with HIP events (roofline); 0 = skip')
     p.add_argument('--quality-steps', type=int, default=1500, help='total optimizer steps before the held-out metrics; 0 = skip')
     p.add_argument('--no-march', action='store_true', help='skip the occupancy-grid marching leg (second config)')
