@@ -1314,26 +1314,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
   }
 }
 
-// dW[e] += sum over the blocks' slabs, fixed order (4 interleaved partial sums per element, then one add)
-__global__ __launch_bounds__(1024) void k_dw_reduce(const float* __restrict__ ws, int nparts, int n, float* __restrict__ dW) {
-  __shared__ float part[4][256];
-  const int t = threadIdx.x & 255, g = threadIdx.x >> 8, e = blockIdx.x * 256 + t;
+// dW[e] += sum over the blocks' slabs, fixed order: 16 interleaved partial sums per element (thread (e, g) adds slabs g, g + 16, ...
+// with all its loads in flight at once), folded pairwise in LDS.  (4 partial sums and 256 elements per block took 6.5 us per
+// head, all of it load latency: 64 dependent-in-batches loads per thread.)
+#define DWR_G 16
+#define DWR_E 64
+__global__ __launch_bounds__(DWR_G * DWR_E) void k_dw_reduce(const float* __restrict__ ws, int nparts, int n, float* __restrict__ dW) {
+  __shared__ float part[DWR_G][DWR_E];
+  const int t = threadIdx.x % DWR_E, g = threadIdx.x / DWR_E, e = blockIdx.x * DWR_E + t;
   float acc = 0.f;
   if (e < n) {
     int p = g;
 #pragma unroll 1
-    for (; p + 28 < nparts; p += 32) {
-      float v[8];
+    for (; p + 15 * DWR_G < nparts; p += 16 * DWR_G) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(p + 4 * u) * n + e];
+      for (int u = 0; u < 16; ++u) v[u] = ws[(size_t)(p + DWR_G * u) * n + e];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 16; ++u) acc += v[u];
     }
-    for (; p < nparts; p += 4) acc += ws[(size_t)p * n + e];
+    for (; p < nparts; p += DWR_G) acc += ws[(size_t)p * n + e];
   }
   part[g][t] = acc;
   __syncthreads();
-  if (g == 0 && e < n) dW[e] += (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+#pragma unroll
+  for (int h = DWR_G / 2; h > 0; h >>= 1) {
+    if (g < h) part[g][t] += part[g + h][t];
+    __syncthreads();
+  }
+  if (g == 0 && e < n) dW[e] += part[0][t];
 }
 
 template <int IN, int HID, int OUT, int NHID, bool OCC2, int RPW>
@@ -1373,7 +1382,7 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
 #undef LAUNCH_SRC
   ALN_CHECK_LAUNCH("mlp_bwd_recomp");
   if (ws) {
-    hipLaunchKernelGGL(k_dw_reduce, dim3((n_w + 255) / 256), dim3(1024), 0, s, ws, g, n_w, dW);
+    hipLaunchKernelGGL(k_dw_reduce, dim3((n_w + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, ws, g, n_w, dW);
     ALN_CHECK_LAUNCH("dw_reduce");
   }
   return 0;
@@ -1887,8 +1896,8 @@ static int launch_sem_bwd_fused5(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
                      dfs, rows, (h16*)d_geo, dW_f, dW_o, ws_f, ws_o, found_inf);
   ALN_CHECK_LAUNCH("sem_bwd_fused5");
   if (slabs) {
-    hipLaunchKernelGGL(k_dw_reduce, dim3(((int)nwf + 255) / 256), dim3(1024), 0, s, ws_f, g, (int)nwf, dW_f);
-    hipLaunchKernelGGL(k_dw_reduce, dim3(((int)nwo + 255) / 256), dim3(1024), 0, s, ws_o, g, (int)nwo, dW_o);
+    hipLaunchKernelGGL(k_dw_reduce, dim3(((int)nwf + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, ws_f, g, (int)nwf, dW_f);
+    hipLaunchKernelGGL(k_dw_reduce, dim3(((int)nwo + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, ws_o, g, (int)nwo, dW_o);
     ALN_CHECK_LAUNCH("dw_reduce");
   }
   return 0;
