@@ -1670,8 +1670,11 @@ __global__ __launch_bounds__(512) void k_sem_bwd_fused5(const h16* __restrict__ 
 
 // ---------------------------------------------------------------- launchers
 static int mlp_grid(int rows) {
+  // blocks per launch of the forward / data-gradient kernels (256 threads, weights in LDS): ALN_MLP_FWD_GRID, default 3 per CU
+  // (the 128-wide heads' fragment images are 48-52 KB and the kernels use <= 168 VGPRs, so three blocks fit a CU)
+  static const int cap = getenv("ALN_MLP_FWD_GRID") ? atoi(getenv("ALN_MLP_FWD_GRID")) : 768;
   int tiles = (rows + 127) / 128;
-  int g = tiles < 512 ? tiles : 512;
+  int g = tiles < cap ? tiles : cap;
   return g < 1 ? 1 : g;
 }
 
