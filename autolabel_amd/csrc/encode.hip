@@ -510,19 +510,15 @@ __device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
 
 __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   __shared__ uint2 sorted[BIN_CHUNK];                        // 32 KB
-  __shared__ uint32_t gtile[ALN_MAX_LEVELS * (BIN_TILE + 1)]; // level-major d_enc grid part, 32 KB
   __shared__ uint32_t cnt[2][BIN_MAX_SLICES], base[BIN_MAX_SLICES], total_s, vmax_s[2], shift_s;
   const EncParams& p = b.p;
   const int tid = threadIdx.x, lane = tid & 63;
   const int tile = blockIdx.x;
   const int row0 = tile * BIN_TILE;
-  const int rows_here = min(BIN_TILE, p.rows - row0);
-  const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq, nl = p.e.grid.n_levels;
-  // d_enc grid columns of the tile -> LDS, level-major (reads below: lane = sample, conflict-free)
-  for (int i = tid; i < rows_here * nl; i += BIN_TILE) {
-    const int r = i / nl, l = i - r * nl;
-    gtile[l * (BIN_TILE + 1) + r] = *(const uint32_t*)(b.d_enc + (size_t)(row0 + r) * pad + fdim + 2 * l);
-  }
+  const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq;
+  // The row's gradient word of a level (fp16x2) is read straight from d_enc, one level ahead: its 64 grid bytes are one or two
+  // cache lines that stay in L1 / L2 over the 16 levels.  (Staging all levels of the tile in LDS first cost 32 KB per block and
+  // held the kernel at two blocks per CU; without it three fit -- the kernel is bound by LDS and barrier latency, not by loads.)
   if (tid < 2 * BIN_MAX_SLICES) cnt[0][tid] = 0;
   if (tid < 2) vmax_s[tid] = 0u;
   const int row = row0 + tid;
@@ -530,11 +526,15 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   float x[3] = {0, 0, 0}, xn[3];
   if (valid) bin_row_position(b, row, x);
   normalize_pos(x, p.e.bound, true, xn);
+  const uint32_t* const grow = (const uint32_t*)(b.d_enc + (size_t)(valid ? row : 0) * pad + fdim);
+  uint32_t gw_next = (valid && p.level_lo < p.level_hi) ? grow[p.level_lo] : 0u;
   __syncthreads();
   for (int l = p.level_lo; l < p.level_hi; ++l) {
     const int par = l & 1;
-    float g0 = 0.f, g1 = 0.f;
-    if (valid) { const uint32_t gw = gtile[l * (BIN_TILE + 1) + tid]; const h16x2 g = *(const h16x2*)&gw; g0 = (float)g[0]; g1 = (float)g[1]; }
+    const uint32_t gw = gw_next;
+    if (valid && l + 1 < p.level_hi) gw_next = grow[l + 1];
+    const h16x2 g = *(const h16x2*)&gw;
+    const float g0 = (float)g[0], g1 = (float)g[1];
     uint32_t idx[8]; float w[8]; uint32_t cell[3];
     grid_corners(p.e.grid, l, xn, idx, w, cell);
     // run-dedupe along the ray (as in k_encode_bwd): adjacent lanes in the same cell are summed into the run head
