@@ -89,14 +89,18 @@ def test_encode_backward_is_the_adjoint_of_forward_at_full_size(H):
     for a, b in ((0, h), (h, N)):
         H.call('aln_encode_bwd', C.byref(e), H.ptr(ro[a:b]), H.ptr(rd[a:b]), H.ptr(z[a * S:b * S]), None, (b - a) * S, S,
                H.ptr(d_enc[a * S:b * S]), H.ptr(g2), H.stream())
-    assert torch.equal(g2 != 0, grad != 0)
+    # (no exact comparison of the touched-entry patterns here: with fp32 atomics a sum of opposite contributions can round to
+    #  exactly 0.0 in one arrival order and to 1 ulp in another -- seen once in three runs of 2^20 rows; the tolerance covers it,
+    #  and the small-size kernel tests hold the touched-entry sets against the oracle)
     assert (g2 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
+    assert ((g2 != 0) != (grad != 0)).sum().item() <= 1e-5 * grad.numel()
     # level groups (the data-parallel launch order) tile the same scatter
     g3 = torch.zeros_like(grad)
     for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
         H.call('aln_encode_bwd_levels', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(d_enc), H.ptr(g3), lo, hi,
                H.stream())
-    assert torch.equal(g3 != 0, grad != 0) and (g3 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
+    assert (g3 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
+    assert ((g3 != 0) != (grad != 0)).sum().item() <= 1e-5 * grad.numel()
 
 
 def test_binned_scatter_is_the_adjoint_of_the_gather_at_full_size(H):
