@@ -100,7 +100,10 @@ def test_training_through_marched_samples_converges(graph):
     with torch.inference_mode():
         out = model.eval().render(t['rays_o'], t['rays_d'], t['direction_norms'], staged=True, perturb=False)
     psnr = -10 * math.log10(((out['image'] - t['pixels'].view_as(out['image'])) ** 2).mean().item())
-    assert psnr > 11.0, psnr      # (400 steps in a box 12x the cube: the dense path reaches the same)
+    # 400 steps in a box 12x the cube (the dense path reaches the same).  The fit is not bit-reproducible (compaction order, fp32
+    # flush of the dense grid levels) and lands in one of two basins: 20 runs gave 11.2 - 12.5 dB (14 runs) or 14.5 - 16.6 dB
+    # (scripts/dev/debug_march_psnr.py); an untrained model renders the white background, ~6 dB.
+    assert psnr > 10.0, psnr
     # the grid and the bitfield are part of the checkpoint (upstream: density_grid / density_bitfield buffers)
     sd = model.state_dict()
     assert 'density_grid' in sd and 'density_bitfield' in sd and (sd['density_grid'] > 0).any()
