@@ -102,8 +102,8 @@ def test_training_through_marched_samples_converges(graph):
     psnr = -10 * math.log10(((out['image'] - t['pixels'].view_as(out['image'])) ** 2).mean().item())
     # 400 steps in a box 12x the cube (the dense path reaches the same).  The fit is not bit-reproducible (compaction order, fp32
     # flush of the dense grid levels) and lands in one of two basins: 20 runs gave 11.2 - 12.5 dB (14 runs) or 14.5 - 16.6 dB
-    # (scripts/dev/debug_march_psnr.py); an untrained model renders the white background, ~6 dB.
-    assert psnr > 10.0, psnr
+    # (scripts/dev/debug_march_psnr.py); after one step the same render scores 9.9 dB.
+    assert psnr > 10.5, psnr
     # the grid and the bitfield are part of the checkpoint (upstream: density_grid / density_bitfield buffers)
     sd = model.state_dict()
     assert 'density_grid' in sd and 'density_bitfield' in sd and (sd['density_grid'] > 0).any()
