@@ -242,7 +242,8 @@ def test_training_reduces_loss_on_cube_scene():
         if i % 50 == 0 or i == 299:
             losses.append(eng.terms.tolist())
     assert all(math.isfinite(v) for t in losses for v in t)
-    assert losses[-1][0] < 0.25 * losses[0][0], f'rgb loss did not drop: {losses[0]} -> {losses[-1]}'
+    # (12 runs, scripts/dev/debug_dense_psnr.py: ratio 0.206 - 0.231, PSNR 16.5 - 17.7 dB)
+    assert losses[-1][0] < 0.3 * losses[0][0], f'rgb loss did not drop: {losses[0]} -> {losses[-1]}'
     assert losses[-1][1] < 0.5 * losses[0][1], 'depth loss did not drop'
     # rendering a training view reproduces it
     t = frames.get_test(0)
