@@ -489,7 +489,8 @@ extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const fl
 #define BIN_SLICE (1 << BIN_SLICE_LOG2)
 #define BIN_MAX_SLICES 64       // 2^19 entries / 8192
 #define BIN_CHUNK (BIN_TILE * 8)   // records per (tile, level) chunk of the pool
-#define BIN_MAX_SHIFT 12        // largest per-tile up-scaling of the fp16 record values (2^12)
+#define BIN_MAX_SHIFT 11        // largest per-tile up-scaling of the fp16 record values (2^11: every scaled record stays below 2^51
+                                // accumulator units, which the double-precision decode of phase 2 needs)
 
 struct BinParams {
   EncParams p;
@@ -617,7 +618,7 @@ struct AccParams {
 // fp16 record value -> exact 64-bit fixed point in units of 2^-24 (the smallest fp16 denormal): every fp16 is an integer
 // < 2^40 in that unit, so 2^23 records can be summed without overflow and the sum is EXACT and order-independent.
 // (ds_add_f32 runs at 0.33 lanes/clk/CU on gfx950, ds_add_u64 at 4.6: profiles/r02_probe_lds_atomics.txt.)
-// Records scaled up by 2^e (e <= BIN_MAX_SHIFT, phase 1) are shifted left by BIN_MAX_SHIFT - e: the accumulator unit is 2^-36,
+// Records scaled up by 2^e (e <= BIN_MAX_SHIFT, phase 1) are shifted left by BIN_MAX_SHIFT - e: the accumulator unit is 2^-(24 + BIN_MAX_SHIFT),
 // |value| < 2^16 * 2^36 = 2^52 per record, so 2^11 records of the largest fp16 magnitude still fit.
 __device__ inline long long fx_from_half(h16 h) {
   const float a = (float)h * 16777216.0f;              // exact: 11-bit significand, |a| < 2^40
@@ -625,7 +626,14 @@ __device__ inline long long fx_from_half(h16 h) {
   const float lo = a - hi * 1048576.0f;                // exact, same sign, |lo| < 2^20
   return ((long long)(int)hi << 20) + (long long)(int)lo;
 }
-#define FX_UNIT (1.0 / 68719476736.0)   // 2^-36
+// The same value through double precision: h * 2^e (e = 24 + BIN_MAX_SHIFT - shift) is an integer below 2^51 in magnitude, exact
+// in a double; adding 1.5 * 2^52 parks it, two's complement, in the low mantissa bits (v_cvt_f64_f32, v_ldexp_f64, v_add_f64
+// and one 64-bit subtract instead of the float split + two 64-bit shifts: the add side of phase 2 is VALU-bound).
+__device__ inline long long fx_from_half_d(h16 h, int e) {
+  const double z = ldexp((double)(float)h, e) + 6755399441055744.0;
+  return __double_as_longlong(z) - 0x4338000000000000LL;
+}
+#define FX_UNIT (1.0 / (double)(1ull << (24 + BIN_MAX_SHIFT)))   // 2^-(24 + BIN_MAX_SHIFT)
 
 #define ACC_THREADS 1024
 #define ACC_LPR (BIN_TILE / 256)  // 8-byte loads per lane and run held in registers: covers the average run of a hashed level twice
@@ -648,8 +656,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   auto add = [&](uint2 r, uint32_t up) {   // up = BIN_MAX_SHIFT - shift of the run's tile
     const h16x2 hv = *(const h16x2*)&r.y;
     bad |= (r.y & 0x7C00u) == 0x7C00u || (r.y & 0x7C000000u) == 0x7C000000u;
-    atomicAdd((unsigned long long*)&acc[2 * r.x], (unsigned long long)(fx_from_half(hv[0]) << up));
-    atomicAdd((unsigned long long*)&acc[2 * r.x + 1], (unsigned long long)(fx_from_half(hv[1]) << up));
+    atomicAdd((unsigned long long*)&acc[2 * r.x], (unsigned long long)fx_from_half_d(hv[0], 24 + (int)up));
+    atomicAdd((unsigned long long*)&acc[2 * r.x + 1], (unsigned long long)fx_from_half_d(hv[1], 24 + (int)up));
   };
   if (K > 1) {
     // coarse levels (few slices, long runs of hundreds of records per tile): one tile per wave at a time, four loads per lane
