@@ -112,3 +112,51 @@ extern "C" int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream
   ALN_CHECK_LAUNCH("cast_f16");
   return 0;
 }
+
+// ---- fp16 wire format of the data-parallel gradient exchange (autolabel_amd/parallel.py): the hash-grid gradient block is
+// loss-scaled, i.e. already sized for fp16 (tcnn keeps these gradients in fp16 altogether), so it crosses xGMI as halves:
+// out = fp16(g * mul) with mul = 1 / world (the SUM over the ranks is then the average and cannot overflow unless an input did),
+// and back: g = fp32(in), raising found_inf for a non-finite element (the step is skipped and the scale backs off, exactly as
+// for an fp16 overflow anywhere else).  8 elements per thread, 16-byte accesses on the fp16 side.
+__global__ void k_grad_pack_f16(const float* __restrict__ g, size_t n, float mul, h16* __restrict__ out) {
+  const size_t n8 = n / 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = *(const float4*)(g + 8 * i), b = *(const float4*)(g + 8 * i + 4);
+    h16x8 v;
+    v[0] = (h16)(a.x * mul); v[1] = (h16)(a.y * mul); v[2] = (h16)(a.z * mul); v[3] = (h16)(a.w * mul);
+    v[4] = (h16)(b.x * mul); v[5] = (h16)(b.y * mul); v[6] = (h16)(b.z * mul); v[7] = (h16)(b.w * mul);
+    *(h16x8*)(out + 8 * i) = v;
+  }
+  if (blockIdx.x == 0) for (size_t i = 8 * n8 + threadIdx.x; i < n; i += blockDim.x) out[i] = (h16)(g[i] * mul);
+}
+__global__ void k_grad_unpack_f16(const h16* __restrict__ in, size_t n, float* __restrict__ g, int* __restrict__ found_inf) {
+  const size_t n8 = n / 8;
+  bool bad = false;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const h16x8 v = *(const h16x8*)(in + 8 * i);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { f[j] = (float)v[j]; bad |= !(fabsf(f[j]) <= 65504.f); }
+    *(float4*)(g + 8 * i) = make_float4(f[0], f[1], f[2], f[3]);
+    *(float4*)(g + 8 * i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+  if (blockIdx.x == 0) for (size_t i = 8 * n8 + threadIdx.x; i < n; i += blockDim.x) { const float f = (float)in[i]; bad |= !(fabsf(f) <= 65504.f); g[i] = f; }
+  if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
+}
+extern "C" int aln_grad_pack_f16(const float* grad, int64_t n, float mul, void* out_f16, void* stream) {
+  ALN_REQUIRE(grad && out_f16 && n >= 0, "grad_pack_f16: bad arguments");
+  ALN_REQUIRE(((uintptr_t)grad & 15) == 0 && ((uintptr_t)out_f16 & 15) == 0, "grad_pack_f16: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_grad_pack_f16, dim3(aln_grid_for(n / 8 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, grad, (size_t)n, mul, (h16*)out_f16);
+  ALN_CHECK_LAUNCH("grad_pack_f16");
+  return 0;
+}
+extern "C" int aln_grad_unpack_f16(const void* in_f16, int64_t n, float* grad, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(grad && in_f16 && n >= 0, "grad_unpack_f16: bad arguments");
+  ALN_REQUIRE(((uintptr_t)grad & 15) == 0 && ((uintptr_t)in_f16 & 15) == 0, "grad_unpack_f16: buffers must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_grad_unpack_f16, dim3(aln_grid_for(n / 8 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const h16*)in_f16, (size_t)n, grad,
+                     found_inf);
+  ALN_CHECK_LAUNCH("grad_unpack_f16");
+  return 0;
+}

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
 // two neighbouring levels = 4 MB of table), every wave writes its 64 samples' features of a level as one
 // coalesced 256-byte store into a per-level plane, and a second, streaming kernel assembles the row-major [rows, enc_pad]
 // operand (frequency features, planes, ones) the MLP reads.
-#define ENC_LG 1   // levels per phase (measured: 1 -> 135 us, 2 -> 140 us, 4 -> 202 us per 512 K samples; ALN_ENC_LG overrides)
+#define ENC_LG 1   // levels per phase (measured: 1 -> 135 us, 2 -> 140 us, 4 -> 202 us per 512 K samples)
 __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.x / nblk, b = blockIdx.x % nblk;
@@ -278,7 +278,7 @@ extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16,
   if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
   ALN_REQUIRE(e->use_grid && table_f16 && planes_ws && enc_out, "encode_fwd_phased: needs a grid encoding, its table and the plane workspace");
   if (rows == 0) return 0;
-  static const int lg = getenv("ALN_ENC_LG") ? atoi(getenv("ALN_ENC_LG")) : ENC_LG;
+  const int lg = ENC_LG;
   const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
   hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
   ALN_CHECK_LAUNCH("encode_grid_phased");
@@ -286,84 +286,6 @@ extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16,
                      (const h16x2*)planes_ws, (h16*)enc_out);
   ALN_CHECK_LAUNCH("encode_assemble");
   return 0;
-}
-
-// Backward: scatter-add of w_c * dL/dfeat into the fp32 gradient table.
-//
-// Measured on MI355X (scripts/dev/probe_atomics*.hip): a global float atomic costs one request per distinct
-// 32-byte sector per wave-instruction (~21 G requests/s chip-wide, independent of scope, XCD locality or table size);
-// lanes hitting the SAME address serialize (14 G lane-ops/s), lanes sharing a sector coalesce (8 lanes/sector: 166 G
-// lane-ops/s).  Hence:
-//  1. run-dedupe: consecutive samples of a ray fall into the same cell at coarse levels (and, for the importance
-//     samples, far into the fine levels); a wave-level segmented reduction sums them before anything is issued;
-//  2. sector-aware issue: the 16 (corner, feature) adds of one cell are issued by 16 ADJACENT lanes ordered
-//     [corner bit0 = x][feature], so the 2 features (8 B) and, when x is even, the x-pair (idx ^ 1: the x prime is 1)
-//     share one 16-byte span -- 4..8 requests per cell instead of 16.
-__global__ __launch_bounds__(256) void k_encode_bwd(EncParams p, const h16* __restrict__ d_enc, float* __restrict__ grad) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int pad = p.e.enc_pad;
-  const int fdim = 3 * 2 * p.e.n_freq;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  h16* tile = (h16*)smem;                                              // [ENC_TILE][pad]
-  float* sval = (float*)(smem + ((ENC_TILE * pad * 2 + 15) & ~15)) + wave * (64 * 16);   // per wave [64 runs][16]
-  uint32_t* sidx = (uint32_t*)((float*)(smem + ((ENC_TILE * pad * 2 + 15) & ~15)) + 4 * 64 * 16) + wave * (64 * 8);
-  const int ntiles = (p.rows + ENC_TILE - 1) / ENC_TILE;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    int rows_here = min(ENC_TILE, p.rows - t * ENC_TILE);
-    int n16 = rows_here * pad / 8;
-    const uint4* src = (const uint4*)(d_enc + (size_t)t * ENC_TILE * pad);
-    uint4* dst = (uint4*)tile;
-    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
-    __syncthreads();
-    const int row = t * ENC_TILE + lane;
-    const bool valid = row < p.rows;
-    float x[3] = {0, 0, 0}, xn[3];
-    if (valid) row_position(p, row, x);
-    normalize_pos(x, p.e.bound, true, xn);
-    for (int l = p.level_lo + wave; l < p.level_hi; l += 4) {
-      float g0 = 0.f, g1 = 0.f;
-      if (valid) { h16x2 g = *(h16x2*)&tile[lane * pad + fdim + 2 * l]; g0 = (float)g[0]; g1 = (float)g[1]; }
-      uint32_t idx[8]; float w[8];
-      uint32_t cell[3];
-      grid_corners(p.e.grid, l, xn, idx, w, cell);
-      // a run = adjacent lanes in the same cell (same base corner => same 8 indices)
-      // (shuffles are evaluated unconditionally: no short-circuit around cross-lane ops)
-      uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
-      bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
-      unsigned long long hm = __ballot(head);
-      int rid = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
-      float v[16];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { v[2 * c] = w[c] * g0; v[2 * c + 1] = w[c] * g1; }
-      const int nruns = __popcll(hm);
-      if (nruns < 64) {  // segmented sum towards the run head
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          int r2 = __shfl_down(rid, off);
-          bool take = (lane + off < 64) && (r2 == rid);
-#pragma unroll
-          for (int k = 0; k < 16; ++k) { float o = __shfl_down(v[k], off); v[k] += take ? o : 0.f; }
-        }
-      }
-      if (head) {
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) *(float4*)&sval[rid * 16 + k] = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
-#pragma unroll
-        for (int c = 0; c < 8; c += 4) *(uint4*)&sidx[rid * 8 + c] = make_uint4(idx[c], idx[c + 1], idx[c + 2], idx[c + 3]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      float* gt = grad + 2 * (size_t)p.e.grid.offset[l];
-      const int nops = nruns * 16;
-      for (int op = lane; op < nops; op += 64) {
-        int r = op >> 4, k = op & 15;
-        float val = sval[r * 16 + k];
-        if (val != 0.f) unsafeAtomicAdd(gt + 2 * (size_t)sidx[r * 8 + (k >> 1)] + (k & 1), val);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-  }
 }
 
 static int fill_params(EncParams& p, const AlnEncDesc* e, const void* table, const float* rays_o, const float* rays_d,
@@ -408,7 +330,7 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
   p.xyz = nullptr; p.cell_G = G; p.cell0 = cell0; p.cell_seed = seed; p.cell_step = step; p.cell_step_dev = step_dev;
   if (rows == 0) return 0;
   if (e->use_grid && planes_ws) {
-    static const int lg = getenv("ALN_ENC_LG") ? atoi(getenv("ALN_ENC_LG")) : ENC_LG;
+    const int lg = ENC_LG;
     const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
     hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
     ALN_CHECK_LAUNCH("encode_grid_phased");
@@ -425,57 +347,19 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
   return 0;
 }
 
-// dev probe (scripts/dev/probe_encode_fwd_levels.py): forward for levels [level_lo, level_hi) only (other columns stay unwritten)
-extern "C" int aln_dev_encode_fwd_levels(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
-                                         const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* enc_out,
-                                         int32_t level_lo, int32_t level_hi, void* stream) {
-  EncParams p;
-  if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
-  if (rows == 0) return 0;
-  p.level_lo = level_lo; p.level_hi = level_hi;
-  int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
-  int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
-  size_t lds = (size_t)ENC_TILE * e->enc_pad * sizeof(h16);
-  hipLaunchKernelGGL(k_encode_fwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (h16*)enc_out);
-  ALN_CHECK_LAUNCH("encode_fwd_levels");
-  return 0;
-}
-
-extern "C" int aln_encode_bwd_levels(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
-                                     const float* xyz, int32_t rows, int32_t rays_stride, const void* d_enc,
-                                     float* grad_table, int32_t level_lo, int32_t level_hi, void* stream) {
-  EncParams p;
-  if (int rc = fill_params(p, e, nullptr, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
-  if (rows == 0 || !e->use_grid) return 0;
-  ALN_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= (int)e->grid.n_levels, "encode_bwd: level range [%d, %d)", level_lo,
-              level_hi);
-  if (level_lo == level_hi) return 0;
-  p.level_lo = level_lo; p.level_hi = level_hi;
-  int ntiles = (rows + ENC_TILE - 1) / ENC_TILE;
-  int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
-  size_t lds = (((size_t)ENC_TILE * e->enc_pad * sizeof(h16) + 15) & ~(size_t)15) + 4 * 64 * (16 * sizeof(float) + 8 * sizeof(uint32_t));
-  hipLaunchKernelGGL(k_encode_bwd, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, (const h16*)d_enc, grad_table);
-  ALN_CHECK_LAUNCH("encode_bwd");
-  return 0;
-}
-
-extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
-                              const float* xyz, int32_t rows, int32_t rays_stride, const void* d_enc,
-                              float* grad_table, void* stream) {
-  ALN_REQUIRE(e, "encode_bwd: NULL descriptor");
-  return aln_encode_bwd_levels(e, rays_o, rays_d, z, xyz, rows, rays_stride, d_enc, grad_table, 0, (int32_t)e->grid.n_levels, stream);
-}
-
 // ---------------------------------------------------------------- binned backward (no global atomics)
-// The atomic scatter above is bound by the L2 atomic units (~21 G 64-byte requests/s, profiles/r02_probe_atomics.txt): every
-// (sample, level) costs ~4 requests although each 64-byte chunk of a 4 MB level table is hit ~64 times per step.  The binned
-// backward turns the scatter into two streaming passes:
+// A scatter through global fp32 atomics is bound by the L2 atomic units (~21 G 64-byte requests/s, profiles/r02_probe_atomics.txt):
+// every (sample, level) costs ~4 requests although each 64-byte chunk of a 4 MB level table is hit ~64 times per step (round 1's
+// kernel; it also made every run order-dependent).  The binned backward turns the scatter into two streaming passes:
 //   phase 1 (k_encode_bwd_bin): a block owns a tile of 512 consecutive sample rows.  Per level it computes the run-deduped
-//     (index, w * dL/dfeat) records exactly as the atomic kernel does, counting-sorts them in LDS by table SLICE (8192 entries =
-//     64 KB of fp32 accumulators) and writes the sorted records as ONE contiguous run into the tile's fixed chunk of the record
-//     pool, plus one (start, count) descriptor per slice.  Records are 8 bytes: slot within the slice | fp16x2 value.
+//     (index, w * dL/dfeat) records, counting-sorts them in LDS by table SLICE (1/64 of the level: 8192 entries for a hashed
+//     level, 64 for the 16^3 level) and writes the sorted records as ONE contiguous run into the tile's fixed chunk of the record
+//     pool, plus one (start, count, shift) descriptor per slice.  Records are 8 bytes: slot within the slice | fp16x2 value.
 //   phase 2 (k_encode_bwd_accum): a block owns one (level, slice); it streams that slice's runs of every tile, accumulates
-//     them with LDS atomics in fp32 and adds the slice to the gradient table with plain coalesced stores.
+//     them with 64-bit integer LDS atomics (exact, order-independent) and adds the slice to the gradient table with plain
+//     coalesced stores.  Every level has the same 64-way split, so no entry is ever shared by two blocks: the whole gradient
+//     table is bit-reproducible run to run (round 2 split the tiles of the two coarsest levels over blocks that met in fp32
+//     global atomics).
 // HBM traffic: 8 B written + 8 B read per record (<= 8 x 16 records per sample) instead of 4 atomic requests per (sample, level).
 #ifndef BIN_TILE
 #define BIN_TILE 512            // sample rows per phase-1 block (= threads: lane = sample, so runs along a ray dedupe in-wave); -DBIN_TILE=1024
@@ -485,12 +369,20 @@ extern "C" int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const fl
 #define DESC_START(q) ((q) & 0x1FFFu)
 #define DESC_COUNT(q) (((q) >> 13) & 0x3FFFu)
 #define DESC_SHIFT(q) ((q) >> 27)
-#define BIN_SLICE_LOG2 13       // table entries per slice (x 2 features x 4 B = 64 KB LDS in phase 2)
+#define BIN_SLICE_LOG2 13       // largest slice: 8192 table entries (x 2 features x 8 B = 128 KB of LDS accumulators in phase 2)
 #define BIN_SLICE (1 << BIN_SLICE_LOG2)
-#define BIN_MAX_SLICES 64       // 2^19 entries / 8192
+#define BIN_MAX_SLICES 64       // slices per level (2^19 entries / 8192)
 #define BIN_CHUNK (BIN_TILE * 8)   // records per (tile, level) chunk of the pool
-#define BIN_MAX_SHIFT 11        // largest per-tile up-scaling of the fp16 record values (2^11: every scaled record stays below 2^51
-                                // accumulator units, which the double-precision decode of phase 2 needs)
+#define BIN_MAX_SHIFT 11        // largest per-tile up-scaling of the fp16 record values
+#define BIN_DEDUPE_LEVELS 8     // levels below this run the in-wave run-dedupe (finer: consecutive samples practically never share a cell)
+
+// entries per slice of a level = 2^slice_log2: the level is cut into at most BIN_MAX_SLICES slices of at most BIN_SLICE entries
+static inline int bin_slice_log2(uint32_t size) {
+  int lg = 0;
+  while ((1ull << lg) < size) ++lg;
+  lg -= 6;
+  return lg < 0 ? 0 : (lg > BIN_SLICE_LOG2 ? BIN_SLICE_LOG2 : lg);
+}
 
 struct BinParams {
   EncParams p;
@@ -499,7 +391,7 @@ struct BinParams {
   uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  DESC_START | DESC_COUNT | DESC_SHIFT
   int ntiles;
   int rows1, stride2; // rows [0, rows1) use p.rays_stride samples per ray, the rest stride2 (coarse + fine pass in one launch)
-  int dedupe_levels;  // levels below this run the in-wave run-dedupe
+  uint8_t slice_log2[ALN_MAX_LEVELS];
 };
 
 __device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
@@ -532,16 +424,17 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   __syncthreads();
   for (int l = p.level_lo; l < p.level_hi; ++l) {
     const int par = l & 1;
+    const uint32_t sl = b.slice_log2[l], slot_mask = (1u << sl) - 1u;
     const uint32_t gw = gw_next;
     if (valid && l + 1 < p.level_hi) gw_next = grow[l + 1];
     const h16x2 g = *(const h16x2*)&gw;
     const float g0 = (float)g[0], g1 = (float)g[1];
     uint32_t idx[8]; float w[8]; uint32_t cell[3];
     grid_corners(p.e.grid, l, xn, idx, w, cell);
-    // run-dedupe along the ray (as in k_encode_bwd): adjacent lanes in the same cell are summed into the run head
-    // (levels finer than b.dedupe_levels skip it: at 4096 cells per axis and beyond consecutive samples practically never share
+    // run-dedupe along the ray: adjacent lanes in the same cell are summed into the run head
+    // (levels from BIN_DEDUPE_LEVELS on skip it: at 4096 cells per axis and beyond consecutive samples practically never share
     //  a cell -- 8.1-8.3 of 8.4 M records survive -- so the compare / ballot / ladder step costs more than the records it saves)
-    const bool dd = l < b.dedupe_levels;
+    const bool dd = l < BIN_DEDUPE_LEVELS;
     uint32_t q0 = cell[0], q1 = cell[1], q2 = cell[2];
     if (dd) { q0 = __shfl_up(cell[0], 1); q1 = __shfl_up(cell[1], 1); q2 = __shfl_up(cell[2], 1); }
     const bool head = !dd | (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
@@ -572,7 +465,7 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     if (emit) {
       atomicMax(&vmax_s[par], __float_as_uint(vmax));   // non-negative floats order like their bit patterns
 #pragma unroll
-      for (int c = 0; c < 8; ++c) rk[c] = atomicAdd(&cnt[par][idx[c] >> BIN_SLICE_LOG2], 1u);
+      for (int c = 0; c < 8; ++c) rk[c] = atomicAdd(&cnt[par][idx[c] >> sl], 1u);
     }
     __syncthreads();
     if (tid < 64) {   // exclusive prefix over the slice counters; descriptors; reset the counters for level l + 2
@@ -594,8 +487,8 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         h16x2 hv; hv[0] = (h16)(v[2 * c] * sc); hv[1] = (h16)(v[2 * c + 1] * sc);
-        const uint32_t s = idx[c] >> BIN_SLICE_LOG2;
-        sorted[base[s] + rk[c]] = make_uint2(idx[c] & (BIN_SLICE - 1u), *(const uint32_t*)&hv);
+        const uint32_t s = idx[c] >> sl;
+        sorted[base[s] + rk[c]] = make_uint2(idx[c] & slot_mask, *(const uint32_t*)&hv);
       }
     }
     __syncthreads();
@@ -611,70 +504,65 @@ struct AccParams {
   const uint2* pool; const uint32_t* desc; float* grad; int32_t* found_inf;
   int ntiles, level_lo, n_levels_here;
   uint32_t blk_start[ALN_MAX_LEVELS + 1];   // first block of each launched level (levels enumerated from level_lo)
-  uint32_t split[ALN_MAX_LEVELS];           // blocks per slice: coarse levels have few slices, their tiles are split over blocks
   uint32_t size[ALN_MAX_LEVELS], offset[ALN_MAX_LEVELS];
+  uint8_t slice_log2[ALN_MAX_LEVELS];
 };
 
-// fp16 record value -> exact 64-bit fixed point in units of 2^-24 (the smallest fp16 denormal): every fp16 is an integer
-// < 2^40 in that unit, so 2^23 records can be summed without overflow and the sum is EXACT and order-independent.
+// fp16 record value -> 64-bit fixed point, exact and order-independent under integer addition.  A record value h carries the
+// true value t = h * 2^-shift (shift = the tile's up-scaling, phase 1); the accumulator holds round(t * 2^U).  With the default
+// U = 35 (2^-35 = the smallest fp16 denormal, 2^-24, scaled up by 2^11) the conversion of every record is exact.  Through double
+// precision: h * 2^(U - shift) has at most 11 significant bits and lies below 2^51, so adding 1.5 * 2^52 parks it (rounded to an
+// integer, ties to even, when U < 35 leaves fraction bits) in the low mantissa bits, two's complement
+// (v_cvt_f64_f32, v_ldexp_f64, v_add_f64 and one 64-bit subtract; the add side of phase 2 is VALU-bound).
 // (ds_add_f32 runs at 0.33 lanes/clk/CU on gfx950, ds_add_u64 at 4.6: profiles/r02_probe_lds_atomics.txt.)
-// Records scaled up by 2^e (e <= BIN_MAX_SHIFT, phase 1) are shifted left by BIN_MAX_SHIFT - e: the accumulator unit is 2^-(24 + BIN_MAX_SHIFT),
-// |value| < 2^16 * 2^36 = 2^52 per record, so 2^11 records of the largest fp16 magnitude still fit.
-__device__ inline long long fx_from_half(h16 h) {
-  const float a = (float)h * 16777216.0f;              // exact: 11-bit significand, |a| < 2^40
-  const float hi = truncf(a * (1.0f / 1048576.0f));    // |hi| < 2^20
-  const float lo = a - hi * 1048576.0f;                // exact, same sign, |lo| < 2^20
-  return ((long long)(int)hi << 20) + (long long)(int)lo;
-}
-// The same value through double precision: h * 2^e (e = 24 + BIN_MAX_SHIFT - shift) is an integer below 2^51 in magnitude, exact
-// in a double; adding 1.5 * 2^52 parks it, two's complement, in the low mantissa bits (v_cvt_f64_f32, v_ldexp_f64, v_add_f64
-// and one 64-bit subtract instead of the float split + two 64-bit shifts: the add side of phase 2 is VALU-bound).
 __device__ inline long long fx_from_half_d(h16 h, int e) {
   const double z = ldexp((double)(float)h, e) + 6755399441055744.0;
   return __double_as_longlong(z) - 0x4338000000000000LL;
 }
-#define FX_UNIT (1.0 / (double)(1ull << (24 + BIN_MAX_SHIFT)))   // 2^-(24 + BIN_MAX_SHIFT)
+#define FX_UNIT_LOG2 (24 + BIN_MAX_SHIFT)   // 35
 
 #define ACC_THREADS 1024
 #define ACC_LPR (BIN_TILE / 256)  // 8-byte loads per lane and run held in registers: covers the average run of a hashed level twice
 #define ACC_RB (12 / ACC_LPR)    // runs per batch in the accumulate loop (12 loads per batch: 16 spill at the 128-VGPR budget of 16 waves per CU)
 __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
-  long long* acc = (long long*)acc_smem;   // [BIN_SLICE][2] = 128 KB
+  long long* acc = (long long*)acc_smem;   // [slice entries][2] <= 128 KB
+  __shared__ unsigned long long bound_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = ACC_THREADS / 64;
   int li = 0;
   while (li + 1 < a.n_levels_here && blockIdx.x >= a.blk_start[li + 1]) ++li;
   const int l = a.level_lo + li;
-  const uint32_t nsl = (a.size[l] + BIN_SLICE - 1) >> BIN_SLICE_LOG2, K = a.split[li];
-  const uint32_t bl = blockIdx.x - a.blk_start[li];
-  const int s = bl % nsl, part = bl / nsl;
-  for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ll;
-  __syncthreads();
+  const uint32_t sl = a.slice_log2[l];
+  const int s = blockIdx.x - a.blk_start[li];
+  const uint32_t e0 = (uint32_t)s << sl;
+  const uint32_t ne = min(1u << sl, a.size[l] - e0);   // entries of this slice (the LDS accumulators beyond them are never touched)
   const uint32_t* d = a.desc + ((size_t)l * BIN_MAX_SLICES + s) * a.ntiles;
+  // Range guard.  A record is below 2^(15 - shift) in magnitude (2^16 for shift 0: the tile was not scaled), so the sum over the
+  // runs of count * that bounds any accumulator of the slice; if that bound times 2^35 could pass 2^62, the block accumulates in a coarser unit 2^-U
+  // (records are then ROUNDED to it -- still one fixed integer per record, so the sums stay order-independent).  In training
+  // this never triggers for the hashed levels; it is what lets the two coarsest levels (thousands of records per entry at the
+  // largest loss scales) share the exact path.
+  if (tid == 0) bound_s = 0ull;
+  for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) acc[i] = 0ll;
+  __syncthreads();
+  {
+    unsigned long long bsum = 0ull;
+    for (int t = tid; t < a.ntiles; t += ACC_THREADS) { const uint32_t q = d[t]; const uint32_t sh = DESC_SHIFT(q); bsum += (unsigned long long)DESC_COUNT(q) << (sh ? 15u - sh : 16u); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o);
+    if (lane == 0 && bsum) atomicAdd(&bound_s, bsum);
+  }
+  __syncthreads();
+  int U = FX_UNIT_LOG2;
+  { const unsigned long long bd = bound_s; const int lg = bd ? 64 - __clzll(bd) : 0; U = min(FX_UNIT_LOG2, 62 - lg); }   // bd < 2^lg
   const uint2* pool = a.pool + (size_t)l * a.ntiles * BIN_CHUNK;
   bool bad = false;   // a non-finite record (inf / nan upstream, or an fp16 overflow of a run sum)
-  auto add = [&](uint2 r, uint32_t up) {   // up = BIN_MAX_SHIFT - shift of the run's tile
+  auto add = [&](uint2 r, int ex) {   // ex = U - shift of the run's tile
     const h16x2 hv = *(const h16x2*)&r.y;
     bad |= (r.y & 0x7C00u) == 0x7C00u || (r.y & 0x7C000000u) == 0x7C000000u;
-    atomicAdd((unsigned long long*)&acc[2 * r.x], (unsigned long long)fx_from_half_d(hv[0], 24 + (int)up));
-    atomicAdd((unsigned long long*)&acc[2 * r.x + 1], (unsigned long long)fx_from_half_d(hv[1], 24 + (int)up));
+    atomicAdd((unsigned long long*)&acc[2 * r.x], (unsigned long long)fx_from_half_d(hv[0], ex));
+    atomicAdd((unsigned long long*)&acc[2 * r.x + 1], (unsigned long long)fx_from_half_d(hv[1], ex));
   };
-  if (K > 1) {
-    // coarse levels (few slices, long runs of hundreds of records per tile): one tile per wave at a time, four loads per lane
-    // in flight; the tiles of the slice are dealt out over the K blocks
-    for (int t = part * nw + wave; t < a.ntiles; t += K * nw) {
-      const uint32_t q = d[t];
-      const uint32_t st0 = DESC_START(q), n0 = DESC_COUNT(q), up0 = BIN_MAX_SHIFT - DESC_SHIFT(q);
-      const uint2* src = pool + (size_t)t * BIN_CHUNK + st0;
-      for (uint32_t k = lane; k < n0; k += 256) {
-        uint2 rr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) rr[u] = (k + 64 * u < n0) ? src[k + 64 * u] : make_uint2(0u, 0u);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (k + 64 * u < n0) add(rr[u], up0);
-      }
-    }
-  } else
   {
     // the tiles are dealt out to the 16 waves in equal contiguous shares (all waves busy for any tile count); a wave walks its
     // share in rounds of <= 64 tiles (one descriptor per lane) and batches of ACC_RB runs: the first 128 records of each run in
@@ -685,12 +573,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     for (int t0 = tlo; t0 < thi; t0 += 64) {
       const int nt = min(64, thi - t0);
       const uint32_t dd = (lane < nt) ? d[t0 + lane] : 0u;
-      uint2 r[2][ACC_LPR * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB], up[2][ACC_RB];
+      uint2 r[2][ACC_LPR * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB]; int ex[2][ACC_RB];
       auto request = [&](int buf, int j0) {
 #pragma unroll
         for (int u = 0; u < ACC_RB; ++u) {
           const uint32_t q = __builtin_amdgcn_readlane(dd, (j0 + u) & 63);
-          st[buf][u] = DESC_START(q); n[buf][u] = (j0 + u < nt) ? DESC_COUNT(q) : 0u; up[buf][u] = BIN_MAX_SHIFT - DESC_SHIFT(q);
+          st[buf][u] = DESC_START(q); n[buf][u] = (j0 + u < nt) ? DESC_COUNT(q) : 0u; ex[buf][u] = U - (int)DESC_SHIFT(q);
           const uint2* src = pool + (size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u];
 #pragma unroll
           for (int v = 0; v < ACC_LPR; ++v) {
@@ -704,9 +592,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
         for (int u = 0; u < ACC_RB; ++u) {
 #pragma unroll
           for (int v = 0; v < ACC_LPR; ++v)
-            if ((uint32_t)lane + 64u * v < n[buf][u]) add(r[buf][ACC_LPR * u + v], up[buf][u]);
+            if ((uint32_t)lane + 64u * v < n[buf][u]) add(r[buf][ACC_LPR * u + v], ex[buf][u]);
           for (uint32_t k = 64 * ACC_LPR + lane; k < n[buf][u]; k += 64)   // long runs
-            add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], up[buf][u]);
+            add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], ex[buf][u]);
         }
       };
       request(0, 0);
@@ -719,15 +607,11 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     }
   }
   __syncthreads();
-  const uint32_t e0 = (uint32_t)s << BIN_SLICE_LOG2;
-  const uint32_t ne = min((uint32_t)BIN_SLICE, a.size[l] - e0);
   float* g = a.grad + 2 * ((size_t)a.offset[l] + e0);
+  const double unit = ldexp(1.0, -U);
   for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) {
     const long long q = acc[i];
-    if (q != 0ll) {
-      const float v = (float)((double)q * FX_UNIT);    // one rounding of the exact sum
-      if (K > 1) unsafeAtomicAdd(&g[i], v); else g[i] += v;   // adjacent lanes, adjacent floats: 16 lanes per request
-    }
+    if (q != 0ll) g[i] += (float)((double)q * unit);    // one rounding of the exact sum; no other block owns this entry
   }
   if (bad) {   // poison the slice (torch's GradScaler looks at the gradient tensor itself) and raise the engine's flag
     g[0] = __builtin_nanf("");
@@ -758,31 +642,30 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
   const int ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
   b.p.level_lo = level_lo; b.p.level_hi = level_hi;
   b.d_enc = (const h16*)d_enc; b.ntiles = ntiles; b.rows1 = rows_pass1; b.stride2 = stride2 > 0 ? stride2 : 1;
-  static const int dedupe_levels = getenv("ALN_BIN_DEDUPE_LEVELS") ? atoi(getenv("ALN_BIN_DEDUPE_LEVELS")) : 8;
-  b.dedupe_levels = dedupe_levels;
   b.pool = (uint2*)ws;
   b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * BIN_CHUNK * sizeof(uint2));
+  AccParams a;
+  for (int l = 0; l < ALN_MAX_LEVELS; ++l) b.slice_log2[l] = a.slice_log2[l] = (uint8_t)(l < nl ? bin_slice_log2(e->grid.size[l]) : 0);
   hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
   ALN_CHECK_LAUNCH("encode_bwd_bin");
-  AccParams a;
   a.pool = b.pool; a.desc = b.desc; a.grad = grad_table; a.found_inf = found_inf; a.ntiles = ntiles;
   a.level_lo = level_lo; a.n_levels_here = level_hi - level_lo;
-  uint32_t nblk = 0;
+  uint32_t nblk = 0, max_entries = 1;
   for (int l = level_lo; l < level_hi; ++l) {
-    const uint32_t nsl = (e->grid.size[l] + BIN_SLICE - 1) >> BIN_SLICE_LOG2;
-    uint32_t K = nsl >= 32 ? 1 : (BIN_MAX_SLICES + nsl - 1) / nsl;     // coarse levels: at least 64 blocks per level
-    const uint32_t kmax = (uint32_t)(ntiles + 15) / 16;   // a block of 16 waves needs at least 16 tiles
-    if (K > kmax) K = kmax;
-    if (K < 1) K = 1;
-    a.blk_start[l - level_lo] = nblk; a.split[l - level_lo] = K;
-    nblk += nsl * K;
+    const uint32_t per = 1u << a.slice_log2[l], nsl = (e->grid.size[l] + per - 1) / per;
+    ALN_REQUIRE(nsl <= BIN_MAX_SLICES, "encode_bwd_binned: level %d has %u slices", l, nsl);
+    a.blk_start[l - level_lo] = nblk;
+    nblk += nsl;
+    if (per > max_entries) max_entries = per;
   }
   a.blk_start[level_hi - level_lo] = nblk;
   for (int l = 0; l < nl; ++l) { a.size[l] = e->grid.size[l]; a.offset[l] = e->grid.offset[l]; }
   static const bool lds_ok = hipFuncSetAttribute((const void*)k_encode_bwd_accum, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  2 * BIN_SLICE * (int)sizeof(long long)) == hipSuccess;
   ALN_REQUIRE(lds_ok, "encode_bwd_binned: cannot reserve 128 KB of LDS");
-  hipLaunchKernelGGL(k_encode_bwd_accum, dim3(nblk), dim3(ACC_THREADS), 2 * BIN_SLICE * sizeof(long long), (hipStream_t)stream, a);
+  // LDS for the largest slice of this launch (a launch of coarse levels only -- the last level group of the data-parallel
+  // schedule -- then fits several blocks per CU)
+  hipLaunchKernelGGL(k_encode_bwd_accum, dim3(nblk), dim3(ACC_THREADS), 2 * (size_t)max_entries * sizeof(long long), (hipStream_t)stream, a);
   ALN_CHECK_LAUNCH("encode_bwd_accum");
   return 0;
 }

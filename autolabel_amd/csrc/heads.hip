@@ -19,16 +19,43 @@ extern "C" int aln_sigma_act(const void* sigma_out, int32_t rows, float* sigma, 
   return 0;
 }
 
-// live = w > thresh (renderer: mask = weights > 1e-4).  Ballot compaction; ONE returning atomic per 4096-row block
-// (same-address atomics serialize at ~12 ns each on MI355X, so per-wave atomics cost 200 us per million rows).
+// live = w > thresh (renderer: mask = weights > 1e-4).  Ballot compaction in ROW ORDER: pass 1 counts the live rows of every
+// 4096-row chunk, pass 2 re-derives the bits, takes the sum of the earlier chunks' counts as its base (<= 512 chunks at 2^21
+// rows: one coalesced read per block) and writes.  The compact order is a pure function of w_row -- the color head sees its rows,
+// and forms its weight-gradient partial sums, in the same order every run (round 2 handed out chunk bases with a returning
+// atomic: block arrival order).
 #define COMPACT_ITERS 16
-__global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ w_row, int rows, float thresh, int* __restrict__ n_live,
-                                                     int* __restrict__ live_idx, int* __restrict__ cidx_row) {
-  __shared__ int s_cnt[4], s_base;
+#define COMPACT_CHUNK (256 * COMPACT_ITERS)
+__global__ __launch_bounds__(256) void k_compact_count(const float* __restrict__ w_row, int rows, float thresh, int* __restrict__ chunk_cnt) {
+  __shared__ int s_cnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nchunks = (rows + 256 * COMPACT_ITERS - 1) / (256 * COMPACT_ITERS);
+  const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
   for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const int r0 = ch * 256 * COMPACT_ITERS + wave * 64 * COMPACT_ITERS;  // each wave owns a contiguous 1024-row span
+    const int r0 = ch * COMPACT_CHUNK + wave * 64 * COMPACT_ITERS;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < COMPACT_ITERS; ++i) {
+      const int r = r0 + i * 64 + lane;
+      cnt += __popcll(__ballot(r < rows && w_row[r] > thresh));
+    }
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[ch] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ w_row, int rows, float thresh, const int* __restrict__ chunk_cnt,
+                                                     int* __restrict__ n_live, int* __restrict__ live_idx, int* __restrict__ cidx_row) {
+  __shared__ int s_cnt[4], s_part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    // base = number of live rows in chunks [0, ch): integer sum, any order gives the same value
+    int part = 0;
+    for (int q = threadIdx.x; q < ch; q += 256) part += chunk_cnt[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const int r0 = ch * COMPACT_CHUNK + wave * 64 * COMPACT_ITERS;  // each wave owns a contiguous 1024-row span
     unsigned bits = 0; int cnt = 0;
 #pragma unroll
     for (int i = 0; i < COMPACT_ITERS; ++i) {
@@ -37,12 +64,11 @@ __global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ 
       bits |= (unsigned)live << i;
       cnt += __popcll(__ballot(live));
     }
-    if (lane == 0) s_cnt[wave] = cnt;
+    if (lane == 0) { s_cnt[wave] = cnt; s_part[wave] = part; }
     __syncthreads();
-    if (threadIdx.x == 0) s_base = atomicAdd(n_live, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
-    __syncthreads();
-    int off = s_base;
+    int off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     for (int w = 0; w < wave; ++w) off += s_cnt[w];
+    if (ch == nchunks - 1 && threadIdx.x == 0) *n_live = s_part[0] + s_part[1] + s_part[2] + s_part[3] + s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 #pragma unroll
     for (int i = 0; i < COMPACT_ITERS; ++i) {
       int r = r0 + i * 64 + lane;
@@ -58,14 +84,17 @@ __global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ 
     __syncthreads();
   }
 }
+// chunk_ws: caller-owned scratch of aln_compact_live_ws_ints(rows) int32 (the per-chunk counts between the two passes)
+extern "C" int32_t aln_compact_live_ws_ints(int32_t rows) { return rows > 0 ? (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK : 0; }
 extern "C" int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx,
-                                int32_t* cidx_row, void* stream) {
-  ALN_REQUIRE(w_row && n_live && live_idx && cidx_row, "compact_live: NULL pointer");
-  hipMemsetAsync(n_live, 0, sizeof(int), (hipStream_t)stream);
-  if (rows <= 0) return 0;
-  int nchunks = (rows + 256 * COMPACT_ITERS - 1) / (256 * COMPACT_ITERS);
+                                int32_t* cidx_row, int32_t* chunk_ws, void* stream) {
+  ALN_REQUIRE(w_row && n_live && live_idx && cidx_row && chunk_ws, "compact_live: NULL pointer");
+  if (rows <= 0) { hipMemsetAsync(n_live, 0, sizeof(int), (hipStream_t)stream); return 0; }
+  const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
+  hipLaunchKernelGGL(k_compact_count, dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh, chunk_ws);
+  ALN_CHECK_LAUNCH("compact_count");
   hipLaunchKernelGGL(k_compact_live, dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh,
-                     n_live, live_idx, cidx_row);
+                     (const int*)chunk_ws, n_live, live_idx, cidx_row);
   ALN_CHECK_LAUNCH("compact_live");
   return 0;
 }
@@ -194,26 +223,6 @@ __global__ void k_assemble_dsemf_out(h16* __restrict__ d_feat, const h16* __rest
     *(h16x8*)(d_feat + r * D + c0) = g;
   }
   if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
-}
-// g *= (act > 0) in place + overflow watch: the ReLU backward of the library-GEMM heads, one pass instead of torch's three
-__global__ void k_relu_bwd(h16* __restrict__ g, const h16* __restrict__ act, size_t n8, int* __restrict__ found_inf) {
-  bool bad = false;
-  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n8; t += (size_t)gridDim.x * blockDim.x) {
-    h16x8 gv = *(const h16x8*)(g + 8 * t);
-    const h16x8 av = *(const h16x8*)(act + 8 * t);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { if (!((float)av[j] > 0.f)) gv[j] = (h16)0.f; bad |= !(fabsf((float)gv[j]) <= 65504.f); }
-    *(h16x8*)(g + 8 * t) = gv;
-  }
-  if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
-}
-extern "C" int aln_relu_bwd(void* g, const void* act, int64_t n, int32_t* found_inf, void* stream) {
-  ALN_REQUIRE(g && act && n % 8 == 0, "relu_bwd: NULL pointer or n %% 8 != 0");
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_relu_bwd, dim3(aln_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (h16*)g, (const h16*)act,
-                     (size_t)(n / 8), found_inf);
-  ALN_CHECK_LAUNCH("relu_bwd");
-  return 0;
 }
 // d_sigma_out[row] = [d_h0, d_geo(semf_in) + d_geo(semo_in) + d_geo(color_in)] (16 wide)
 __global__ void k_assemble_dsigma_out(const float* __restrict__ d_h0, const h16* __restrict__ d_semf_in, int semf_in_pad,

@@ -148,26 +148,31 @@ extern "C" int aln_grid_points(int32_t G, float bound, uint32_t seed, uint32_t s
   return 0;
 }
 
-// grid = max(grid * decay, sigma * density_scale) on cells >= 0; stats[0] += sum, stats[1] += count (floats; zero them first)
-__global__ void k_grid_ema(float* __restrict__ grid, const float* __restrict__ sigma, size_t n, float decay, float density_scale,
-                           float* __restrict__ stats) {
+// grid = max(grid * decay, sigma * density_scale) on cells >= 0; stats[0] += sum (fixed point, 2^-16), stats[1] += count
+// (zero them first).  Integer accumulation: the mean -- and with it the bitfield of cells sitting at the threshold -- does not
+// depend on the order in which the waves arrive.  sigma == NULL: statistics of the grid as it is.
+#define GRID_SUM_SCALE 65536.0
+__global__ void k_grid_ema(float* grid, const float* sigma, size_t n, float decay, float density_scale,
+                           unsigned long long* __restrict__ stats) {
   float s = 0.f, cnt = 0.f;
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
     float g = grid[c];
     if (g >= 0.f) {
-      g = fmaxf(__fmul_rn(g, decay), __fmul_rn(sigma[c], density_scale));
-      grid[c] = g;
+      if (sigma) { g = fmaxf(__fmul_rn(g, decay), __fmul_rn(sigma[c], density_scale)); grid[c] = g; }
       s += g; cnt += 1.f;
     }
   }
-  s = wave_sum(s); cnt = wave_sum(cnt);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], s); atomicAdd(&stats[1], cnt); }
+  s = wave_sum(s); cnt = wave_sum(cnt);   // fixed lane order within the wave; the waves meet in integer adds
+  if ((threadIdx.x & 63) == 0 && cnt > 0.f) {
+    atomicAdd(&stats[0], (unsigned long long)((double)fminf(s, 1e30f) * GRID_SUM_SCALE));
+    atomicAdd(&stats[1], (unsigned long long)cnt);
+  }
 }
 
 // bit c = grid[c] > min(mean, thresh)   (32 cells per thread-word: a wave writes 256 contiguous bytes)
-__global__ void k_grid_bits(const float* __restrict__ grid, size_t n, const float* __restrict__ stats, float thresh,
+__global__ void k_grid_bits(const float* __restrict__ grid, size_t n, const unsigned long long* __restrict__ stats, float thresh,
                             uint32_t* __restrict__ bits, int* __restrict__ n_set) {
-  const float mean = stats[1] > 0.f ? stats[0] / stats[1] : 0.f;
+  const float mean = stats[1] ? (float)((double)stats[0] / GRID_SUM_SCALE / (double)stats[1]) : 0.f;
   const float th = fminf(mean, thresh);
   int local = 0;
   const size_t nw = (n + 31) / 32;
@@ -187,21 +192,36 @@ __global__ void k_grid_bits(const float* __restrict__ grid, size_t n, const floa
 }
 
 extern "C" int aln_grid_update(float* grid, const float* sigma, int32_t G, float decay, float density_scale, float thresh,
-                               float* stats /*[2] scratch*/, uint32_t* bitfield, int32_t* n_set /*[1] or NULL*/, void* stream) {
+                               void* stats /*16 bytes of scratch*/, uint32_t* bitfield, int32_t* n_set /*[1] or NULL*/, void* stream) {
   ALN_REQUIRE(grid && stats && bitfield && G > 0, "grid_update: bad arguments");
   const size_t n = (size_t)G * G * G;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(stats, 0, 2 * sizeof(float), s) != hipSuccess) { aln_set_error("grid_update: memset failed"); return -2; }
+  if (hipMemsetAsync(stats, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) { aln_set_error("grid_update: memset failed"); return -2; }
   if (n_set && hipMemsetAsync(n_set, 0, sizeof(int), s) != hipSuccess) { aln_set_error("grid_update: memset failed"); return -2; }
-  if (sigma) {
-    hipLaunchKernelGGL(k_grid_ema, dim3(aln_grid_for((int64_t)n, 256, 2048)), dim3(256), 0, s, grid, sigma, n, decay, density_scale, stats);
-    ALN_CHECK_LAUNCH("grid_ema");
-  } else {   // statistics of the grid as it is (after a checkpoint load / mark_untrained)
-    hipLaunchKernelGGL(k_grid_ema, dim3(aln_grid_for((int64_t)n, 256, 2048)), dim3(256), 0, s, grid, grid, n, 1.0f, 1.0f, stats);
-    ALN_CHECK_LAUNCH("grid_ema");
-  }
-  hipLaunchKernelGGL(k_grid_bits, dim3(aln_grid_for((int64_t)((n + 31) / 32), 256, 2048)), dim3(256), 0, s, grid, n, stats, thresh, bitfield, n_set);
+  // sigma == NULL: statistics of the grid as it is (after mark_untrained_grid)
+  hipLaunchKernelGGL(k_grid_ema, dim3(aln_grid_for((int64_t)n, 256, 2048)), dim3(256), 0, s, grid, sigma, n, decay, density_scale,
+                     (unsigned long long*)stats);
+  ALN_CHECK_LAUNCH("grid_ema");
+  hipLaunchKernelGGL(k_grid_bits, dim3(aln_grid_for((int64_t)((n + 31) / 32), 256, 2048)), dim3(256), 0, s, grid, n,
+                     (const unsigned long long*)stats, thresh, bitfield, n_set);
   ALN_CHECK_LAUNCH("grid_bits");
+  return 0;
+}
+
+// n_set = number of set bits of a bitfield that arrived with a checkpoint (the bits themselves are kept as stored)
+__global__ void k_bitfield_count(const uint32_t* __restrict__ bits, size_t nw, int* __restrict__ n_set) {
+  int local = 0;
+  for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nw; w += (size_t)gridDim.x * blockDim.x) local += __popc(bits[w]);
+  const float f = wave_sum((float)local);
+  if ((threadIdx.x & 63) == 0 && f > 0.f) atomicAdd(n_set, (int)f);
+}
+extern "C" int aln_bitfield_count(const uint32_t* bitfield, int64_t n_words, int32_t* n_set, void* stream) {
+  ALN_REQUIRE(bitfield && n_set && n_words >= 0, "bitfield_count: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(n_set, 0, sizeof(int), s) != hipSuccess) { aln_set_error("bitfield_count: memset failed"); return -2; }
+  if (n_words == 0) return 0;
+  hipLaunchKernelGGL(k_bitfield_count, dim3(aln_grid_for(n_words, 256, 2048)), dim3(256), 0, s, bitfield, (size_t)n_words, n_set);
+  ALN_CHECK_LAUNCH("bitfield_count");
   return 0;
 }
 

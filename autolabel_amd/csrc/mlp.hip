@@ -12,8 +12,6 @@
 // Activations therefore never leave registers between layers; weights live in LDS in fragment order
 // (one conflict-free ds_read_b128 per lane per MFMA).
 #include "common.h"
-#include <stdlib.h>
-#include <string.h>
 
 typedef __attribute__((address_space(3))) h16 lds_h16;   // LDS-typed element: ds_* with 32-bit addresses + immediate offsets
 #define LDS_VEC(T) __attribute__((address_space(3))) T
@@ -768,15 +766,13 @@ __global__ __launch_bounds__(256) void k_dw_gemm(const h16* __restrict__ dA, int
   }
 }
 
-// ---------------------------------------------------------------- fused backward (data path + weight gradients)
-// One kernel per head: the backward chain stays in registers as above; for the weight gradients
+// ---------------------------------------------------------------- weight-gradient operands of the fused backward
 //   dW_l[o][i] = sum_samples dA_l[s][o] * X_l[s][i]
-// the contraction index is the SAMPLE, i.e. both MFMA operands need 8 consecutive samples per lane.  The block stages
-// dA_l and X_l (saved activations / layer input) of its 128 samples in LDS as plain row-major [sample][feature] tiles and
-// reads operand fragments with the gfx950 hardware transpose read ds_read_b64_tr_b16 (16 lanes fetch a 4-sample x 16-feature
-// block; lane i receives feature i of 4 consecutive samples -- semantics verified by scripts/dev/probe_trread.hip).
-// dW accumulators live in registers for the whole kernel (each wave owns a fixed subset of 32x32 C-blocks) and are flushed
-// once at the end: no per-layer dA round trip through HBM and no separate dW GEMM launches.
+// The contraction index is the SAMPLE, i.e. both MFMA operands need 8 consecutive samples per lane.  The backward kernel parks
+// dA_l and X_l of its 128 samples in LDS as plain row-major [sample][feature] tiles and reads operand fragments with the gfx950
+// hardware transpose read ds_read_b64_tr_b16 (16 lanes fetch a 4-sample x 16-feature block; lane i receives feature i of 4
+// consecutive samples -- semantics verified by scripts/dev/probe_trread.hip).  dW accumulators live in registers for the whole
+// kernel (each dW wave owns a fixed subset of 32x32 C-blocks) and leave once at the end.
 typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4v* lds_s16x4_ptr;
 template <class TV>
@@ -792,17 +788,6 @@ __device__ inline h16x8 tr_frag(TV t, int col0, int ks, int lane) {
   u.s.l = lo; u.s.h = hi;
   return u.v;
 }
-// cooperative global -> LDS tile load: nrows x ncols halves (ncols % 8 == 0), rows >= limit are zero-filled
-__device__ inline void load_tile(h16* tile, int pitch, const h16* g, int ncols, int r0, int nrows, int limit) {
-  const int per_row = ncols / 8;
-  for (int i = threadIdx.x; i < nrows * per_row; i += 256) {
-    int r = i / per_row, k = i % per_row;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + r < limit) v = *(const uint4*)(g + (size_t)(r0 + r) * ncols + 8 * k);
-    *(uint4*)(tile + (size_t)r * pitch + 8 * k) = v;
-  }
-}
-
 // dW accumulate over the block tile: wave owns C-blocks blk = wave + 4b (blk -> (ob, ib) = (blk / NIB, blk % NIB)).
 // When 4 % NIB == 0 the input block ib is the same for all owned blocks, so its fragment is fetched once per k-step.
 template <int NBLK, int NOB, int NIB, int TROWS = 128, class TVA, class TVB>
@@ -831,150 +816,6 @@ __device__ inline void dw_accumulate(f32x16 (&dw)[NBLK], TVA tA, TVB tB, int wav
       if (blk < NOB * NIB) dw[b] = mfma16(a[ks & 1][b], bq[ks & 1][IB_CONST ? 0 : (b < NBF ? b : 0)], dw[b]);
     }
   }
-}
-
-template <int IN, int HID, int OUT, int NHID>
-__global__ __launch_bounds__(256) void k_mlp_bwd_fused(const h16* __restrict__ wb_g, size_t wb_halves,
-                                                      const h16* __restrict__ x, const h16* __restrict__ h1,
-                                                      const h16* __restrict__ h2, const h16* __restrict__ d_out, int rows,
-                                                      const int* __restrict__ rows_dev, h16* __restrict__ d_in,
-                                                      float* __restrict__ dW, int* __restrict__ found_inf) {
-  constexpr int NB = HID / 32, KS = HID / 16, KSO = OUT / 16, IB = (IN + 31) / 32, OB = (OUT + 31) / 32;
-  constexpr int PD = HID + 8, PX = (HID > IN ? HID : IN) + 8, PO = OUT + 8;   // LDS row pitches (halves)
-  constexpr int TR = 128;                                                        // rows per block tile
-  // C-blocks owned per wave (round-robin over the 4 waves)
-  constexpr int NBLK_LAST = (OB * NB + 3) / 4, NBLK_MID = (NB * NB + 3) / 4, NBLK_FIRST = (NB * IB + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  h16* wl = (h16*)smem;
-  h16* tD = wl + wb_halves;
-  h16* tX = tD + TR * PD;
-  h16* tO = tX + TR * PX;
-  copy_to_lds(wl, wb_g, wb_halves);
-  const h16x8* frag = (const h16x8*)wl;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hf = lane >> 5, c = lane & 31;
-  if (rows_dev) rows = min(rows, *rows_dev);
-  const size_t f1 = (size_t)NB * KSO;
-  const size_t fl = f1 + (NHID == 2 ? (size_t)NB * KS : 0);
-  MlpLayers L = mlp_layers(IN, HID, OUT, NHID);
-  f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
-  zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
-  bool bad = false;
-  const int ntiles = (rows + TR - 1) / TR;
-  const h16* hl = (NHID == 2) ? h2 : h1;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int r0 = tile * TR;
-    const int srow = wave * 32 + c;           // this lane's sample row inside the tile
-    __syncthreads();                          // previous tile's readers are done with tO / tX / tD
-    load_tile(tO, PO, d_out, OUT, r0, TR, rows);
-    load_tile(tX, PX, hl, HID, r0, TR, rows);
-    __syncthreads();
-    // ---- dW_last[o][i] += dOut^T . h_last
-    dw_accumulate<NBLK_LAST, OB, NB>(dw_last, plainv(tO, PO), plainv(tX, PX), wave, lane);
-    // ---- chain: dA_last = relu'(h_last) * (W_last^T dOut)
-    f32x16 acc[NB];
-    zero_acc(acc);
-#pragma unroll
-    for (int ks = 0; ks < KSO; ++ks) {
-      h16x8 bfr = *(const h16x8*)(tO + (size_t)srow * PO + 16 * ks + 8 * hf);
-#pragma unroll
-      for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[((size_t)m * KSO + ks) * 64 + lane], bfr, acc[m]);
-    }
-    h16x8 p[KS];
-    bad |= mask_pack_store<NB>(acc, p, tX + (size_t)srow * PX, nullptr, hf, true);
-    if (NHID == 2) {
-      __syncthreads();                        // everyone is done reading tX (= h2) and tO
-#pragma unroll
-      for (int m = 0; m < NB; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
-          v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
-          *(h16x4*)(tD + (size_t)srow * PD + 32 * m + 8 * q + 4 * hf) = v;
-        }
-      load_tile(tX, PX, h1, HID, r0, TR, rows);
-      __syncthreads();
-      dw_accumulate<NBLK_MID, NB, NB>(dw_mid, plainv(tD, PD), plainv(tX, PX), wave, lane);
-      zero_acc(acc);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int m = 0; m < NB; ++m) acc[m] = mfma16(frag[(f1 + (size_t)m * KS + ks) * 64 + lane], p[ks], acc[m]);
-      bad |= mask_pack_store<NB>(acc, p, tX + (size_t)srow * PX, nullptr, hf, true);
-    }
-    __syncthreads();                          // done reading tX (= h1) / tD
-#pragma unroll
-    for (int m = 0; m < NB; ++m)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        h16x4 v; v[0] = p[2 * m + (q >> 1)][4 * (q & 1)]; v[1] = p[2 * m + (q >> 1)][4 * (q & 1) + 1];
-        v[2] = p[2 * m + (q >> 1)][4 * (q & 1) + 2]; v[3] = p[2 * m + (q >> 1)][4 * (q & 1) + 3];
-        *(h16x4*)(tD + (size_t)srow * PD + 32 * m + 8 * q + 4 * hf) = v;
-      }
-    load_tile(tX, PX, x, IN, r0, TR, rows);
-    // columns IN..32*IB-1 of the last C-block read whatever follows in LDS: they only reach dW columns >= IN, which are never flushed
-    __syncthreads();
-    dw_accumulate<NBLK_FIRST, NB, IB>(dw_first, plainv(tD, PD), plainv(tX, PX), wave, lane);
-    if (d_in) {
-      const int row = r0 + srow;
-#pragma unroll
-      for (int ib = 0; ib < IB; ++ib) {
-        f32x16 o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) o = mfma16(frag[(fl + (size_t)ib * KS + ks) * 64 + lane], p[ks], o);
-        if (row < rows) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f = 32 * ib + 8 * q + 4 * hf;
-            if (f < IN) {
-              h16x4 v;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { v[r] = (h16)o[4 * q + r]; bad |= !(fabsf((float)v[r]) <= 65504.f); }
-              *(h16x4*)(d_in + (size_t)row * IN + f) = v;
-            }
-          }
-        }
-      }
-    }
-  }
-  // ---- flush weight gradients (C layout: lane = input column, 32 consecutive floats per row)
-  auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, size_t off) {
-    float* const base = dW + off;
-    const int i = 32 * ib + c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
-      if (o < OUTL && i < INL && a[r] != 0.f) unsafeAtomicAdd(base + (size_t)o * INL + i, a[r]);
-    }
-  };
-  if (dW) {
-#pragma unroll
-    for (int b = 0; b < NBLK_LAST; ++b) { int blk = wave + 4 * b; if (blk < OB * NB) flush(dw_last[b], blk / NB, blk % NB, OUT, HID, L.w_off[L.n - 1]); }
-    if (NHID == 2) {
-#pragma unroll
-      for (int b = 0; b < NBLK_MID; ++b) { int blk = wave + 4 * b; if (blk < NB * NB) flush(dw_mid[b], blk / NB, blk % NB, HID, HID, L.w_off[1]); }
-    }
-#pragma unroll
-    for (int b = 0; b < NBLK_FIRST; ++b) { int blk = wave + 4 * b; if (blk < NB * IB) flush(dw_first[b], blk / IB, blk % IB, HID, IN, L.w_off[0]); }
-  }
-  if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
-}
-
-template <int IN, int HID, int OUT, int NHID>
-static int launch_bwd_fused(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int rows,
-                            const int* rows_dev, void* d_in, float* dW, int* found_inf, hipStream_t s) {
-  constexpr int PD = HID + 8, PX = (HID > IN ? HID : IN) + 8, PO = OUT + 8;
-  size_t halves = (size_t)aln_mlp_frag_halves(IN, HID, OUT, NHID, 1);
-  size_t lds = (halves + 128 * (size_t)(PD + PX + PO)) * 2;
-  ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_fused: LDS %zu B exceeds 160 KiB", lds);
-  int tiles = (rows + 127) / 128;
-  int g = tiles < 256 ? tiles : 256;
-  hipFuncSetAttribute((const void*)k_mlp_bwd_fused<IN, HID, OUT, NHID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_mlp_bwd_fused<IN, HID, OUT, NHID>), dim3(g), dim3(256), lds, s, (const h16*)m->wb, halves, (const h16*)x,
-                     (const h16*)h1, (const h16*)h2, (const h16*)d_out, rows, rows_dev, (h16*)d_in, dW, found_inf);
-  ALN_CHECK_LAUNCH("mlp_bwd_fused");
-  return 0;
 }
 
 // relu'(h) mask read back from the LDS tile holding h (C-layout 8-byte chunks)
@@ -1285,11 +1126,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
     PT_FLUSH(1)
     if (dW) {
       bool bad = false;
-      // With a partial-sum workspace (dw_ws: one [n_weights] slab per block) the block's sums leave as plain coalesced stores
-      // and k_dw_reduce adds the slabs up in a fixed order: no atomics, bit-reproducible weight gradients.  Measured before:
+      // The block's sums leave as plain coalesced stores into its slab of the partial-sum workspace (dw_ws: one [n_weights] slab
+      // per block) and k_dw_reduce adds the slabs up in a fixed order: no atomics, bit-reproducible weight gradients.  Measured before:
       // 256-512 blocks finishing together and adding into the same 9-25 K floats with fp32 atomics cost ~0.1 us per block
       // (27 us of a 115 us launch for the 64-wide heads) -- every line takes one add per block, serialised at the memory side.
-      float* const slab = dw_ws ? dw_ws + (size_t)blockIdx.x * (L.w_off[L.n - 1] + (size_t)L.in_[L.n - 1] * L.out_[L.n - 1]) : nullptr;
+      float* const slab = dw_ws + (size_t)blockIdx.x * (L.w_off[L.n - 1] + (size_t)L.in_[L.n - 1] * L.out_[L.n - 1]);
       auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, size_t off) {
         const int i = 32 * ib + c;
 #pragma unroll
@@ -1297,8 +1138,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
           const int o = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
           const bool in_w = o < OUTL && i < INL;
           bad |= in_w && !(fabsf(a[r]) <= 3.0e38f);
-          if (slab) { if (in_w) slab[off + (size_t)o * INL + i] = a[r]; }
-          else if (in_w && a[r] != 0.f) unsafeAtomicAdd(dW + off + (size_t)o * INL + i, a[r]);
+          if (in_w) slab[off + (size_t)o * INL + i] = a[r];
         }
       };
 #pragma unroll
@@ -1359,8 +1199,9 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
   int g = tiles < gmax ? tiles : gmax;
   const MlpLayers LL = mlp_layers(IN, HID, OUT, NHID);
   const int n_w = (int)(LL.w_off[LL.n - 1] + (size_t)LL.in_[LL.n - 1] * LL.out_[LL.n - 1]);
-  static const bool use_ws = !(getenv("ALN_MLP_DW") && !strcmp(getenv("ALN_MLP_DW"), "atomic"));   // A/B switch
-  float* ws = (dW && use_ws && m->dw_ws && (size_t)m->dw_ws_bytes >= (size_t)g * n_w * sizeof(float)) ? (float*)m->dw_ws : nullptr;
+  ALN_REQUIRE(!dW || (m->dw_ws && (size_t)m->dw_ws_bytes >= (size_t)g * n_w * sizeof(float)),
+              "mlp_bwd: AlnMlpDesc.dw_ws must hold %d slabs of %d floats (aln_mlp_dw_ws_bytes)", g, n_w);
+  float* ws = dW ? (float*)m->dw_ws : nullptr;
 #define LAUNCH_SRC(XM, DM)                                                                                                  \
   do {                                                                                                                     \
     hipFuncSetAttribute((const void*)k_mlp_bwd_recomp8<IN, HID, OUT, NHID, XM, DM, OCC2, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -1388,291 +1229,24 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
   return 0;
 }
 // 64-wide heads with a narrow input (semantic_features): two blocks per CU (OCC2).  Measured in the training step (2^20 rows,
-// on-the-fly row sources): one block 172 us, OCC2 150 us, 256-row tiles with two sub-tiles per chain wave (RPW = 2) 201 us (105 vs
-// 120 us on plain sources: the late per-ray loads and 33 spilled registers eat the gain).  ALN_MLP_OCC2=0 / ALN_MLP_RPW=2 select
-// the other variants for A/B timing.
+// on-the-fly row sources): one block per CU 172 us, OCC2 150 us.
 template <int IN, int HID, int OUT, int NHID>
 static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in,
                              float* dW, int* found_inf, hipStream_t s) {
-  if constexpr (HID == 64) {
-    constexpr int IB = (IN + 31) / 32, OB = (OUT + 31) / 32, PO = OB * 32 + (OB == 1 ? 0 : 8);
+  if constexpr (HID == 64 && IN <= 32) {   // (IN = 80, semantic_out, does not fit the 128-VGPR budget of two blocks per CU)
+    constexpr int OB = (OUT + 31) / 32, PO = OB * 32 + (OB == 1 ? 0 : 8);
     const size_t halves = (size_t)aln_mlp_rowmajor_halves(IN, HID, OUT, NHID);
-    const size_t lds_rpw2 = (((halves + 7) & ~(size_t)7) + 256 * (size_t)(IB * 32 + 8 + 2 * hid_pitch(HID) + PO)) * 2;
-    static const int rpw = getenv("ALN_MLP_RPW") ? atoi(getenv("ALN_MLP_RPW")) : 1;
-    if constexpr (IN <= 32) {   // (IN = 80, semantic_out, spills 90-150 registers with either variant: measured 118 -> 264 us / 157 -> 232 us)
-      if (rpw == 2 && lds_rpw2 <= 160 * 1024)
-        return launch_bwd_recomp_occ<IN, HID, OUT, NHID, false, 2>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
-      const size_t lds2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(IN + 8 + 2 * hid_pitch(HID) + PO)) * 2;
-      static const bool want = !(getenv("ALN_MLP_OCC2") && atoi(getenv("ALN_MLP_OCC2")) == 0);
-      if (want && lds2 <= 80 * 1024) return launch_bwd_recomp_occ<IN, HID, OUT, NHID, true, 1>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
-    }
+    const size_t lds2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(IN + 8 + 2 * hid_pitch(HID) + PO)) * 2;
+    if (lds2 <= 80 * 1024) return launch_bwd_recomp_occ<IN, HID, OUT, NHID, true, 1>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
   }
   return launch_bwd_recomp_occ<IN, HID, OUT, NHID, false, 1>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
 }
 
-// ---------------------------------------------------------------- both semantic heads, backward, ONE kernel
-// semantic_features (geo 16 -> 64 -> 64 -> f 64) and semantic_out (cat[relu(f), geo] 80 -> 64 -> logits) of models.py:248-256
-// as one five-layer chain with a tap (f takes the feature-loss gradient w_row * g_feat[ray]) and a skip (geo enters layer 4).
-// The two-launch path (k_mlp_bwd_recomp8 twice) reads f back (128 B/row), writes d(semantic_out input) [rows, 80] and reads it
-// back for the tap: 420 B/row of HBM traffic and two sets of barriers / tile loads for ~2000 MFMA cycles of work per tile.
-// Here nothing but sigma_out (32 B), w_row and the per-ray output gradients come in and one 32-byte d(geo) row goes out;
-// f, relu(f) and every hidden activation are recomputed in registers and parked in LDS only as weight-gradient operands.
-// Same roles as k_mlp_bwd_recomp8: waves 0-3 run the register chain on 32 rows each, waves 4-7 accumulate dW for the
-// 128-row tile; LDS tiles are reused activation -> gradient (h -> dh) between barrier pairs.
-template <int NBLK, int NOB, int NIB, class TVA, class BFrag>
-__device__ inline void dw_accumulate_v(f32x16 (&dw)[NBLK], TVA tA, BFrag bfrag, int wave, int lane) {
-  h16x8 a[2][NBLK], bq[2][NBLK];
-  auto fetch = [&](int ks, int slot) {
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-      const int blk = wave + 4 * b;
-      if (blk < NOB * NIB) { a[slot][b] = tr_frag(tA, 32 * (blk / NIB), ks, lane); bq[slot][b] = bfrag(blk % NIB, ks); }
-    }
-  };
-  fetch(0, 0);
-#pragma unroll
-  for (int ks = 0; ks < 128 / 16; ++ks) {
-    if (ks + 1 < 128 / 16) fetch(ks + 1, (ks + 1) & 1);
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-      const int blk = wave + 4 * b;
-      if (blk < NOB * NIB) dw[b] = mfma16(a[ks & 1][b], bq[ks & 1][b], dw[b]);
-    }
-  }
-}
-// p = fp16( relu'(act) * acc + add ): the tap of the fused semantic backward (act, add: LDS tiles in C-layout 8-byte pieces)
-template <int NB, int NA, class TV>
-__device__ inline void mask_add_pack_lds(f32x16 (&acc)[NA], h16x8 (&p)[2 * NB], TV tact, TV tadd, int srow, int hf) {
-  u32x2 a[NB][4], d[NB][4];
-#pragma unroll
-  for (int m = 0; m < NB; ++m)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      a[m][q] = *(const LDS_VEC(u32x2)*)tact.at(srow, 32 * m + 8 * q + 4 * hf);
-      d[m][q] = *(const LDS_VEC(u32x2)*)tadd.at(srow, 32 * m + 8 * q + 4 * hf);
-    }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int m = 0; m < NB; ++m)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      union { u32x2 u; h16x4 h; } av, dv; av.u = a[m][q]; dv.u = d[m][q];
-      float g[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) g[r] = ((float)av.h[r] > 0.f ? acc[m][4 * q + r] : 0.f) + (float)dv.h[r];
-      uint32_t* w = (uint32_t*)&p[2 * m + (q >> 1)];
-      w[2 * (q & 1)] = cvt_pk(g[0], g[1]);
-      w[2 * (q & 1) + 1] = cvt_pk(g[2], g[3]);
-    }
-}
-
-template <int OUT>   // OUT = padded class count (16, 32, 48, 64)
-__global__ __launch_bounds__(512) void k_sem_bwd_fused5(const h16* __restrict__ wr_f, size_t halves_f, const h16* __restrict__ wr_o,
-                                                        size_t halves_o, RowSrc xs, RowSrc dls, RowSrc dfs, int rows,
-                                                        h16* __restrict__ d_geo, float* __restrict__ dW_f, float* __restrict__ dW_o,
-                                                        float* __restrict__ ws_f, float* __restrict__ ws_o,
-                                                        int* __restrict__ found_inf) {
-  constexpr int IN = 16, HID = 64, D = 64, NB = 2, KS = 4, KSO = OUT / 16, OB = (OUT + 31) / 32, INO = D + 16, IBO = 3;
-  constexpr int PW0 = IN + 8, PH = hid_pitch(HID), PM0 = INO + 8, PX = 40, PO = OB * 32 + (OB == 1 ? 0 : 8), TR = 128;
-  constexpr int NBLK_M1 = (OB * NB + 3) / 4, NBLK_M0 = (NB * IBO + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  lds_h16* W0 = (lds_h16*)smem;                         // semantic_features, row-major (k_mlp_rowmajor image)
-  lds_h16* W1 = W0 + HID * PW0;
-  lds_h16* W2 = W1 + HID * PH;
-  lds_h16* M0 = W0 + (int)((halves_f + 7) & ~(size_t)7); // semantic_out
-  lds_h16* M1 = M0 + HID * PM0;
-  lds_h16* tX = M0 + (int)((halves_o + 7) & ~(size_t)7);
-  lds_h16* tH1 = tX + TR * PX;
-  lds_h16* tH2 = tH1 + TR * PH;
-  lds_h16* tRF = tH2 + TR * PH;
-  lds_h16* tG1 = tRF + TR * PH;
-  lds_h16* tDF = tG1 + TR * PH;
-  lds_h16* tDL = tDF + TR * PH;
-  const PlainV<lds_h16*> vW0{W0, PW0}, vW1{W1, PH}, vW2{W2, PH}, vM0{M0, PM0}, vM1{M1, PH}, vX{tX, PX}, vH1{tH1, PH}, vH2{tH2, PH},
-      vRF{tRF, PH}, vG1{tG1, PH}, vDF{tDF, PH}, vDL{tDL, PO};
-  copy_to_lds((h16*)W0, wr_f, halves_f);
-  copy_to_lds((h16*)M0, wr_o, halves_o);
-  for (int i = threadIdx.x; i < TR * PX; i += 512) tX[i] = (h16)0.f;
-  for (int i = threadIdx.x; i < TR * PO; i += 512) tDL[i] = (h16)0.f;
-  const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool chain = wave < 4;
-  const int cw = wave & 3;
-  const int srow = cw * 32 + c;
-  const int ntiles = (rows + TR - 1) / TR;
-  constexpr int XCH = IN / 8, LCH = OUT / 8, FCH = D / 8;
-  constexpr int NXS = (TR * XCH + 511) / 512, NLS = (TR * LCH + 511) / 512, NFS = (TR * FCH + 511) / 512;
-  RawChunk px[NXS], pl[NLS], pf[NFS];
-  auto prefetch = [&](int r0) {
-#pragma unroll
-    for (int q = 0; q < NXS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
-      if (i < TR * XCH && r0 + r < rows) raw_load<SRC_SEMF_IN>(px[q], xs, r0 + r, 8 * k);
-    }
-#pragma unroll
-    for (int q = 0; q < NLS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / LCH, k = i % LCH;
-      if (i < TR * LCH && r0 + r < rows) raw_load<SRC_DLOGITS>(pl[q], dls, r0 + r, 8 * k);
-    }
-#pragma unroll
-    for (int q = 0; q < NFS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / FCH, k = i % FCH;
-      if (i < TR * FCH && r0 + r < rows) raw_load<SRC_DLOGITS>(pf[q], dfs, r0 + r, 8 * k);
-    }
-  };
-  auto stash = [&](int r0) {
-    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < NXS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
-      if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX + r * PX + 8 * k) = (r0 + r < rows) ? raw_finish<SRC_SEMF_IN>(px[q], xs, 8 * k) : z;
-    }
-#pragma unroll
-    for (int q = 0; q < NLS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / LCH, k = i % LCH;
-      if (i < TR * LCH) *(LDS_VEC(h16x8)*)(tDL + r * PO + 8 * k) = (r0 + r < rows) ? raw_finish<SRC_DLOGITS>(pl[q], dls, 8 * k) : z;
-    }
-#pragma unroll
-    for (int q = 0; q < NFS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / FCH, k = i % FCH;
-      if (i < TR * FCH) *(LDS_VEC(h16x8)*)(tDF + r * PH + 8 * k) = (r0 + r < rows) ? raw_finish<SRC_DLOGITS>(pf[q], dfs, 8 * k) : z;
-    }
-  };
-  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x * TR);
-  if (chain) {
-    h16x2 nanz = {0, 0};
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int r0 = tile * TR;
-      __syncthreads();   // B0: the weight-gradient waves are done with the previous tile
-      stash(r0);
-      __syncthreads();   // B1
-      { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
-      f32x16 acc[NB];
-      h16x8 p[KS];
-      auto xchunk = [&]() -> h16x8 { return *(const LDS_VEC(h16x8)*)(tX + srow * PX + 8 * hf); };
-      // ---- forward recompute: geo -> h1 -> h2 -> f -> relu(f) ++ geo -> g1
-      chain_layer<NB, 1>(acc, [&](int m, int ks) { return fwd_frag_natural(W0, PW0, m, ks, lane); }, [&](int) { return xchunk(); });
-      relu_pack_store<NB>(acc, p, nullptr, hf);
-      write_packed_tile<NB>(vH1, srow, p, hf);
-      chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(vW1, m, ks, lane); }, [&](int ks) { return p[ks]; });
-      relu_pack_store<NB>(acc, p, nullptr, hf);
-      write_packed_tile<NB>(vH2, srow, p, hf);
-      chain_layer<NB, KS>(acc, [&](int m, int ks) { return fwd_frag_chained(vW2, m, ks, lane); }, [&](int ks) { return p[ks]; });
-      relu_pack_store<NB>(acc, p, nullptr, hf);      // relu(fp16(f)): what semantic_out sees; f > 0 <=> relu(f) bits != 0
-      write_packed_tile<NB>(vRF, srow, p, hf);
-      chain_layer<NB, KS + 1>(acc,
-                              [&](int m, int ks) -> h16x8 {
-                                if (ks < KS) return fwd_frag_chained(vM0, m, ks, lane);
-                                return *(const LDS_VEC(h16x8)*)(M0 + (32 * m + c) * PM0 + D + 8 * hf);
-                              },
-                              [&](int ks) -> h16x8 { return ks < KS ? p[ks] : xchunk(); });
-      relu_pack_store<NB>(acc, p, nullptr, hf);
-      write_packed_tile<NB>(vG1, srow, p, hf);
-      __syncthreads();   // B2
-      // ---- semantic_out backward
-      chain_layer<NB, KSO>(acc, [&](int m, int ks) { return tr_frag(vM1, 32 * m, ks, lane); },
-                           [&](int ks) { return *(const LDS_VEC(h16x8)*)(tDL + srow * PO + 16 * ks + 8 * hf); });
-      mask_pack_lds<NB>(acc, p, vG1, srow, hf);                         // d g1
-      __syncthreads();   // B3: dM1 has consumed g1
-      write_packed_tile<NB>(vG1, srow, p, hf);
-      __syncthreads();   // B4
-      f32x16 o[IBO];                                                     // d relu(f) (2 blocks), d geo through the skip (1 block)
-      chain_layer<IBO, KS>(o, [&](int ib, int ks) { return tr_frag_chained(vM0, 32 * ib, ks, lane); }, [&](int ks) { return p[ks]; });
-      mask_add_pack_lds<NB, IBO>(o, p, vRF, vDF, srow, hf);             // d f = relu'(f) * d relu(f) + w_row * g_feat[ray]
-      const f32x16 dgeo_skip = o[2];
-      __syncthreads();   // B5: dM0 has consumed relu(f)
-      write_packed_tile<NB>(vRF, srow, p, hf);
-      __syncthreads();   // B6
-      // ---- semantic_features backward
-      chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(vW2, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
-      mask_pack_lds<NB>(acc, p, vH2, srow, hf);                         // d h2
-      __syncthreads();   // B7: dL2 has consumed h2
-      write_packed_tile<NB>(vH2, srow, p, hf);
-      __syncthreads();   // B8
-      chain_layer<NB, KS>(acc, [&](int m, int ks) { return tr_frag_chained(vW1, 32 * m, ks, lane); }, [&](int ks) { return p[ks]; });
-      mask_pack_lds<NB>(acc, p, vH1, srow, hf);                         // d h1
-      __syncthreads();   // B9: dL1 has consumed h1
-      write_packed_tile<NB>(vH1, srow, p, hf);
-      __syncthreads();   // B10
-      {
-        const int row = r0 + srow;
-        f32x16 og[1];
-        chain_layer<1, KS>(og, [&](int, int ks) { return tr_frag_chained(vW0, 0, ks, lane); }, [&](int ks) { return p[ks]; });
-        if (row < rows) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {                                  // features 8q + 4hf + r < 16
-            h16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (h16)(og[0][4 * q + r] + dgeo_skip[4 * q + r]);
-            nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
-            *(h16x4*)(d_geo + (size_t)row * IN + 8 * q + 4 * hf) = v;
-          }
-        }
-      }
-    }
-    if (found_inf && __any(nan_bad(nanz)) && lane == 0) atomicOr(found_inf, 1);
-  } else {
-    const MlpLayers LF = mlp_layers(IN, HID, D, 2), LO = mlp_layers(INO, HID, OUT, 1);
-    f32x16 dw_m1[NBLK_M1], dw_m0[NBLK_M0], dw_l2[1], dw_l1[1], dw_l0[1];
-    zero_acc(dw_m1); zero_acc(dw_m0); zero_acc(dw_l2); zero_acc(dw_l1); zero_acc(dw_l0);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int r0 = tile * TR;
-      __syncthreads();   // B0
-      stash(r0);
-      __syncthreads();   // B1
-      { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
-      __syncthreads();   // B2
-      dw_accumulate<NBLK_M1, OB, NB>(dw_m1, vDL, vG1, cw, lane);        // dM1 += dlogits^T g1
-      __syncthreads();   // B3
-      __syncthreads();   // B4
-      dw_accumulate_v<NBLK_M0, NB, IBO>(dw_m0, vG1, [&](int ib, int ks) -> h16x8 {   // dM0 += dg1^T [relu(f), geo]
-        return ib < 2 ? tr_frag(vRF, 32 * ib, ks, lane) : tr_frag(vX, 0, ks, lane);
-      }, cw, lane);
-      __syncthreads();   // B5
-      __syncthreads();   // B6
-      dw_accumulate<1, NB, NB>(dw_l2, vRF, vH2, cw, lane);              // dL2 += df^T h2
-      __syncthreads();   // B7
-      __syncthreads();   // B8
-      dw_accumulate<1, NB, NB>(dw_l1, vH2, vH1, cw, lane);              // dL1 += dh2^T h1
-      __syncthreads();   // B9
-      __syncthreads();   // B10
-      dw_accumulate<1, NB, 1>(dw_l0, vH1, vX, cw, lane);                // dL0 += dh1^T geo
-    }
-    if (dW_f && dW_o) {
-      bool bad = false;
-      const size_t nwf = LF.w_off[2] + (size_t)HID * D, nwo = LO.w_off[1] + (size_t)HID * OUT;
-      float* const slab_f = ws_f ? ws_f + (size_t)blockIdx.x * nwf : nullptr;
-      float* const slab_o = ws_o ? ws_o + (size_t)blockIdx.x * nwo : nullptr;
-      auto flush = [&](f32x16& a, int ob, int ib, int OUTL, int INL, float* slab, float* dW, size_t off) {
-        const int i = 32 * ib + c;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int oo = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * hf;
-          const bool in_w = oo < OUTL && i < INL;
-          bad |= in_w && !(fabsf(a[r]) <= 3.0e38f);
-          if (slab) { if (in_w) slab[off + (size_t)oo * INL + i] = a[r]; }
-          else if (in_w && a[r] != 0.f) unsafeAtomicAdd(dW + off + (size_t)oo * INL + i, a[r]);
-        }
-      };
-#pragma unroll
-      for (int b = 0; b < NBLK_M1; ++b) { const int blk = cw + 4 * b; if (blk < OB * NB) flush(dw_m1[b], blk / NB, blk % NB, OUT, HID, slab_o, dW_o, LO.w_off[1]); }
-#pragma unroll
-      for (int b = 0; b < NBLK_M0; ++b) { const int blk = cw + 4 * b; if (blk < NB * IBO) flush(dw_m0[b], blk / IBO, blk % IBO, HID, INO, slab_o, dW_o, LO.w_off[0]); }
-      if (cw < NB * NB) {
-        flush(dw_l2[0], cw / NB, cw % NB, D, HID, slab_f, dW_f, LF.w_off[2]);
-        flush(dw_l1[0], cw / NB, cw % NB, HID, HID, slab_f, dW_f, LF.w_off[1]);
-      }
-      if (cw < NB) flush(dw_l0[0], cw, 0, HID, IN, slab_f, dW_f, LF.w_off[0]);
-      if (found_inf && __any(bad) && lane == 0) atomicOr(found_inf, 1);
-    }
-  }
-}
-
 // ---------------------------------------------------------------- launchers
 static int mlp_grid(int rows) {
-  // blocks per launch of the forward / data-gradient kernels (256 threads, weights in LDS): ALN_MLP_FWD_GRID, default 3 per CU
+  // blocks per launch of the forward / data-gradient kernels (256 threads, weights in LDS): 3 per CU
   // (the 128-wide heads' fragment images are 48-52 KB and the kernels use <= 168 VGPRs, so three blocks fit a CU)
-  static const int cap = getenv("ALN_MLP_FWD_GRID") ? atoi(getenv("ALN_MLP_FWD_GRID")) : 768;
+  const int cap = 768;
   int tiles = (rows + 127) / 128;
   int g = tiles < cap ? tiles : cap;
   return g < 1 ? 1 : g;
@@ -1775,13 +1349,6 @@ extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, c
   ALN_REQUIRE(!dW || (x && dA1 && (m->n_hidden == 1 || dA2)), "mlp_bwd: dW needs x, dA1, dA2 buffers");
   if (rows <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (dW && !getenv("ALN_MLP_BWD_UNFUSED")) {
-#define TRY(I, H, O, N)                                                                                   \
-    if (m->in_pad == I && m->hidden == H && m->out_pad == O && m->n_hidden == N)                          \
-      return launch_bwd_fused<I, H, O, N>(m, x, h1, h2, d_out, rows, rows_dev, d_in, dW, found_inf, s);
-    TRY(48, 128, 16, 2) TRY(32, 128, 16, 2) TRY(64, 128, 16, 2) TRY(16, 64, 64, 2) TRY(80, 64, 16, 1) TRY(80, 64, 32, 1)
-#undef TRY
-  }
   size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 1);
   size_t lds = halves * 2;
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd: weights (%zu B) exceed LDS", lds);
@@ -1832,7 +1399,7 @@ extern "C" int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
   ALN_REQUIRE(semf && semo && sigma_out && feat && logits, "sem_heads_fwd: NULL pointer");
   ALN_REQUIRE(semf->out_pad == D && semo->in_pad >= D + G + 1 && D % 8 == 0, "sem_heads_fwd: shape mismatch");
   if (semf->in_pad == 16 && semf->hidden == 64 && semf->n_hidden == 2 && semf->out_pad == 64 && D == 64 && semo->in_pad == 80 &&
-      semo->hidden == 64 && semo->n_hidden == 1 && semo->out_pad <= 64 && semf->wf && semo->wf && !getenv("ALN_SEM_FWD_UNFUSED")) {
+      semo->hidden == 64 && semo->n_hidden == 1 && semo->out_pad <= 64 && semf->wf && semo->wf) {
     if (rows <= 0) return 0;
     size_t hf_ = (size_t)aln_mlp_frag_halves(16, 64, 64, 2, 0), ho_ = (size_t)aln_mlp_frag_halves(80, 64, semo->out_pad, 1, 0);
     size_t lds = (((hf_ + 7) & ~(size_t)7) + ((ho_ + 7) & ~(size_t)7) + 4 * 32 * (64 + 8)) * 2;
@@ -1867,60 +1434,4 @@ extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
   RowSrc gf{}; gf.mode = SRC_DSEMF_OUT; gf.a = (const h16*)feat; gf.lda = D; gf.b = (const h16*)d_semo_in; gf.ldb = semo->in_pad;
   gf.w_row = w_row; gf.g = g_feat; gf.gw = D; gf.N = N; gf.S1 = S1; gf.S2 = S2 > 0 ? S2 : 1; gf.D = D; gf.fold_geo = fold_geo;
   return mlp_bwd_recomp_src(semf, xf, gf, rows, nullptr, d_semf_in, dW_semf, found_inf, s);
-}
-
-// One-kernel form (k_sem_bwd_fused5): d_geo [rows, 16] = d(semantic_features input) + the geo_feat columns of d(semantic_out
-// input) -- what k_assemble_dsigma_out needs from the two heads; `feat` is not read (f is recomputed).
-extern "C" int aln_sem_heads_bwd_fused_ok(const AlnMlpDesc* semf, const AlnMlpDesc* semo, int32_t D) {
-  // Measured (bench scene, 2^20 rows): 340 us against 149 + 156 us for the two launches -- the phases of these 64-wide heads are
-  // bound by their dependent LDS / MFMA / barrier latencies, not by the HBM traffic the fusion removes, and the fused chain just
-  // adds the phases up.  Kept behind ALN_SEM_BWD_FUSED5=1 (parity-tested) as the base for a sub-tiled version.
-  if (!semf || !semo || !getenv("ALN_SEM_BWD_FUSED5") || atoi(getenv("ALN_SEM_BWD_FUSED5")) != 1) return 0;
-  return D == 64 && semf->in_pad == 16 && semf->hidden == 64 && semf->out_pad == 64 && semf->n_hidden == 2 && semo->in_pad == 80 &&
-         semo->hidden == 64 && semo->n_hidden == 1 && (semo->out_pad == 16 || semo->out_pad == 32 || semo->out_pad == 48 || semo->out_pad == 64) &&
-         semf->wr && semo->wr;
-}
-template <int OUT>
-static int launch_sem_bwd_fused5(const AlnMlpDesc* semf, const AlnMlpDesc* semo, RowSrc xs, RowSrc dls, RowSrc dfs, int rows, void* d_geo,
-                                 float* dW_f, float* dW_o, int* found_inf, hipStream_t s) {
-  constexpr int OB = (OUT + 31) / 32, PO = OB * 32 + (OB == 1 ? 0 : 8);
-  const size_t hf_ = (size_t)aln_mlp_rowmajor_halves(16, 64, 64, 2), ho_ = (size_t)aln_mlp_rowmajor_halves(80, 64, OUT, 1);
-  const size_t lds = (((hf_ + 7) & ~(size_t)7) + ((ho_ + 7) & ~(size_t)7) + 128 * (size_t)(40 + 5 * hid_pitch(64) + PO)) * 2;
-  ALN_REQUIRE(lds <= 160 * 1024, "sem_heads_bwd_fused: LDS %zu B exceeds 160 KiB", lds);
-  const int tiles = (rows + 127) / 128, g = tiles < 256 ? tiles : 256;
-  const size_t nwf = 16 * 64 + 64 * 64 + 64 * 64, nwo = 80 * 64 + 64 * (size_t)OUT;
-  static const bool use_ws = !(getenv("ALN_MLP_DW") && !strcmp(getenv("ALN_MLP_DW"), "atomic"));
-  const bool slabs = dW_f && dW_o && use_ws && semf->dw_ws && semo->dw_ws && (size_t)semf->dw_ws_bytes >= g * nwf * sizeof(float) &&
-                     (size_t)semo->dw_ws_bytes >= g * nwo * sizeof(float);
-  float* ws_f = slabs ? (float*)semf->dw_ws : nullptr;
-  float* ws_o = slabs ? (float*)semo->dw_ws : nullptr;
-  hipFuncSetAttribute((const void*)k_sem_bwd_fused5<OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_sem_bwd_fused5<OUT>), dim3(g), dim3(512), lds, s, (const h16*)semf->wr, hf_, (const h16*)semo->wr, ho_, xs, dls,
-                     dfs, rows, (h16*)d_geo, dW_f, dW_o, ws_f, ws_o, found_inf);
-  ALN_CHECK_LAUNCH("sem_bwd_fused5");
-  if (slabs) {
-    hipLaunchKernelGGL(k_dw_reduce, dim3(((int)nwf + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, ws_f, g, (int)nwf, dW_f);
-    hipLaunchKernelGGL(k_dw_reduce, dim3(((int)nwo + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, ws_o, g, (int)nwo, dW_o);
-    ALN_CHECK_LAUNCH("dw_reduce");
-  }
-  return 0;
-}
-extern "C" int aln_sem_heads_bwd_fused(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const float* w_row,
-                                       const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C,
-                                       int32_t rows, int32_t D, int32_t G, void* d_geo, float* dW_semf, float* dW_semo,
-                                       int32_t* found_inf, void* stream) {
-  ALN_REQUIRE(semf && semo && sigma_out && w_row && g_sem && g_feat && d_geo, "sem_heads_bwd_fused: NULL pointer");
-  ALN_REQUIRE(aln_sem_heads_bwd_fused_ok(semf, semo, D), "sem_heads_bwd_fused: unsupported head shapes (use aln_sem_heads_bwd)");
-  ALN_REQUIRE(C <= semo->out_pad && G <= 15 && (!dW_semf == !dW_semo), "sem_heads_bwd_fused: bad C / G / dW arguments");
-  if (rows <= 0) return 0;
-  RowSrc xs{}; xs.mode = SRC_SEMF_IN; xs.a = (const h16*)sigma_out; xs.lda = 16; xs.G = G; xs.D = D;
-  RowSrc dl{}; dl.mode = SRC_DLOGITS; dl.w_row = w_row; dl.g = g_sem; dl.gw = C; dl.N = N; dl.S1 = S1; dl.S2 = S2 > 0 ? S2 : 1;
-  RowSrc df = dl; df.g = g_feat; df.gw = D;
-  hipStream_t s = (hipStream_t)stream;
-  switch (semo->out_pad) {
-    case 16: return launch_sem_bwd_fused5<16>(semf, semo, xs, dl, df, rows, d_geo, dW_semf, dW_semo, found_inf, s);
-    case 32: return launch_sem_bwd_fused5<32>(semf, semo, xs, dl, df, rows, d_geo, dW_semf, dW_semo, found_inf, s);
-    case 48: return launch_sem_bwd_fused5<48>(semf, semo, xs, dl, df, rows, d_geo, dW_semf, dW_semo, found_inf, s);
-    default: return launch_sem_bwd_fused5<64>(semf, semo, xs, dl, df, rows, d_geo, dW_semf, dW_semo, found_inf, s);
-  }
 }

@@ -292,25 +292,18 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
   hipStream_t s = (hipStream_t)stream;
   // (measured on the 1M x 512 x 512 layers: wave tile 32 x 128 at 2 waves/SIMD 1.3 ms; 64 x 128 needs > 256 VGPRs, one wave per
   //  SIMD: 1.5 ms)
-  static const int mt = getenv("ALN_WIDE_MT") ? atoi(getenv("ALN_WIDE_MT")) : 1;
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm + 7) / 8 * 8 * ((N + bn - 1) / bn))); };
-  static const bool no_dma = getenv("ALN_WIDE_NODMA") != nullptr;
-  if (!no_dma && a1 && !geo && !relu1 && p.K % 64 == 0 && ((uintptr_t)a1 & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+  if (a1 && !geo && !relu1 && p.K % 64 == 0 && ((uintptr_t)a1 & 15) == 0 && ((uintptr_t)w & 15) == 0) {
+    // plain operands: tiles filled by global_load_lds (k_wide_nt_dma)
     if (N > 64) hipLaunchKernelGGL((k_wide_nt_dma<128>), grid(128, 128), dim3(256), 0, s, p);
     else if (N > 32) hipLaunchKernelGGL((k_wide_nt_dma<64>), grid(128, 64), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_wide_nt_dma<32>), grid(128, 32), dim3(256), 0, s, p);
     ALN_CHECK_LAUNCH("wide_nt_dma");
     return 0;
   }
-  if (mt == 2) {
-    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 2>), grid(256, 128), dim3(256), 0, s, p);
-    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 2>), grid(256, 64), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_wide_nt<32, 2>), grid(256, 32), dim3(256), 0, s, p);
-  } else {
-    if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 1>), grid(128, 128), dim3(256), 0, s, p);
-    else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 1>), grid(128, 64), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_wide_nt<32, 1>), grid(128, 32), dim3(256), 0, s, p);
-  }
+  if (N > 64) hipLaunchKernelGGL((k_wide_nt<128, 1>), grid(128, 128), dim3(256), 0, s, p);
+  else if (N > 32) hipLaunchKernelGGL((k_wide_nt<64, 1>), grid(128, 64), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((k_wide_nt<32, 1>), grid(128, 32), dim3(256), 0, s, p);
   ALN_CHECK_LAUNCH("wide_nt");
   return 0;
 }

@@ -5,7 +5,6 @@ forward, GradScaler-scaled backward, per-optimizer step, scaler.update) with no 
 scale, the overflow flag, the optimizer step counter and the loss terms all live on the device.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -18,9 +17,13 @@ SCALER_DEFAULTS = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5
 class TrainEngine:
     def __init__(self, pipe, lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6, rgb_weight=1.0, depth_weight=0.1,
                  semantic_weight=1.0, feature_weight=0.5, feature_loss=False, num_steps=128, upsample_steps=128,
-                 scaler=None, process_group=None):
+                 scaler=None, process_group=None, overlap_comm=True, grad_payload='f16'):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
         dv = self.P.device
+        # the step's intermediates live in a workspace of the engine's own: a render through the same pipeline (pipe.ws) between
+        # two steps cannot move the buffers a captured step points into
+        from .pipeline import Workspace
+        self.ws = Workspace(dv)
         self._lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(weight_decay_net)
         self.weights = (float(rgb_weight), float(depth_weight), float(semantic_weight), float(feature_weight))
         self.feature_loss = feature_loss
@@ -30,7 +33,7 @@ class TrainEngine:
         n = self.L.n_total
         self.m = torch.zeros(n, device=dv)
         self.v = torch.zeros(n, device=dv)
-        self.state_i = torch.zeros(16, dtype=torch.int32, device=dv)  # [steps, growth tracker, found_inf, -, per-block steps]
+        self.state_i = torch.zeros(16, dtype=torch.int32, device=dv)  # [steps, growth tracker, found_inf, scatter found_inf (DP overlap), per-block steps]
         self.state_f = torch.tensor([sc['init_scale'], float(lr), 0, 0], dtype=torch.float32, device=dv)  # [loss scale, lr]
         self.consts = torch.zeros(24, device=dv)
         # parameter blocks = the reference's parameter tensors (torch skips tensors whose grad is None)
@@ -48,7 +51,8 @@ class TrainEngine:
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         # data parallel: the gradient all-reduce runs in buckets on a side stream while the hash-grid scatter is still
         # working on the remaining levels (the scatter is the last and longest kernel of the backward pass)
-        self.overlap_comm = self.world > 1 and os.environ.get('ALN_DP_OVERLAP', '1') != '0'   # ALN_DP_OVERLAP=0: one collective
+        self.overlap_comm = self.world > 1 and bool(overlap_comm)   # False: one collective after the backward pass
+        self.grad_payload = grad_payload     # 'f16': the hash-grid gradient crosses the wire as fp16 (parallel.allreduce_bucket)
         self._comm = torch.cuda.Stream(device=dv) if self.world > 1 else None
         self._g = {}
         # occupancy-grid marching (pipe.occ set by enable_marching / ALNetwork(cuda_ray=True)): S1 rows per ray inside occupied
@@ -83,7 +87,7 @@ class TrainEngine:
         L, pipe = self.L, self.pipe
         N = batch['rays_o'].shape[0]
         out, ctx = pipe.forward(batch['rays_o'], batch['rays_d'], batch['direction_norms'].reshape(-1), self.S1, self.S2, True,
-                                train=True, seed=seed, step=step, noise=noise, u=u, step_dev=step_dev, march=self.march)
+                                train=True, seed=seed, step=step, noise=noise, u=u, step_dev=step_dev, march=self.march, ws=self.ws)
         gt_feat = batch.get('features') if self.feature_loss else None
         Cf = gt_feat.shape[1] if gt_feat is not None else 0
         g_image, g_depth = self._gbuf('g_image', (N, 3)), self._gbuf('g_depth', (N,))
@@ -95,7 +99,10 @@ class TrainEngine:
                H.ptr(self.counts), H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem), H.ptr(g_feat), H.ptr(self.terms), H.stream())
         if self.world > 1 and self.overlap_comm:
             self._reduced = True
-            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat, level_groups=self.level_groups(), on_grad_ready=self._bucket_ready)
+            # the scatter raises its own flag word: the MLP bucket's tail overwrites state_i[2] on the communication stream while
+            # the scatter is still running on the compute stream, so a flag stored there in between could be lost
+            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat, level_groups=self.level_groups(), on_grad_ready=self._bucket_ready,
+                          scatter_flag=self.state_i[3:4])
         else:
             self._reduced = False
             pipe.backward(ctx, g_image, g_depth, g_sem, g_feat)
@@ -123,13 +130,24 @@ class TrainEngine:
             if kind == 'mlp':   # MLP block + the overflow flag in the tail element (every rank must skip the same steps)
                 allreduce_bucket(self.P.grad, a, b, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts)
             else:
-                allreduce_bucket(self.P.grad, a, b, self.pg)
+                allreduce_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire(b - a), flag=self.state_i[3:4])
                 if a == 0:
-                    # last bucket.  The binned scatter can still raise the overflow flag (a non-finite record) AFTER the flag
-                    # travelled with the MLP bucket: one more 4-byte MAX all-reduce keeps the ranks' skip decisions identical
-                    flag = self.state_i[2:3].to(torch.float32)
+                    # last bucket: every scatter group has run (this stream waited for the compute stream's event).  The scatter's
+                    # own flag word (state_i[3]: a non-finite record) is MAX-reduced over the ranks and OR-ed into the step's flag
+                    # here, on the stream that also wrote the MLP bucket's flag -- ordered after both writers
+                    flag = self.state_i[3:4].to(torch.float32)
                     torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.pg)
-                    self.state_i[2:3] = (flag > 0).to(self.state_i.dtype)
+                    self.state_i[2:3] = torch.maximum(self.state_i[2:3], (flag > 0).to(self.state_i.dtype))
+                    self.state_i[3:4] = 0
+
+    def _wire(self, n):
+        """fp16 staging buffer of the gradient payload (one per engine, grown to the largest bucket)."""
+        if self.grad_payload != 'f16':
+            return None
+        t = self._g.get('wire')
+        if t is None or t.numel() < n:
+            t = self._g['wire'] = torch.empty(n, dtype=torch.float16, device=self.P.device)
+        return t
 
     def all_reduce_grads(self):
         """Average every gradient over the ranks.  With overlap the buckets are already in flight on the communication
@@ -140,7 +158,8 @@ class TrainEngine:
                 torch.cuda.current_stream().wait_stream(self._comm)
             else:
                 from .parallel import allreduce_gradients
-                allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts)
+                allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts, n_grid=self.L.n_grid,
+                                    payload=self.grad_payload, scratch=self._wire(self.L.n_grid))
 
     def optimizer_step(self):
         P, L, sc = self.P, self.L, self.scaler_cfg
@@ -151,9 +170,10 @@ class TrainEngine:
         P.refresh_shadows(grid=False)
 
     def maybe_update_grid(self):
-        """`if self.model.cuda_ray and self.global_step % 16 == 0: update_extra_state()` (autolabel/trainer.py:34-36)."""
+        """Density-grid refresh every `update_interval` (16) steps: upstream torch-ngp's cadence, this build's own spec (the
+        reference never runs with cuda_ray=True, autolabel/model_utils.py:72, and only carries the mark_untrained_grid hooks)."""
         if self.march and self._calls % self.pipe.occ.update_interval == 0:
-            self.pipe.update_density_grid(step=self._calls)
+            self.pipe.update_density_grid(step=self._calls, ws=self.ws)
         self._calls += 1
 
     def step(self, batch, seed, step, noise=None, u=None, step_dev=None, grid_update=True):
@@ -173,14 +193,16 @@ class TrainEngine:
         def body(step_dev):
             frames.next_train(batch, seed=data_seed, step=first_step, frame_range=frame_range, step_dev=step_dev)
             self.step(batch, seed=seed, step=first_step, step_dev=step_dev, grid_update=False)
+        guard = lambda: (self.ws.generation, batch['rays_o'].data_ptr())
         if not self.march:
-            return GraphedStep(body, self.P.device, warmup=warmup)
-        # marching: every update_interval-th step starts with the density-grid refresh (autolabel/trainer.py:34-36); that
+            return GraphedStep(body, self.P.device, warmup=warmup, guard=guard)
+        # marching: every update_interval-th step starts with the density-grid refresh (see maybe_update_grid); that
         # variant of the step is a second captured graph, so the loop never issues a launch of its own between replays
         def body_with_refresh(step_dev):
-            self.pipe.update_density_grid(step=first_step, step_dev=step_dev)
+            self.pipe.update_density_grid(step=first_step, step_dev=step_dev, ws=self.ws)
             body(step_dev)
-        return GraphedStep(body, self.P.device, warmup=warmup, alt_body=body_with_refresh, alt_every=self.pipe.occ.update_interval)
+        return GraphedStep(body, self.P.device, warmup=warmup, alt_body=body_with_refresh, alt_every=self.pipe.occ.update_interval,
+                           guard=guard)
 
     # checkpoint payload mirrors torch's {'optimizer', 'scaler'} entries (autolabel/backend.py:157-164)
     def state_dict(self):
@@ -192,6 +214,10 @@ class TrainEngine:
         self.state_f[1:2].copy_(torch.tensor([self._lr], dtype=torch.float32))
 
 
+class GraphUnsafe(RuntimeError):
+    """hipGraph replay cannot be trusted in this process (see autolabel_amd.graph_replay_is_safe)."""
+
+
 class GraphedStep:
     """A fixed launch sequence captured into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm).
 
@@ -201,10 +227,15 @@ class GraphedStep:
     second graph) that replaces it on every ``alt_every``-th step, counted from step 0.  Re-capture (``GraphedStep(...)`` again)
     after anything baked into the launches changes: batch size, loss weights, level groups."""
 
-    def __init__(self, body, device, warmup=3, alt_body=None, alt_every=0):
+    def __init__(self, body, device, warmup=3, alt_body=None, alt_every=0, guard=None):
+        import autolabel_amd
+        ok, why = autolabel_amd.graph_replay_is_safe()
+        if not ok:
+            raise GraphUnsafe(why)
         self.counter = torch.zeros(1, dtype=torch.int32, device=device)
         self.body, self.alt_body, self.alt_every = body, alt_body, int(alt_every)
         self.steps = 0
+        self._guard = guard
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -221,6 +252,12 @@ class GraphedStep:
             self.alt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.alt_graph, stream=side):
                 self._once(True)
+        self._captured = guard() if guard is not None else None
+
+    def valid(self):
+        """False once a buffer the captured launches point into has been reallocated (Workspace.generation moved): replaying
+        would write through stale pointers.  The owner re-captures (SimpleTrainer) or stops."""
+        return self._guard is None or self._guard() == self._captured
 
     def _is_alt(self):
         return self.alt_body is not None and self.steps % self.alt_every == 0
@@ -230,5 +267,8 @@ class GraphedStep:
         self.counter.add_(1)
 
     def __call__(self):
+        if not self.valid():
+            raise RuntimeError('GraphedStep: a workspace buffer of the captured step was reallocated after the capture (a step of another '
+                               'batch size ran through the same engine?); capture again')
         (self.alt_graph if self._is_alt() else self.graph).replay()
         self.steps += 1

@@ -10,8 +10,6 @@ import torch
 
 from .build import LIB
 
-LIB = os.environ.get('ALN_HIP_LIB') or LIB   # (dev builds of scripts/dev/ only; the product library is the in-tree one)
-
 ALN_MAX_LEVELS = 16
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
@@ -59,9 +57,6 @@ _SIGS = {
     'aln_encode_fwd_ws_bytes': (i64, [vp, i32]),
     'aln_encode_fwd_phased': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'aln_encode_fwd_cells': (i32, [vp, vp, i32, u32, u32, vp, i32, i32, vp, vp, vp]),
-    'aln_dev_encode_fwd_levels': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, vp]),
-    'aln_encode_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
-    'aln_encode_bwd_levels': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp]),
     'aln_encode_bwd_binned_ws_bytes': (i64, [vp, i32]),
     'aln_encode_bwd_binned_tile_rows': (i32, []),
     'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp]),
@@ -78,26 +73,27 @@ _SIGS = {
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     'aln_sem_heads_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 4 + [i32] + [vp] * 2),
-    'aln_sem_heads_bwd_fused_ok': (i32, [vp, vp, i32]),
-    'aln_sem_heads_bwd_fused': (i32, [vp] * 6 + [i32] * 7 + [vp] * 5),
     'aln_sigma_act': (i32, [vp, i32, vp, vp]),
-    'aln_compact_live': (i32, [vp, i32, f32, vp, vp, vp, vp]),
+    'aln_compact_live_ws_ints': (i32, [i32]),
+    'aln_compact_live': (i32, [vp, i32, f32, vp, vp, vp, vp, vp]),
     'aln_color_fwd': (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
     'aln_build_color_in': (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp]),
     'aln_build_sem_in': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'aln_assemble_grads': (i32, [vp, vp, i32, vp, i32, i32, vp, i32, vp, i32, i32, vp, vp, vp]),
-    'aln_relu_bwd': (i32, [vp, vp, i64, vp, vp]),
     'aln_assemble_dsemf_out': (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     'aln_composite_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'aln_march_rays': (i32, [vp, vp, i32, i32, f32, f32, vp, i32, i32, i32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'aln_grid_points': (i32, [i32, f32, u32, u32, vp, vp, vp, vp]),
     'aln_grid_update': (i32, [vp, vp, i32, f32, f32, f32, vp, vp, vp, vp]),
+    'aln_bitfield_count': (i32, [vp, i64, vp, vp]),
     'aln_mark_untrained_grid': (i32, [vp, i32, f32, vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 6),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),
     'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, vp, vp]),
     'aln_cast_f16': (i32, [vp, vp, i64, vp]),
+    'aln_grad_pack_f16': (i32, [vp, i64, f32, vp, vp]),
+    'aln_grad_unpack_f16': (i32, [vp, i64, vp, vp, vp]),
     'aln_lzf_decompress': (i64, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
 }
 

@@ -160,7 +160,7 @@ class ALNetwork(NeRFRenderer):
                 self._pipe.occ = OccupancyGrid(p0.device, G=self.grid_size, max_steps=self.max_steps, samples=self.march_samples,
                                                density_thresh=float(self.density_thresh), grid=self.density_grid,
                                                bits=self.density_bitfield)
-                self._pipe.refresh_bitfield()    # (a loaded checkpoint carries the grid; the bit count is recomputed)
+                self._pipe.recount_bitfield()    # a loaded checkpoint carries grid AND bitfield: the bits are kept as stored
             self._shadow_version = None
         ver = tuple(p._version for _, p in self._param_blocks())
         if ver != self._shadow_version:
@@ -229,7 +229,7 @@ class ALNetwork(NeRFRenderer):
         so = torch.zeros(n, 16, dtype=f16, device=dev)
         so[:, 1:1 + L.G] = geo_features.to(f16)
         fs, os_ = L.nets['semf'], L.nets['semo']
-        if L.sem_wide and not L.sem_lib:     # LSeg-width heads: wide.hip GEMMs, inputs built inside the kernels
+        if L.sem_wide:     # LSeg-width heads: wide.hip GEMMs, inputs built inside the kernels
             logits, feat, _ = pipe.wide_sem_fwd(so, n, lambda name, shp: torch.empty(shp, dtype=f16, device=dev))
             return logits[:, :L.C], feat[:, :L.D]
         fin = torch.empty(n, fs.in_pad, dtype=f16, device=dev)
@@ -237,15 +237,9 @@ class ALNetwork(NeRFRenderer):
         oin = torch.empty(n, os_.in_pad, dtype=f16, device=dev)
         logits = torch.empty(n, os_.out_pad, dtype=f16, device=dev)
         H.call('aln_build_sem_in', H.ptr(so), None, n, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
-        if fs.lib:
-            feat, _ = pipe._lib_fwd('semf', fin, False)
-        else:
-            H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semf']), H.ptr(fin), n, None, None, None, H.ptr(feat), H.stream())
+        H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semf']), H.ptr(fin), n, None, None, None, H.ptr(feat), H.stream())
         H.call('aln_build_sem_in', H.ptr(so), H.ptr(feat), n, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
-        if os_.lib:
-            logits, _ = pipe._lib_fwd('semo', oin, False)
-        else:
-            H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semo']), H.ptr(oin), n, None, None, None, H.ptr(logits), H.stream())
+        H.call('aln_mlp_fwd', C.byref(pipe.P.descs['semo']), H.ptr(oin), n, None, None, None, H.ptr(logits), H.stream())
         return logits[:, :L.C], feat[:, :L.D]
 
     @torch.no_grad()

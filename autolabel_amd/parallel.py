@@ -1,6 +1,6 @@
 """Data parallelism over the 8 GPUs of one node: one process per GPU, frames sharded across ranks, model replicated,
-ONE collective per step -- the all-reduce of the flat gradient buffer (hash grid 14.2 M + MLPs ~0.06 M fp32 = 57 MB) over
-RCCL/xGMI.  The reference has no multi-GPU path; this is the single data-parallel axis of 8(e).
+ONE exchange per step -- the all-reduce of the flat gradient buffer (hash grid 14.2 M + MLPs ~0.06 M parameters) over RCCL/xGMI;
+the hash-grid block crosses the wire as fp16 (28.5 MB per rank and step instead of 57 MB).  The reference has no multi-GPU path; this is the single data-parallel axis of 8(e).
 
 The GradScaler overflow flag rides in the tail of the same buffer so every rank skips the same steps.
 """
@@ -51,25 +51,58 @@ def _unpack_tail(grad, tail, found_inf, counts):
     grad[tail:tail + 2] = 0
 
 
-def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None):
-    """Average `grad[:n_total]` over the group in place with a single collective; `found_inf` (int32[1]) becomes the
-    logical OR over ranks, and so does "some rank had labelled rays" (`counts[1] > 0`, which decides whether the semantic
-    heads take an optimizer step).  `grad` must have at least two spare elements at index n_total."""
+def _avg_inplace(view, group, world):
+    if dist.get_backend(group) == 'nccl':
+        dist.all_reduce(view, op=dist.ReduceOp.AVG, group=group)
+    else:  # gloo has no AVG
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        view.mul_(1.0 / world)
+
+
+def _avg_f16(grad, a, b, scratch, found_inf, group, world):
+    """grad[a:b] averaged over the ranks with fp16 on the wire: pack (x 1/world) -> SUM all-reduce of the halves -> unpack.
+    A non-finite element after the reduction (the same on every rank) raises `found_inf`: the step is skipped like any other
+    fp16 overflow.  Device tensors only: the two conversions are HIP kernels (csrc/adam.hip)."""
+    from . import hip as H
+    if not grad.is_cuda:
+        raise RuntimeError("payload='f16' needs device tensors (the conversions are HIP kernels); use payload='f32' on the CPU")
+    n = b - a
+    assert scratch is not None and scratch.dtype == torch.float16 and scratch.numel() >= n, 'fp16 staging buffer too small'
+    assert a % 4 == 0, 'bucket start must keep the fp32 side 16-byte aligned'
+    wire = scratch[:n]
+    H.call('aln_grad_pack_f16', H.ptr(grad[a:b]), n, 1.0 / world, H.ptr(wire), H.stream())
+    dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group)
+    H.call('aln_grad_unpack_f16', H.ptr(wire), n, H.ptr(grad[a:b]), H.ptr(found_inf) if found_inf is not None else None, H.stream())
+
+
+def wire_bytes(n_grid, n_total, payload='f16'):
+    """Bytes one rank contributes to the gradient exchange of a step (before the ring's 2 (P - 1) / P factor)."""
+    return n_grid * (2 if payload == 'f16' else 4) + (n_total - n_grid + 2) * 4
+
+
+def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None, n_grid=0, payload='f32', scratch=None):
+    """Average `grad[:n_total]` over the group in place; `found_inf` (int32[1]) becomes the logical OR over ranks, and so does
+    "some rank had labelled rays" (`counts[1] > 0`, which decides whether the semantic heads take an optimizer step).  `grad`
+    must have at least two spare elements at index n_total.  payload='f32': ONE collective over the flat buffer.
+    payload='f16': the hash-grid block grad[:n_grid] crosses the wire as fp16 (28.5 MB instead of 57 MB at the default model),
+    the small MLP block + flags stay fp32 (two collectives)."""
     world = dist.get_world_size(group)
     if world == 1:
         return
     _pack_tail(grad, n_total, found_inf, counts)
-    if dist.get_backend(group) == 'nccl':
-        dist.all_reduce(grad, op=dist.ReduceOp.AVG, group=group)
-    else:  # gloo has no AVG
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
-        grad.mul_(1.0 / world)
+    if payload == 'f16' and n_grid > 0:
+        _avg_inplace(grad[n_grid:n_total + 2], group, world)
+        _unpack_tail(grad, n_total, found_inf, counts)
+        _avg_f16(grad, 0, n_grid, scratch, found_inf, group, world)
+        return
+    _avg_inplace(grad[:n_total + 2], group, world)
     _unpack_tail(grad, n_total, found_inf, counts)
 
 
-def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=None):
+def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=None, payload='f32', scratch=None, flag=None):
     """Average `grad[a:b]` over the group in place (one collective on the current stream).  With `found_inf` the bucket
-    must end at `tail` (= n_total): the flags travel in `grad[tail:tail + 2]` and come back as the OR over ranks."""
+    must end at `tail` (= n_total): the flags travel in `grad[tail:tail + 2]` and come back as the OR over ranks.
+    payload='f16' (hash-grid buckets): fp16 on the wire through `scratch`; `flag` (int32[1]) is raised on a non-finite result."""
     world = dist.get_world_size(group)
     if world == 1:
         return
@@ -77,12 +110,10 @@ def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=N
         assert b == tail, 'the overflow flag rides right behind the bucket'
         _pack_tail(grad, tail, found_inf, counts)
         b = tail + 2
-    view = grad[a:b]
-    if dist.get_backend(group) == 'nccl':
-        dist.all_reduce(view, op=dist.ReduceOp.AVG, group=group)
-    else:  # gloo has no AVG
-        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
-        view.mul_(1.0 / world)
+    elif payload == 'f16':
+        _avg_f16(grad, a, b, scratch, flag, group, world)
+        return
+    _avg_inplace(grad[a:b], group, world)
     if found_inf is not None:
         _unpack_tail(grad, tail, found_inf, counts)
 

@@ -10,7 +10,6 @@ table (what the gather kernel reads) and fp16 MFMA-fragment copies of the MLP we
 """
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -38,7 +37,6 @@ class MlpSpec:
         # 16->512->512->512, semo 528->64->C; or hundreds of classes -- run layer by layer on the hand-written MFMA GEMMs of
         # wide.hip (weights streamed from L2, inputs / ReLU / masks / accumulation fused into prologue and epilogue).
         self.wide = hidden not in (64, 128) or self.in_pad > 96 or self.out_pad > 64
-        self.lib = False   # (round 1 sent these heads to hipBLASLt through torch.mm; ALN_WIDE=lib keeps that path for A/B timing)
 
 
 class ModelLayout:
@@ -64,9 +62,6 @@ class ModelLayout:
         self.n_total = o
         self.Cpad = self.nets['semo'].out_pad
         self.sem_wide = self.nets['semf'].wide or self.nets['semo'].wide    # then BOTH semantic heads take the wide path
-        self.sem_lib = self.sem_wide and os.environ.get('ALN_WIDE') == 'lib'
-        if self.sem_lib:
-            self.nets['semf'].lib = self.nets['semo'].lib = True
 
 
 class Params:
@@ -78,10 +73,10 @@ class Params:
         self.flat = torch.zeros(L.n_total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(L.n_total + 8, dtype=torch.float32, device=device)  # +8: side channel for DP (found_inf)
         self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
-        self.frags, self.descs, self.lib_w, self.wide_wt = {}, {}, {}, {}
+        self.frags, self.descs, self.wide_w, self.wide_wt = {}, {}, {}, {}
         for k, s in L.nets.items():
-            if s.lib or (L.sem_wide and k in ('semf', 'semo')):   # row-major fp16 [out, in] per layer (+ transposes for the data gradients)
-                self.lib_w[k] = [torch.zeros(o, i, dtype=torch.float16, device=device) for o, i in s.shapes]
+            if L.sem_wide and k in ('semf', 'semo'):   # row-major fp16 [out, in] per layer (+ transposes for the data gradients)
+                self.wide_w[k] = [torch.zeros(o, i, dtype=torch.float16, device=device) for o, i in s.shapes]
                 self.wide_wt[k] = [torch.zeros(i, o, dtype=torch.float16, device=device) for o, i in s.shapes]
                 continue
             nf = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 0)
@@ -127,9 +122,9 @@ class Params:
             H.call('aln_cast_f16', H.ptr(self.flat), H.ptr(self.table16), L.n_grid, H.stream())
         fused = []
         for k, s in L.nets.items():
-            if k in self.lib_w:
+            if k in self.wide_w:
                 o = L.offsets[k]
-                for w, wt in zip(self.lib_w[k], self.wide_wt[k]):
+                for w, wt in zip(self.wide_w[k], self.wide_wt[k]):
                     w.copy_(self.flat[o:o + w.numel()].view_as(w))
                     H.call('aln_transpose_f16', H.ptr(w), w.shape[0], w.shape[1], H.ptr(wt), H.stream())
                     o += w.numel()
@@ -143,16 +138,22 @@ class Params:
 
 
 class Workspace:
-    """Lazily allocated, shape-keyed device buffers (the caller owns all memory the kernels touch)."""
+    """Lazily allocated, shape-keyed device buffers (the caller owns all memory the kernels touch).
+
+    ``generation`` counts (re)allocations: a captured hipGraph bakes in the raw pointers of the buffers it touched, so whoever
+    replays one compares the generation it captured under with the current one (engine.GraphedStep).  The training engine owns
+    a Workspace of its own (TrainEngine.ws): renders through the same pipeline use ``HipPipeline.ws`` and can never move the
+    buffers a captured training step points into."""
 
     def __init__(self, device):
-        self.device, self.bufs = device, {}
+        self.device, self.bufs, self.generation = device, {}, 0
 
     def get(self, name, shape, dtype):
         key = (name, tuple(shape), dtype)
         t = self.bufs.get(name)
         if t is None or t[0] != key:
             self.bufs[name] = (key, torch.empty(shape, dtype=dtype, device=self.device))
+            self.generation += 1
         return self.bufs[name][1]
 
     def scratch(self, name, nbytes):
@@ -160,6 +161,7 @@ class Workspace:
         t = self.bufs.get(name)
         if t is None or t[1].numel() < nbytes:
             self.bufs[name] = (('scratch', name), torch.empty(int(nbytes), dtype=torch.uint8, device=self.device))
+            self.generation += 1
         return self.bufs[name][1]
 
 
@@ -171,7 +173,7 @@ class OccupancyGrid:
     One level, G^3 cells over [-bound, bound]^3; `grid` / `bits` may be the model's registered buffers (they travel with
     state_dict like upstream's density_grid / density_bitfield)."""
 
-    def __init__(self, device, G=128, max_steps=1024, samples=96, density_thresh=0.01, decay=0.95, update_interval=16,
+    def __init__(self, device, G=128, max_steps=1024, samples=96, density_thresh=10.0, decay=0.95, update_interval=16,
                  grid=None, bits=None):
         self.G, self.max_steps, self.samples = int(G), int(max_steps), int(samples)
         self.density_thresh, self.decay, self.update_interval = float(density_thresh), float(decay), int(update_interval)
@@ -179,7 +181,7 @@ class OccupancyGrid:
         self.grid = grid if grid is not None else torch.zeros(n, dtype=f32_, device=device)
         self.bits = bits if bits is not None else torch.zeros((n + 31) // 32, dtype=i32_, device=device)
         assert self.grid.numel() == n and self.bits.numel() == (n + 31) // 32
-        self.stats = torch.zeros(2, dtype=f32_, device=device)
+        self.stats = torch.zeros(2, dtype=torch.int64, device=device)   # fixed-point sum and count of the grid mean (aln_grid_update)
         self.n_set = torch.zeros(1, dtype=i32_, device=device)
         self.updates = 0
 
@@ -200,10 +202,8 @@ class HipPipeline:
         self.phased_min_rows = 1 << 16   # hash-grid forward: level-phased from this many sample rows on
         # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
-        self.recompute = all(k in params.lib_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
+        self.recompute = all(k in params.wide_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
                              for k, s in layout.nets.items())
-        # hash-grid backward: binned two-pass scatter by default; ALN_ENC_BWD=atomic selects the fp32-atomic kernel
-        self.binned_bwd = os.environ.get('ALN_ENC_BWD', 'binned') != 'atomic'
         self.occ = None     # OccupancyGrid: forward(..., march=True) then places the samples by marching (enable_marching)
         self.kernel_events = None  # bench.py: list of ((start, end) HIP events, kernel, tag) around the timed launches
 
@@ -222,15 +222,17 @@ class HipPipeline:
         self.occ = OccupancyGrid(self.P.device, **kw)
         return self.occ
 
-    def update_density_grid(self, step=0, seed=0x5EED, chunk=1 << 19, step_dev=None):
-        """NeRFRenderer.update_extra_state of the fork (autolabel/trainer.py:34-36: every 16 steps): density of one jittered point
-        per cell, grid = max(grid * decay, sigma * density_scale), bit = grid > min(mean, density_thresh)."""
+    def update_density_grid(self, step=0, seed=0x5EED, chunk=1 << 19, step_dev=None, ws=None):
+        """NeRFRenderer.update_extra_state of upstream torch-ngp (the reference only carries the hooks: autolabel/trainer.py:21-23,
+        34-36,176 call mark_untrained_grid; the refresh cadence -- every 16 steps -- is upstream's and this build's own spec):
+        density of one jittered point per cell, grid = max(grid * decay, sigma * density_scale), bit = grid > min(mean, density_thresh)."""
         occ, e = self.occ, self.L.enc
+        ws = self.ws if ws is None else ws
         n = occ.G ** 3
-        sig = self.ws.get('occ_sigma', (n,), f32_)
-        enc = self.ws.get('occ_enc', (chunk, e.enc_pad), f16)
-        out = self.ws.get('occ_out', (chunk, 16), f16)
-        planes = self.ws.scratch('enc_planes', int(e.grid.n_levels) * chunk * 4) if e.use_grid else None
+        sig = ws.get('occ_sigma', (n,), f32_)
+        enc = ws.get('occ_enc', (chunk, e.enc_pad), f16)
+        out = ws.get('occ_out', (chunk, 16), f16)
+        planes = ws.scratch('enc_planes', int(e.grid.n_levels) * chunk * 4) if e.use_grid else None
         for a in range(0, n, chunk):
             rows = min(chunk, n - a)
             # the cell points (aln_grid_points' positions) are generated inside the encoding kernels: no [G^3, 3] buffer
@@ -243,10 +245,15 @@ class HipPipeline:
         occ.updates += 1
 
     def refresh_bitfield(self):
-        """Bitfield from the grid as it is (after mark_untrained_grid / a checkpoint load)."""
+        """Bitfield from the grid as it is (after mark_untrained_grid)."""
         occ = self.occ
         H.call('aln_grid_update', H.ptr(occ.grid), None, occ.G, occ.decay, self.density_scale, occ.density_thresh,
                H.ptr(occ.stats), H.ptr(occ.bits), H.ptr(occ.n_set), H.stream())
+
+    def recount_bitfield(self):
+        """n_set from the bitfield as it is (a loaded checkpoint carries grid AND bitfield: the bits are kept, not re-derived)."""
+        occ = self.occ
+        H.call('aln_bitfield_count', H.ptr(occ.bits), occ.bits.numel(), H.ptr(occ.n_set), H.stream())
 
     def mark_untrained_grid(self, T_CW, intrinsics, size=None, z_near=0.0, sub=2):
         """Cells no camera sees get -1 (never occupied).  T_CW: [F,4,4] world -> OpenCV camera in the renderer's frame."""
@@ -259,11 +266,11 @@ class HipPipeline:
         torch.cuda.current_stream().synchronize()   # T is a temporary
         self.refresh_bitfield()
 
-    def binned_record_count(self, M):
+    def binned_record_count(self, M, ws=None):
         """Records the last binned hash-grid backward over M sample rows streamed through HBM (sum of the per-(level, slice,
         tile) descriptor counts; 8 bytes each, written once by phase 1 and read once by phase 2).  Host sync: reporting only."""
-        t = self.ws.bufs.get('enc_bwd_bins')
-        if t is None or not self.binned_bwd:
+        t = (self.ws if ws is None else ws).bufs.get('enc_bwd_bins')
+        if t is None:
             return None
         tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
         nl, nt = int(self.L.enc.grid.n_levels), (M + tile - 1) // tile
@@ -287,7 +294,7 @@ class HipPipeline:
         bufs: callable name, shape -> fp16 buffer.  Returns (logits [M, Cpad], f [M, D], saved activations)."""
         L = self.L
         fs, os_ = L.nets['semf'], L.nets['semo']
-        Wf, Wo = self.P.lib_w['semf'], self.P.lib_w['semo']
+        Wf, Wo = self.P.wide_w['semf'], self.P.wide_w['semo']
         fl = ('sem', M)
         h1, h2 = bufs('wide_h1', (M, fs.hidden)), bufs('wide_h2', (M, fs.hidden))
         feat, ho = bufs('feat', (M, fs.out_pad)), bufs('wide_ho', (M, os_.hidden))
@@ -329,54 +336,13 @@ class HipPipeline:
         self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=sout, tag=bl)
         return d_fin, d_ogeo
 
-    # ---- library-GEMM heads (MlpSpec.lib): y = relu(x W0^T) ... ; fp16 operands, fp32 accumulate (hipBLASLt)
-    def _lib_fwd(self, k, x, save):
-        ws, h, hs = self.P.lib_w[k], x, []
-        for i, w in enumerate(ws):
-            h = h @ w.t()
-            if i + 1 < len(ws):
-                h = torch.relu_(h)
-                if save:
-                    hs.append(h)
-        return h, hs
-
-    def _lib_dw(self, g, a):
-        """dW = g^T a with fp32 accumulation, [rows, out] x [rows, in] -> [out, in].  The contraction runs over ~10^6 rows:
-        as one GEMM hipBLASLt gets a 512 x 512 output (4 tiles for 256 CUs); batched over row slabs it fills the chip, and
-        the fp32 slab results are summed afterwards (split-K by hand)."""
-        rows = g.shape[0]
-        slabs = 1
-        while slabs < 64 and rows % (slabs * 2) == 0 and rows // (slabs * 2) >= 4096:
-            slabs *= 2
-        if slabs == 1:
-            return torch.mm(g.t(), a, out_dtype=torch.float32)
-        gb = g.view(slabs, rows // slabs, g.shape[1]).transpose(1, 2)
-        return torch.bmm(gb, a.view(slabs, rows // slabs, a.shape[1]), out_dtype=torch.float32).sum(dim=0)
-
-    def _lib_bwd(self, k, x, hs, d_out):
-        """Accumulates dW into the flat gradient buffer (fp32 GEMM output) and returns dL/dx [rows, in_pad] fp16."""
-        ws, L = self.P.lib_w[k], self.L
-        acts, g = [x] + hs, d_out
-        offs, o = [], L.offsets[k]
-        for w in ws:
-            offs.append(o)
-            o += w.numel()
-        fi = H.ptr(self.found_inf)
-        for i in reversed(range(len(ws))):
-            dW = self._lib_dw(g, acts[i])
-            self.P.grad[offs[i]:offs[i] + ws[i].numel()].add_(dW.view(-1))
-            g = g @ ws[i]
-            if i > 0:   # ReLU backward + overflow watch in one pass
-                H.call('aln_relu_bwd', H.ptr(g), H.ptr(acts[i]), g.numel(), fi, H.stream())
-        self.found_inf.bitwise_or_((~torch.isfinite(g).all()).to(torch.int32))   # the input gradient is an endpoint too
-        return g
-
     # ---- point queries (models.py:175-188, 190-220, 248-256)
-    def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train):
+    def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train, ws=None):
         e, s = self.L.enc, self.L.nets['sigma']
+        ws = self.ws if ws is None else ws
         if e.use_grid and rows >= self.phased_min_rows:
             # large batches: level-phased gathers (tables in flight stay L2-resident) + streaming row assembly
-            planes = self.ws.scratch('enc_planes', int(e.grid.n_levels) * rows * 4)
+            planes = ws.scratch('enc_planes', int(e.grid.n_levels) * rows * 4)
             self._k('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz),
                     rows, stride, H.ptr(planes), H.ptr(enc), H.stream(), tag=('enc_fwd', rows))
         else:
@@ -388,8 +354,9 @@ class HipPipeline:
         H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sigma), H.stream())
 
     def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
-                want_semantic=True, bg=1.0, step_dev=None, march=False):
-        L, P, ws = self.L, self.P, self.ws
+                want_semantic=True, bg=1.0, step_dev=None, march=False, ws=None):
+        L, P = self.L, self.P
+        ws = self.ws if ws is None else ws     # (the training engine passes its own: see Workspace)
         N = rays_o.shape[0]
         if march:   # S1 rows per ray placed inside occupied cells, no importance pass (noise: [N] per-ray jitter)
             assert self.occ is not None, 'forward(march=True) needs enable_marching()'
@@ -399,9 +366,9 @@ class HipPipeline:
         e, nets = L.enc, L.nets
         dev = rays_o.device
         g = lambda n, shp, dt: ws.get(n, shp, dt)
-        self._serial = getattr(self, '_serial', 0) + 1   # every forward rewrites the shared, name-keyed workspaces
+        ws.serial = getattr(ws, 'serial', 0) + 1   # every forward rewrites the name-keyed buffers of its workspace
         c = dict(N=N, S1=S1, S2=S2, M=M, train=train, want_semantic=want_semantic, bg=float(bg),
-                 rays_o=rays_o, rays_d=rays_d, norms=norms, serial=self._serial)
+                 rays_o=rays_o, rays_d=rays_d, norms=norms, serial=ws.serial, ws=ws)
         save = train and not self.recompute
         c['nears'], c['fars'] = g('nears', (N,), f32_), g('fars', (N,), f32_)
         z = c['z'] = g('z', (M,), f32_)
@@ -421,13 +388,13 @@ class HipPipeline:
         else:
             H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
                    H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.ptr(step_dev), H.stream())
-        self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train)
+        self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train, ws=ws)
         if S2 > 0:
             zf = z[M1:]
             H.call('aln_sample_fine', H.ptr(z), H.ptr(sigma), H.ptr(c['nears']), H.ptr(c['fars']), N, S1, S2,
                    self.density_scale, int(perturb), seed, step, H.ptr(u), H.ptr(zf), H.ptr(step_dev), H.stream())
             self.density_rows(N * S2, rays_o, rays_d, zf, None, S2, enc[M1:], h1[M1:] if save else h1,
-                              h2[M1:] if save else h2, sout[M1:], sigma[M1:], train)
+                              h2[M1:] if save else h2, sout[M1:], sigma[M1:], train, ws=ws)
         perm = c['perm'] = g('perm', (N, S), torch.int16)
         w_row, T_row, d_row = g('w_row', (M,), f32_), g('T_row', (M,), f32_), g('delta_row', (M,), f32_)
         c.update(w_row=w_row, T_row=T_row, delta_row=d_row)
@@ -441,7 +408,8 @@ class HipPipeline:
         # color head on live samples only (models.py:195-203)
         n_live, live_idx, cidx = g('n_live', (1,), i32_), g('live_idx', (M,), i32_), g('cidx_row', (M,), i32_)
         c.update(n_live=n_live, live_idx=live_idx, cidx_row=cidx)
-        H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.stream())
+        chunk_ws = g('compact_ws', (max(int(H.lib().aln_compact_live_ws_ints(M)), 1),), i32_)
+        H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(chunk_ws), H.stream())
         cs = nets['color']
         cin = c['color_in'] = g('color_in', (M, cs.in_pad), f16)
         ch1 = c['ch1'] = g('ch1', (M if save else 1, cs.hidden), f16)
@@ -459,7 +427,7 @@ class HipPipeline:
         if want_semantic:
             fs, os_ = nets['semf'], nets['semo']
             c['sem_fused'] = self.recompute and not L.sem_wide
-            c['sem_wide'] = L.sem_wide and not L.sem_lib
+            c['sem_wide'] = L.sem_wide
             if c['sem_wide']:
                 logits, feat, c['wide_saved'] = self.wide_sem_fwd(sout, M, lambda n, shp: g(n, shp, f16))
                 c['feat'], c['logits'] = feat, logits
@@ -472,24 +440,16 @@ class HipPipeline:
                 fin = c['semf_in'] = g('semf_in', (M, fs.in_pad), f16)
                 oin = c['semo_in'] = g('semo_in', (M, os_.in_pad), f16)
                 H.call('aln_build_sem_in', H.ptr(sout), None, M, L.D, L.G, fs.in_pad, os_.in_pad, H.ptr(fin), None, H.stream())
-                if fs.lib:
-                    feat, c['fhs'] = self._lib_fwd('semf', fin, train)
-                    c['feat'] = feat
-                else:
-                    fh1 = c['fh1'] = g('fh1', (M if save else 1, fs.hidden), f16)
-                    fh2 = c['fh2'] = g('fh2', (M if save else 1, fs.hidden), f16)
-                    feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
-                    H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if save else None,
-                           H.ptr(fh2) if save else None, H.ptr(feat), H.stream())
+                fh1 = c['fh1'] = g('fh1', (M if save else 1, fs.hidden), f16)
+                fh2 = c['fh2'] = g('fh2', (M if save else 1, fs.hidden), f16)
+                feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
+                H.call('aln_mlp_fwd', C.byref(P.descs['semf']), H.ptr(fin), M, None, H.ptr(fh1) if save else None,
+                       H.ptr(fh2) if save else None, H.ptr(feat), H.stream())
                 H.call('aln_build_sem_in', H.ptr(sout), H.ptr(feat), M, L.D, L.G, fs.in_pad, os_.in_pad, None, H.ptr(oin), H.stream())
-                if os_.lib:
-                    logits, c['ohs'] = self._lib_fwd('semo', oin, train)
-                    c['logits'] = logits
-                else:
-                    oh1 = c['oh1'] = g('oh1', (M if save else 1, os_.hidden), f16)
-                    logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
-                    H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if save else None, None,
-                           H.ptr(logits), H.stream())
+                oh1 = c['oh1'] = g('oh1', (M if save else 1, os_.hidden), f16)
+                logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
+                H.call('aln_mlp_fwd', C.byref(P.descs['semo']), H.ptr(oin), M, None, H.ptr(oh1) if save else None, None,
+                       H.ptr(logits), H.stream())
             out['semantic'] = torch.empty((N, L.C), dtype=f32_, device=dev)
             out['semantic_features'] = torch.empty((N, L.D), dtype=f32_, device=dev)
         H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(logits), H.ptr(feat), H.ptr(out['weights_sum']),
@@ -497,19 +457,20 @@ class HipPipeline:
                H.ptr(out.get('semantic_features')), H.stream())
         return out, c
 
-    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None):
+    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None, scatter_flag=None):
         """Accumulate d(loss)/d(params) into P.grad from per-ray output gradients (fp32, already loss-scaled).
 
         Data-parallel callers pass ``level_groups`` = [(lo, hi), ...] and ``on_grad_ready``: the hash-grid scatter then runs
         one group of levels at a time and the callback fires as soon as a part of P.grad is final -- ``('mlp', a, b)`` for
         the MLP block (+ overflow flag) before the scatter starts, ``('grid', a, b)`` after each group (flat offsets) -- so
-        its all-reduce overlaps the remaining scatter."""
-        L, P, ws = self.L, self.P, self.ws
+        its all-reduce overlaps the remaining scatter.  ``scatter_flag`` (int32[1]): the hash-grid scatter raises this word instead
+        of ``found_inf`` (a data-parallel caller ships ``found_inf`` with the MLP bucket while the scatter is still running)."""
+        L, P, ws = self.L, self.P, c['ws']
         assert c['train'], 'backward needs a forward(train=True) context'
-        if c.get('serial') != getattr(self, '_serial', None):
-            raise RuntimeError('HipPipeline.backward: another forward() ran on this pipeline since the context was created; the '
-                               'intermediates live in shared workspaces and have been overwritten (call backward before the next '
-                               'render, e.g. one render() per loss, or render previews under a second model)')
+        if c.get('serial') != getattr(ws, 'serial', None):
+            raise RuntimeError('HipPipeline.backward: another forward() ran through the same workspace since the context was created; '
+                               'the intermediates live in its name-keyed buffers and have been overwritten (call backward before the '
+                               'next render, e.g. one render() per loss, or render previews under a second model)')
         N, S1, S2, M = c['N'], c['S1'], c['S2'], c['M']
         M1 = N * S1
         nets, e = L.nets, L.enc
@@ -538,13 +499,7 @@ class HipPipeline:
         self._k('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), hp(c['ch1']), hp(c['ch2']), H.ptr(d_cout),
                 M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream(), tag=('color', c['n_live']))
         d_fin = d_oin = None
-        if sem_fused and H.lib().aln_sem_heads_bwd_fused_ok(C.byref(P.descs['semf']), C.byref(P.descs['semo']), L.D):
-            # both heads in ONE kernel; d_fin already holds the skip-connection (semantic_out input) part of d(geo_feat)
-            d_fin = g('d_semf_in', (M, nets['semf'].in_pad), f16)
-            self._k('aln_sem_heads_bwd_fused', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']),
-                    H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_fin),
-                    gp('semf'), gp('semo'), fi, H.stream(), tag=('sem', M))
-        elif sem_fused:
+        if sem_fused:
             fs, os_ = nets['semf'], nets['semo']
             d_oin, d_fin = g('d_semo_in', (M, os_.in_pad), f16), g('d_semf_in', (M, fs.in_pad), f16)
             self._k('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),
@@ -555,19 +510,13 @@ class HipPipeline:
             d_fin, d_oin = self.wide_sem_bwd(c['sigma_out'], M, c['feat'], c['wide_saved'], d_logits, d_feat, lambda n, shp: g(n, shp, f16))
         elif sem:
             fs, os_ = nets['semf'], nets['semo']
-            if os_.lib:
-                d_oin = self._lib_bwd('semo', c['semo_in'], c['ohs'], d_logits)
-            else:
-                d_oin = g('d_semo_in', (M, os_.in_pad), f16)
-                H.call('aln_mlp_bwd', C.byref(P.descs['semo']), H.ptr(c['semo_in']), hp(c['oh1']), None, H.ptr(d_logits), M, None,
-                       H.ptr(dA1), None, H.ptr(d_oin), gp('semo'), fi, H.stream())
+            d_oin = g('d_semo_in', (M, os_.in_pad), f16)
+            H.call('aln_mlp_bwd', C.byref(P.descs['semo']), H.ptr(c['semo_in']), hp(c['oh1']), None, H.ptr(d_logits), M, None,
+                   H.ptr(dA1), None, H.ptr(d_oin), gp('semo'), fi, H.stream())
             H.call('aln_assemble_dsemf_out', H.ptr(d_feat), H.ptr(c['feat']), H.ptr(d_oin), M, L.D, os_.in_pad, fi, H.stream())
-            if fs.lib:
-                d_fin = self._lib_bwd('semf', c['semf_in'], c['fhs'], d_feat)
-            else:
-                d_fin = g('d_semf_in', (M, fs.in_pad), f16)
-                H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
-                       None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
+            d_fin = g('d_semf_in', (M, fs.in_pad), f16)
+            H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
+                   None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
         d_sout = g('d_sigma_out', (M, 16), f16)
         wide = sem and c.get('sem_wide')   # the wide path hands over the 16 geo columns of d(semo_in) only
         H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), 16 if wide else nets['semo'].in_pad,
@@ -576,35 +525,19 @@ class HipPipeline:
         self._k('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
                 H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
-        passes = [(z, M1, S1, d_enc)] + ([(z[M1:], N * S2, S2, d_enc[M1:])] if S2 > 0 else [])
         if on_grad_ready is not None:
             on_grad_ready('mlp', L.n_grid, L.n_total)
         if not e.use_grid:
             return
-        if self.binned_bwd:
-            # binned scatter (encode.hip): both passes in one launch pair per level group, no global atomics
-            nl = int(e.grid.n_levels)
-            bins = self.ws.scratch('enc_bwd_bins', H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M))
-            F = int(e.grid.n_features)
-            for lo, hi in (level_groups or [(0, nl)]):
-                self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1), H.ptr(d_enc),
-                        H.ptr(P.grad), H.ptr(bins), lo, hi, fi, H.stream(), tag=(M, hi - lo))
-                if on_grad_ready is not None and level_groups is not None:
-                    a = int(e.grid.offset[lo]) * F
-                    b = int(e.grid.offset[hi]) * F if hi < nl else L.n_grid
-                    on_grad_ready('grid', a, b)
-            return
-        if level_groups is None:
-            for (zz, rows, stride, de) in passes:
-                self._k('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de), H.ptr(P.grad),
-                        H.stream(), tag=(rows, int(e.grid.n_levels)))
-            return
+        # binned scatter (encode.hip): both passes in one launch pair per level group, no global atomics, bit-reproducible
+        nl = int(e.grid.n_levels)
+        bins = ws.scratch('enc_bwd_bins', H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M))
         F = int(e.grid.n_features)
-        for lo, hi in level_groups:
-            for (zz, rows, stride, de) in passes:
-                self._k('aln_encode_bwd_levels', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(zz), None, rows, stride, H.ptr(de),
-                        H.ptr(P.grad), lo, hi, H.stream(), tag=(rows, hi - lo))
-            if on_grad_ready is not None:
+        for lo, hi in (level_groups or [(0, nl)]):
+            self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1), H.ptr(d_enc),
+                    H.ptr(P.grad), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi, H.stream(),
+                    tag=(M, hi - lo))
+            if on_grad_ready is not None and level_groups is not None:
                 a = int(e.grid.offset[lo]) * F
-                b = int(e.grid.offset[hi]) * F if hi < int(e.grid.n_levels) else L.n_grid
+                b = int(e.grid.offset[hi]) * F if hi < nl else L.n_grid
                 on_grad_ready('grid', a, b)

@@ -72,7 +72,7 @@ class Trainer:
                  local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
                  workspace='workspace', best_mode='min', use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint='latest', use_tensorboardX=False, scheduler_update_every_step=False, fused=None,
-                 process_group=None):
+                 process_group=None, use_graph=True):
         self.name, self.opt, self.mute, self.metrics = name, opt, mute, metrics
         self.local_rank, self.world_size, self.workspace = local_rank, world_size, workspace
         self.ema_decay, self.fp16, self.best_mode = ema_decay, fp16, best_mode
@@ -83,6 +83,7 @@ class Trainer:
         self.device = device if device is not None else torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')
         self.time_stamp = time.strftime('%Y-%m-%d_%H-%M-%S')
         self.process_group = process_group
+        self.use_graph = bool(use_graph)   # device-resident loaders: replay the whole step from a hipGraph (engine.GraphedStep)
         model.to(self.device)
         self.model = model
         self.criterion = criterion if criterion is not None else torch.nn.MSELoss(reduction='none')
@@ -233,13 +234,16 @@ class SimpleTrainer(Trainer):
     def train_iterations(self, dataloader, iterations):
         """`iterations` optimisation steps, then ONE ema update and ONE scheduler step (autolabel/trainer.py:32-52)."""
         self.model.train()
+        if self.model.cuda_ray and getattr(dataloader, '_data', None) is not None:   # autolabel/trainer.py:34-36
+            self.model.mark_untrained_grid(dataloader._data.poses, dataloader._data.intrinsics)
         from .dataset import DeviceLoader
-        if self.fused and isinstance(dataloader, DeviceLoader) and self.world_size == 1 and os.environ.get('ALN_GRAPH', '1') != '0':
+        if self.fused and isinstance(dataloader, DeviceLoader) and self.world_size == 1 and self.use_graph:
             loss = self._graphed_iterations(dataloader, iterations)
-            if self.ema is not None:
-                self.ema.update()
-            self._step_scheduler(loss)
-            return
+            if loss is not None:
+                if self.ema is not None:
+                    self.ema.update()
+                self._step_scheduler(loss)
+                return
         iterator = iter(dataloader)
         bar = tqdm(range(iterations), desc='Loss: N/A', disable=self.mute or self.local_rank != 0)
         loss = None
@@ -250,7 +254,7 @@ class SimpleTrainer(Trainer):
                 if it % 100 == 99 and hasattr(bar, 'set_description'):
                     bar.set_description(f'Loss: {float(self.engine.terms[4]):.04f}')  # the only host sync, every 100 steps
             else:
-                if self.model.cuda_ray and self.global_step % 16 == 0:   # autolabel/trainer.py:34-36
+                if self.model.cuda_ray and self.global_step % 16 == 0:   # upstream torch-ngp's refresh cadence (own spec)
                     self.model.update_extra_state()
                 for opt in self.optimizers:
                     opt.zero_grad()
@@ -278,16 +282,28 @@ class SimpleTrainer(Trainer):
     def _graphed_iterations(self, loader, iterations):
         """Device-resident data (dataset.DeviceLoader): ray generation + the whole optimisation step replay from ONE hipGraph
         (engine.GraphedStep); the capture is redone when the engine or the loader changes (not for the learning rate: a device word)."""
+        from .engine import GraphUnsafe
         eng = self._engine()
-        key = (id(loader), id(eng))
-        if getattr(self, '_graph', None) is None or self._graph[0] != key:
-            g = eng.graphed(loader.frames, loader.batch, loader.seed, self.model._seed, frame_range=loader.frame_range,
-                            first_step=self.global_step, warmup=1)
+        cur = getattr(self, '_graph', None)
+        # the capture holds raw pointers into the engine's workspace and the loader's batch: it is reused only for the same loader
+        # and engine OBJECTS (references are kept, so an id cannot be recycled) and only while no buffer has been reallocated
+        if cur is None or cur[0] is not loader or cur[1] is not eng or not cur[2].valid():
+            if iterations <= 0:
+                return eng.terms[4]
+            try:
+                g = eng.graphed(loader.frames, loader.batch, loader.seed, self.model._seed, frame_range=loader.frame_range,
+                                first_step=self.global_step, warmup=1)
+            except GraphUnsafe as e:
+                if not getattr(self, '_graph_warned', False):
+                    self.log(f'[WARN] hipGraph replay disabled, stepping launch by launch: {e}')
+                    self._graph_warned = True
+                self.use_graph = False
+                return None
             self.global_step += g.steps
             loader.step += g.steps
-            self._graph = (key, g)
+            self._graph = cur = (loader, eng, g)
             iterations -= g.steps
-        g = self._graph[1]
+        g = cur[2]
         for _ in range(max(iterations, 0)):
             g()
         self.global_step += max(iterations, 0)
@@ -382,7 +398,7 @@ class InteractiveTrainer(SimpleTrainer):
         if self.fused:
             loss = self.fused_step(data)
         else:
-            if self.model.cuda_ray and self.global_step % 16 == 0:   # autolabel/trainer.py:176
+            if self.model.cuda_ray and self.global_step % 16 == 0:   # upstream torch-ngp's cadence (own spec); the hook site is autolabel/trainer.py:176
                 self.model.update_extra_state()
             self.optimizer.zero_grad()
             with torch.autocast('cuda', enabled=self.fp16):

@@ -269,7 +269,7 @@ def main():
     assert B % 512 == 0 and B > 0, 'per-rank batch must be a multiple of the 512-ray chunk (autolabel/dataset.py:171)'
     batch = train.alloc_batch(B)
     dseed, mseed = rank_seed(1234, rank), rank_seed(99, rank)
-    use_graph = not args.no_graph and (world == 1 or os.environ.get('ALN_GRAPH_DP') == '1')
+    use_graph = not args.no_graph and world == 1   # data-parallel steps are issued launch by launch (collectives on a side stream)
     done = [0]
 
     def eager_step():
@@ -317,8 +317,8 @@ def main():
             eager_step()
         sync()
         eng.pipe.kernel_events = None
-    live_rows = float(eng.pipe.ws.get('n_live', (1,), torch.int32).item())   # color-head rows of the last step (w > 1e-4)
-    records_evt = eng.pipe.binned_record_count(B * (eng.S1 + eng.S2))          # records of the last hash-grid backward (same state as the events)
+    live_rows = float(eng.ws.get('n_live', (1,), torch.int32).item())   # color-head rows of the last step (w > 1e-4)
+    records_evt = eng.pipe.binned_record_count(B * (eng.S1 + eng.S2), ws=eng.ws)          # records of the last hash-grid backward (same state as the events)
 
     # render throughput: full 640x480 frames, 512 coarse steps, no upsampling (scripts/render.py:96-102)
     render_mrays, render_roof = None, None
@@ -403,9 +403,8 @@ def main():
                     pmc = json.load(f)
             except (OSError, ValueError):
                 pass
-            binned = eng.pipe.binned_bwd
             res['roofline'] = {
-                'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair)' if binned else 'k_encode_bwd',
+                'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair)',
                 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                 'traffic': pmc.get('encode_bwd_traffic_bytes_per_launch'), 'avg_launch_us': avg_s * 1e6, 'launches': len(durs),
                 'algorithmic_bytes_per_launch': sum(per_launch) / len(per_launch),

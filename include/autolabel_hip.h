@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 3
+#define ALN_ABI_VERSION 4
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -56,8 +56,9 @@ typedef struct {
   const void* wf;   /* forward fragments  */
   const void* wb;   /* backward (transposed) fragments */
   const void* wr;   /* row-major fp16 copy, pitch in+8 (recompute backward); may be NULL */
-  void* dw_ws;      /* ABI 3: scratch for the backward's per-block weight-gradient partial sums, >= aln_mlp_dw_ws_bytes();
-                       NULL (or too small): the blocks add into dW with fp32 atomics instead (slower, order-dependent) */
+  void* dw_ws;      /* scratch for the recompute backward's per-block weight-gradient partial sums, >= aln_mlp_dw_ws_bytes();
+                       required when aln_mlp_bwd / aln_sem_heads_bwd are asked for dW on the recompute path (slabs are reduced in
+                       a fixed order: bit-reproducible weight gradients, no atomics) */
   int64_t dw_ws_bytes;
 } AlnMlpDesc;
 
@@ -139,22 +140,11 @@ int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16, const floa
  * NeRFRenderer.update_extra_state at autolabel/trainer.py:34-36.  planes_ws != NULL selects the level-phased kernels. */
 int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, int32_t G, uint32_t seed, uint32_t step,
                          const uint32_t* step_dev, int32_t cell0, int32_t rows, void* planes_ws, void* enc_out, void* stream);
-/* development probe (scripts/dev/probe_encode_fwd_levels.py): the tile kernel for levels [level_lo, level_hi) only */
-int aln_dev_encode_fwd_levels(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
-                              const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* enc_out,
-                              int32_t level_lo, int32_t level_hi, void* stream);
-int aln_encode_bwd(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
-                   int32_t rows, int32_t rays_stride, const void* d_enc /*[rows,enc_pad] f16*/,
-                   float* grad_table /*[n_entries*F] f32*/, void* stream);
-/* the same for levels [level_lo, level_hi) only: a data-parallel caller launches the levels in groups and all-reduces the
- * finished part of the gradient table while the next group is still being scattered */
-int aln_encode_bwd_levels(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
-                          int32_t rows, int32_t rays_stride, const void* d_enc, float* grad_table, int32_t level_lo,
-                          int32_t level_hi, void* stream);
-
-/* the same gradient WITHOUT global atomics (encode.hip, "binned backward"): phase 1 counting-sorts the run-deduped
- * (index, value) records of every 512-row tile by 64 KB table slice and streams them to `ws`; phase 2 accumulates each slice in
- * LDS and adds it to grad_table.  Rows [0, rows_pass1) are rays_stride1 samples per ray, the rest rays_stride2 (the coarse and
+/* backward: grad_table [n_entries * F] f32 += scatter of w_corner * d_enc, WITHOUT global atomics (encode.hip, "binned
+ * backward"): phase 1 counting-sorts the run-deduped (index, value) records of every 512-row tile by table slice (1/64 of a
+ * level) and streams them to `ws`; phase 2 accumulates each slice in LDS in 64-bit fixed point (exact, order-independent: the
+ * result is bit-reproducible) and adds it to grad_table.  [level_lo, level_hi): a data-parallel caller launches the levels in
+ * groups and all-reduces the finished part of the table while the next group is still being scattered.  Rows [0, rows_pass1) are rays_stride1 samples per ray, the rest rays_stride2 (the coarse and
  * the importance pass of autolabel/trainer.py:64-70 in one launch).  ws = aln_encode_bwd_binned_ws_bytes(e, rows) bytes of
  * caller-owned scratch.  *found_inf is set when a gradient entry is not finite (record values travel as fp16). */
 int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows);
@@ -190,23 +180,17 @@ int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void
 int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat, const float* w_row,
                       const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t rows,
                       int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf, float* dW_semo,
-                      int32_t fold_geo /* ABI 3: 1 = d_semf_in rows also take the geo_feat columns of d_semo_in, so that
+                      int32_t fold_geo /* 1 = d_semf_in rows also take the geo_feat columns of d_semo_in, so that
                                           aln_assemble_grads needs d_semf_in only (d_semo_in = NULL there) */,
                       int32_t* found_inf, void* stream);
-/* The same backward as ONE kernel (ABI 3): five-layer register chain, f recomputed, nothing but sigma_out / w_row / the per-ray
- * gradients read.  d_geo [rows, 16] fp16 = d(semantic_features input) + geo_feat columns of d(semantic_out input): pass it to
- * aln_assemble_grads as d_semf_in with d_semo_in = NULL.  aln_sem_heads_bwd_fused_ok() tells whether the shapes are covered
- * (D = 64, semantic_features 16->64->64->64, semantic_out 80->64->{16,32,48,64}). */
-int aln_sem_heads_bwd_fused_ok(const AlnMlpDesc* semf, const AlnMlpDesc* semo, int32_t D);
-int aln_sem_heads_bwd_fused(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const float* w_row,
-                            const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t rows,
-                            int32_t D, int32_t G, void* d_geo, float* dW_semf, float* dW_semo, int32_t* found_inf, void* stream);
-
 /* ---- head plumbing: autolabel/models.py:175-188 (sigma = trunc_exp(h0), geo_feat = h[1:]), :190-220 (boolean-mask
  * gather + SH(dir) ++ geo_feat), :248-256 (cat[relu(f), geo_feat]) and the matching gradient assembly */
 int aln_sigma_act(const void* sigma_out /*[rows,16] f16*/, int32_t rows, float* sigma, void* stream);
+/* live rows (w_row > thresh: the renderer's `weights > 1e-4` mask, autolabel/models.py:199-203) compacted in row order (a pure
+ * function of w_row: deterministic); chunk_ws = aln_compact_live_ws_ints(rows) int32 of caller-owned scratch */
+int32_t aln_compact_live_ws_ints(int32_t rows);
 int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx, int32_t* cidx_row,
-                     void* stream);
+                     int32_t* chunk_ws, void* stream);
 /* tcnn SphericalHarmonics(degree 4) of the remapped direction (autolabel/models.py:97-103,205-207): out[r, 0:16] f16 */
 int aln_sh4(const float* dirs /*[rows,3]*/, int32_t rows, int32_t out_pitch /*halves, >= 16*/, void* out, void* stream);
 /* color_net forward with its input rows built inside the kernel from live_idx / directions / sigma_out (inference path:
@@ -224,9 +208,6 @@ int aln_assemble_grads(const float* d_h0, const void* d_semf_in, int32_t semf_in
                        int32_t rows, int32_t G, void* d_sigma_out, int32_t* found_inf, void* stream);
 int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d_semo_in, int32_t rows, int32_t D, int32_t semo_in_pad,
                            int32_t* found_inf, void* stream);
-/* ReLU backward in place for the library-GEMM (wide) heads: g[i] = act[i] > 0 ? g[i] : 0, n halves (n % 8 == 0); found_inf
- * is OR-ed when a non-finite gradient passes */
-int aln_relu_bwd(void* g, const void* act, int64_t n, int32_t* found_inf, void* stream);
 
 /* ---- wide semantic heads (wide.hip): semantic_features / semantic_out at LSeg width (hidden_dim_semantic = 512,
  * autolabel/models.py:117-136, scripts/ros/node.py:166-176), one hand-written MFMA GEMM launch per layer.
@@ -254,9 +235,12 @@ int aln_march_rays(const float* rays_o, const float* rays_d, int32_t N, int32_t 
 int aln_grid_points(int32_t G, float bound, uint32_t seed, uint32_t step, const uint32_t* step_dev /*see aln_raygen_train*/,
                     const float* noise /*[G^3,3] or NULL*/, float* xyz, void* stream);
 /* grid = max(grid * decay, sigma * density_scale) on cells >= 0 (sigma NULL: statistics only), then
- * bit = grid > min(mean over cells >= 0, thresh); stats = 2 floats of scratch; n_set (optional) = number of set bits */
-int aln_grid_update(float* grid, const float* sigma, int32_t G, float decay, float density_scale, float thresh, float* stats,
+ * bit = grid > min(mean over cells >= 0, thresh); stats = 16 bytes of scratch (the mean is accumulated in integers: the
+ * bitfield does not depend on the order the blocks arrive in); n_set (optional) = number of set bits */
+int aln_grid_update(float* grid, const float* sigma, int32_t G, float decay, float density_scale, float thresh, void* stats,
                     uint32_t* bitfield, int32_t* n_set, void* stream);
+/* n_set = population count of a bitfield (a checkpoint's density_bitfield is kept as stored, autolabel/model_utils.py:9-18) */
+int aln_bitfield_count(const uint32_t* bitfield, int64_t n_words, int32_t* n_set, void* stream);
 /* cells no camera sees become -1; T_CW [n_poses,4,4] row-major world -> OpenCV camera, pinhole fx fy cx cy, image w x h */
 int aln_mark_untrained_grid(float* grid, int32_t G, float bound, const float* T_CW, int32_t n_poses, float fx, float fy,
                             float cx, float cy, float w, float h, float z_near, int32_t sub, void* stream);
@@ -298,6 +282,11 @@ int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f
                   const int32_t* block_kind /*host*/, int32_t feature_loss, const int32_t* counts /*device, optional*/,
                   void* stream);
 int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
+/* fp16 wire format of the data-parallel exchange of the hash-grid gradient block (the reference has no multi-GPU path; the
+ * gradient it averages is what scripts/train.py:50-63's optimizer consumes): out = fp16(grad * mul), and back grad = fp32(in)
+ * with *found_inf raised on a non-finite element.  Pointers 16-byte aligned. */
+int aln_grad_pack_f16(const float* grad, int64_t n, float mul, void* out_f16, void* stream);
+int aln_grad_unpack_f16(const void* in_f16, int64_t n, float* grad, int32_t* found_inf, void* stream);
 
 /* ---- feature-map file: autolabel/dataset.py:438-441 reads features.hdf through h5py, whose LZF filter (id 32000,
  * scripts/compute_feature_maps.py:85) wraps liblzf.  HOST pointers; returns the number of bytes produced or -1. */

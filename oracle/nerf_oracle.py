@@ -1,4 +1,6 @@
-"""Pure-PyTorch fp32 CPU restatement of the NeRF half of autolabel's hot path.
+"""Pure-PyTorch fp32 restatement of the NeRF half of autolabel's hot path (plain torch ops, CPU by default; the tensors may
+live on any torch device -- the matched-quality gate runs it on the GPU box's device through torch's own kernels, never through
+this repo's HIP library).
 
 TEST INFRASTRUCTURE -- see oracle/__init__.py.  **Parity unpinned**: the
 arithmetic restated here lives in two dependencies that are absent from
@@ -117,7 +119,7 @@ def grid_corner_indices(xn: torch.Tensor, level: dict):
     UNFUSED in fp32 (two roundings) so that floor() is reproducible bit-exactly.
     Corner c uses +1 along dim d iff bit d of c is set; accumulation order c=0..7.
     """
-    scale = torch.tensor(level['scale'], dtype=torch.float32)
+    scale = torch.tensor(level['scale'], dtype=torch.float32, device=xn.device)
     if level.get('pos_fma'):   # x * scale (48 significant bits) + 0.5 is exact in fp64: one rounding to fp32 = the fused result
         pos = (xn.double() * scale.double() + 0.5).float()
     else:
@@ -128,7 +130,7 @@ def grid_corner_indices(xn: torch.Tensor, level: dict):
     res, size = level['res'], level['size']
     idxs, ws = [], []
     for c in range(8):
-        w = torch.ones(xn.shape[0], dtype=torch.float32)
+        w = torch.ones(xn.shape[0], dtype=torch.float32, device=xn.device)
         cg = []
         for d in range(3):
             if c & (1 << d):
@@ -169,7 +171,7 @@ def hashgrid_encode(xn: torch.Tensor, table: torch.Tensor, spec: GridSpec, half_
     outs = []
     for level in spec.levels():
         idx, w = grid_corner_indices(xn, level)
-        acc = torch.zeros(xn.shape[0], spec.n_features, dtype=torch.float32)
+        acc = torch.zeros(xn.shape[0], spec.n_features, dtype=torch.float32, device=xn.device)
         for c in range(8):
             acc = acc + w[:, c:c + 1] * tab[level['offset'] + idx[:, c]]
         outs.append(acc)
@@ -243,7 +245,7 @@ def mlp_forward(x: torch.Tensor, weights: List[torch.Tensor], half_sim=False):
     """
     in_pad = weights[0].shape[1]
     if x.shape[1] < in_pad:
-        x = torch.cat([x, torch.full((x.shape[0], in_pad - x.shape[1]), PAD_VALUE, dtype=x.dtype)], 1)
+        x = torch.cat([x, torch.full((x.shape[0], in_pad - x.shape[1]), PAD_VALUE, dtype=x.dtype, device=x.device)], 1)
     h = _q(x, half_sim)
     for i, W in enumerate(weights):
         h = h @ _q(W, half_sim).t()
@@ -305,10 +307,12 @@ def init_params(cfg: ModelConfig, seed=0) -> Dict[str, torch.Tensor]:
 class OracleModel:
     """Functional restatement of ALNetwork (autolabel/models.py:62-265)."""
 
-    def __init__(self, cfg: ModelConfig, params: Optional[Dict[str, torch.Tensor]] = None, half_sim=False, seed=0):
+    def __init__(self, cfg: ModelConfig, params: Optional[Dict[str, torch.Tensor]] = None, half_sim=False, seed=0, device=None):
         self.cfg = cfg
         self.half_sim = half_sim
         self.params = params if params is not None else init_params(cfg, seed)
+        if device is not None:
+            self.params = {k: v.detach().to(device) for k, v in self.params.items()}
         for v in self.params.values():
             v.requires_grad_(True)
 
@@ -337,7 +341,7 @@ class OracleModel:
     # models.py:190-220
     def color(self, x, d, mask=None, geo_feat=None):
         if mask is not None:
-            rgbs = torch.zeros(mask.shape[0], 3, dtype=torch.float32)
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=torch.float32, device=x.device)
             if not mask.any():
                 return rgbs
             d, geo_feat = d[mask], geo_feat[mask]
@@ -372,7 +376,7 @@ class OracleModel:
         near = torch.fmax(torch.fmax(tn[:, 0], tn[:, 1]), tn[:, 2])
         far = torch.fmin(torch.fmin(tf[:, 0], tf[:, 1]), tf[:, 2])
         miss = ~(near <= far)
-        mn = torch.tensor(self.cfg.min_near, dtype=torch.float32)
+        mn = torch.tensor(self.cfg.min_near, dtype=torch.float32, device=rays_o.device)
         near = torch.where(miss, mn, torch.fmax(near, mn))
         far = torch.where(miss, mn, far)
         far = torch.fmax(far, near)
@@ -399,7 +403,7 @@ class OracleModel:
         N = rays_o.shape[0]
         near, far = self.near_far(rays_o, rays_d)
         near, far = near[:, None], far[:, None]
-        lin = torch.arange(num_steps, dtype=torch.float32) / np.float32(max(num_steps - 1, 1))
+        lin = torch.arange(num_steps, dtype=torch.float32, device=rays_o.device) / np.float32(max(num_steps - 1, 1))
         z = near + (far - near) * lin[None]
         sample_dist = (far - near) / np.float32(num_steps)
         if perturb:
@@ -421,7 +425,7 @@ class OracleModel:
                 if perturb:
                     u = u_fine
                 else:
-                    u = (torch.arange(upsample_steps, dtype=torch.float32) + 0.5) / np.float32(upsample_steps)
+                    u = (torch.arange(upsample_steps, dtype=torch.float32, device=rays_o.device) + 0.5) / np.float32(upsample_steps)
                     u = u[None].expand(N, upsample_steps)
                 new_z = sample_pdf(z_mid, w[:, 1:-1], u.contiguous())
                 if z_fine_override is not None:

@@ -192,38 +192,82 @@ def test_engine_follows_checkpoint_load_and_device_rebind(tmp_path):
     assert now.data_ptr() != 0 and model.sigma_net.params.data_ptr() == model._P.flat[model._layout.offsets['sigma']:].data_ptr()
 
 
-def test_graphed_training_loop_matches_launch_by_launch():
-    """SimpleTrainer.train_iterations over a dataset.DeviceLoader replays ONE captured hipGraph per step; same seeds and step
-    numbers as the launch-by-launch loop (ALN_GRAPH=0) => same trajectory up to the order of the fp32 atomics in the MLP
-    weight-gradient sums."""
+def _graph_vs_eager(render_between):
     from autolabel_amd import synthetic
     from autolabel_amd.dataset import DeviceFrames, DeviceLoader
     scene = synthetic.make_cube_scene(n_frames=8)
     finals = []
-    for graph in ('1', '0'):
-        os.environ['ALN_GRAPH'] = graph
-        try:
-            torch.manual_seed(0)
-            model = make_model(D=64, C_=scene['n_classes'], bound=6.0, grid_scale=1.0)
-            tr = _trainer(model, True)
-            tr.opt.feature_loss = False
-            loader = DeviceLoader(DeviceFrames.from_scene(scene, 'cuda'), 1024, 1000, seed=3)
-            tr.train_iterations(loader, 3)
-            tr.train_iterations(loader, 3)     # lr halves in between (StepLR): the graph is re-captured
-            assert tr.global_step == 6 and loader.step == 6
-            assert int(tr.engine.state_i[0].item()) == 6
-            finals.append((torch.cat([p.detach().reshape(-1).cpu() for _, p in model._param_blocks()]), tr.engine.terms.cpu().clone()))
-        finally:
-            os.environ.pop('ALN_GRAPH', None)
-    (a, ta), (b, tb) = finals
-    n_grid = model._layout.n_grid
-    # measured (scripts/dev/debug_graph.py): graph vs launch-by-launch differ exactly as two launch-by-launch runs do -- MLP
-    # weights by <= 2e-3 after 6 steps, the loss in the 5th digit; Adam (eps 1e-15) turns the sign of a near-zero grid
-    # gradient into a full +-lr step, so ~10 % of the grid entries wander by a step between ANY two runs.  A wrong step
-    # number, seed or a stale capture changes the batches: loss off in the first digit, all weights off by O(lr).
-    assert torch.isfinite(a).all() and (a[n_grid:] - b[n_grid:]).abs().max() < 6e-3
-    assert ((a[:n_grid] - b[:n_grid]).abs() > 2e-3).float().mean() < 0.25
-    assert abs(ta[4].item() - tb[4].item()) < 2e-3 * max(tb[4].item(), 1e-3)
+    for use_graph in (True, False):
+        torch.manual_seed(0)
+        model = make_model(D=64, C_=scene['n_classes'], bound=6.0, grid_scale=1.0)
+        tr = _trainer(model, True)
+        tr.use_graph = use_graph
+        tr.opt.feature_loss = False
+        frames = DeviceFrames.from_scene(scene, 'cuda')
+        loader = DeviceLoader(frames, 1024, 1000, seed=3)
+        tr.train_iterations(loader, 3)
+        if render_between:
+            # a render of another shape through the same model: with a name-keyed workspace shared between training and rendering
+            # this reallocated the buffers the captured step points into (use-after-free on replay)
+            model.eval()
+            with torch.no_grad():
+                o = torch.zeros(777, 3, device='cuda'); d = torch.nn.functional.normalize(torch.randn(777, 3, device='cuda'), dim=1)
+                out = model.render(o, d, torch.ones(777, 1, device='cuda'), staged=True, max_ray_batch=500, num_steps=96, upsample_steps=32)
+            assert torch.isfinite(out['image']).all()
+        tr.train_iterations(loader, 3)     # lr halves in between (StepLR): a device word, the capture is reused
+        assert tr.global_step == 6 and loader.step == 6
+        assert int(tr.engine.state_i[0].item()) == 6
+        finals.append((torch.cat([p.detach().reshape(-1).cpu() for _, p in model._param_blocks()]), tr.engine.terms.cpu().clone()))
+    return finals
+
+
+def test_graphed_training_loop_matches_launch_by_launch():
+    """SimpleTrainer.train_iterations over a dataset.DeviceLoader replays ONE captured hipGraph per step; same seeds and step
+    numbers as the launch-by-launch loop (use_graph=False).  Every kernel of the step is order-independent (integer-accumulated
+    scatter, slab-reduced weight gradients, row-order compaction), so the two trajectories are BIT-IDENTICAL."""
+    (a, ta), (b, tb) = _graph_vs_eager(render_between=False)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), f'{(a != b).sum().item()} of {a.numel()} parameters differ between graph replay and launch-by-launch'
+    assert abs(ta[4].item() - tb[4].item()) < 1e-5 * max(tb[4].item(), 1e-3)   # (the reported loss terms meet in fp32 atomics)
+
+
+def test_render_between_graph_replays_cannot_move_the_captured_buffers():
+    """train -> render with other shapes -> train on the graph path equals the launch-by-launch loop bit for bit: the engine's
+    step lives in its own workspace (TrainEngine.ws), renders in the pipeline's."""
+    (a, _), (b, _) = _graph_vs_eager(render_between=True)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_training_is_bit_reproducible_run_to_run():
+    """Two fresh processes' worth of state in one process: same seeds, 12 optimizer steps each through the fused engine at a batch
+    that spans many tiles; every parameter must agree bit for bit (dense path and occupancy-grid marching)."""
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    scene = synthetic.make_cube_scene(n_frames=8)
+    frames = DeviceFrames.from_scene(scene, 'cuda')
+    for march in (False, True):
+        finals = []
+        for _ in range(2):
+            layout = ModelLayout('hg+freq', 15, 128, 128, 64, scene['n_classes'], bound=6.0)
+            P = Params(layout, torch.device('cuda'))
+            P.init_(seed=0)
+            pipe = HipPipeline(layout, P)
+            if march:
+                pipe.enable_marching(G=64, max_steps=256, samples=48)
+                pipe.mark_untrained_grid(frames.world_to_camera(), (frames.desc.fx, frames.desc.fy, frames.desc.cx, frames.desc.cy),
+                                         size=(frames.w, frames.h))
+            eng = TrainEngine(pipe, num_steps=48, upsample_steps=48)
+            batch = frames.alloc_batch(2048)
+            for it in range(12):
+                frames.next_train(batch, seed=5, step=it)
+                eng.step(batch, seed=9, step=it)
+            torch.cuda.synchronize()
+            assert int(eng.state_i[0].item()) > 0
+            finals.append((P.flat.clone(), eng.m.clone(), eng.v.clone()))
+        for x, y in zip(*finals):
+            assert torch.equal(x, y), f'march={march}: {(x != y).sum().item()} of {x.numel()} values differ between two identical runs'
 
 
 def test_training_reduces_loss_on_cube_scene():

@@ -61,51 +61,9 @@ def test_grid_vertices_return_table_entries_bit_exact(H):
         assert torch.equal(got, want), f'level {lvl}: vertex lookups must be bit-exact'
 
 
-def test_encode_backward_is_the_adjoint_of_forward_at_full_size(H):
-    """<encode(T), D> == <T, encode_bwd(D)> for the grid part (the scatter is the transpose of the gather), B x S rows."""
-    bound = 3.0
-    e = H.make_enc_desc('hg+freq', bound)
-    spec = O.GridSpec()
-    N, S = B_FULL, S_FULL // 2            # one pass of the renderer: 8192 x 128 = 2^20 rows
-    rows = N * S
-    g = torch.Generator().manual_seed(1)
-    ro, rd = _rays(N, bound, 2)
-    z = (torch.rand(N, S, generator=g).sort(dim=1)[0] * 5 + 0.2).cuda().reshape(-1).contiguous()
-    table = ((torch.rand(spec.n_entries, 2, generator=g) - 0.5)).half().cuda()
-    enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
-    H.call('aln_encode_fwd', C.byref(e), H.ptr(table), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(enc), H.stream())
-    d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
-    d_enc[:, 12:44] = (torch.randn(rows, 32, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * 0.05).half()
-    grad = torch.zeros(spec.n_entries * 2, device='cuda')
-    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(d_enc), H.ptr(grad), H.stream())
-    lhs = (enc[:, 12:44].double() * d_enc[:, 12:44].double()).sum().item()
-    rhs = (table.double().reshape(-1) * grad.double()).sum().item()
-    scale = (enc[:, 12:44].double().abs() * d_enc[:, 12:44].double().abs()).sum().item()
-    # the forward rounds every feature to fp16 (2^-11 relative), the backward accumulates in fp32
-    assert abs(lhs - rhs) <= 2.0 ** -10 * scale * 0.05 + 1e-6 * scale, (lhs, rhs, scale)
-    # additivity over rays: scattering two halves of the batch separately gives the same table gradient
-    g2 = torch.zeros_like(grad)
-    h = N // 2
-    for a, b in ((0, h), (h, N)):
-        H.call('aln_encode_bwd', C.byref(e), H.ptr(ro[a:b]), H.ptr(rd[a:b]), H.ptr(z[a * S:b * S]), None, (b - a) * S, S,
-               H.ptr(d_enc[a * S:b * S]), H.ptr(g2), H.stream())
-    # (no exact comparison of the touched-entry patterns here: with fp32 atomics a sum of opposite contributions can round to
-    #  exactly 0.0 in one arrival order and to 1 ulp in another -- seen once in three runs of 2^20 rows; the tolerance covers it,
-    #  and the small-size kernel tests hold the touched-entry sets against the oracle)
-    assert (g2 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
-    assert ((g2 != 0) != (grad != 0)).sum().item() <= 1e-5 * grad.numel()
-    # level groups (the data-parallel launch order) tile the same scatter
-    g3 = torch.zeros_like(grad)
-    for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
-        H.call('aln_encode_bwd_levels', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(d_enc), H.ptr(g3), lo, hi,
-               H.stream())
-    assert (g3 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
-    assert ((g3 != 0) != (grad != 0)).sum().item() <= 1e-5 * grad.numel()
-
-
 def test_binned_scatter_is_the_adjoint_of_the_gather_at_full_size(H):
-    """The same identities for the atomic-free scatter (aln_encode_bwd_binned), both renderer passes in one launch:
-    8192 rays x (128 + 128) samples = 2^21 rows.  Record values are fp16 (2^-11 each), accumulation is fp32."""
+    """<encode(T), D> == <T, encode_bwd(D)> for the grid part (the scatter is the transpose of the gather), both renderer passes
+    in one launch: 8192 rays x (128 + 128) samples = 2^21 rows.  Record values are fp16 (2^-11 each), their sums are exact."""
     bound = 3.0
     e = H.make_enc_desc('hg+freq', bound)
     spec = O.GridSpec()
@@ -139,20 +97,19 @@ def test_binned_scatter_is_the_adjoint_of_the_gather_at_full_size(H):
     scale = (enc[:, 12:44].double().abs() * d_enc[:, 12:44].double().abs()).sum().item()
     assert abs(lhs - rhs) <= 2.0 ** -10 * scale * 0.05 + 1e-6 * scale, (lhs, rhs, scale)
     assert flag.item() == 0
-    # against the fp32-atomic kernel on the same rows
-    ref = torch.zeros_like(grad)
-    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M1, S1, H.ptr(d_enc), H.ptr(ref), H.stream())
-    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, M - M1, S2, H.ptr(d_enc[M1:]), H.ptr(ref), H.stream())
-    assert (grad - ref).norm().item() <= 5e-4 * ref.norm().item()
-    # additivity over rays
+    # bit-reproducible at full size: every level, every entry (integer accumulation, one owner block per entry)
+    again = torch.zeros_like(grad)
+    binned(again)
+    assert torch.equal(again, grad)
+    # additivity over rays (the per-tile scaling of the records changes with the tiling: fp16 record rounding only)
     g2 = torch.zeros_like(grad)
     binned(g2, 0, N // 2); binned(g2, N // 2, N)
     assert (g2 - grad).abs().max().item() <= 1e-4 * max(1.0, grad.abs().max().item())
-    # level groups tile the scatter
+    # level groups (the data-parallel launch order) tile the scatter exactly
     g3 = torch.zeros_like(grad)
     for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
         binned(g3, lo=lo, hi=hi)
-    assert (g3 - grad).abs().max().item() <= 1e-5 * max(1.0, grad.abs().max().item())
+    assert torch.equal(g3, grad)
 
 
 def test_render_is_ray_independent_and_bounded_at_full_batch():

@@ -211,6 +211,22 @@ def test_encode_fwd_bit_exact_grid(H, encoding, L):
         assert (got[:, :fd].float() - want[:, :fd].float()).abs().max() <= 1e-3
 
 
+def _binned_bwd(H, e, ro, rd, z, rows, rows1, s1, s2, d_enc, grad, lo=0, hi=None, flag=None):
+    ws = torch.empty(max(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), 16), dtype=torch.uint8, device='cuda')
+    H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows1, s1, s2, H.ptr(d_enc), H.ptr(grad),
+           H.ptr(ws), lo, int(e.grid.n_levels) if hi is None else hi, H.ptr(flag), H.stream())
+
+
+def _grid_grad_reference(cfg, ro, rd, z_rows, ray_of_row, d_enc, bound):
+    """fp32 autograd of the oracle's encoder on the device (torch kernels, not this library): dL/dtable for upstream d_enc."""
+    x = torch.clamp(ro[ray_of_row] + rd[ray_of_row] * z_rows[:, None], -bound, bound)
+    table = torch.zeros(cfg.grid.n_entries, 2, device=x.device, requires_grad=True)
+    xn = torch.clip((x + bound) / (2.0 * bound), 0.0, 1.0)
+    enc = O.hashgrid_encode(xn, table, cfg.grid)
+    (enc * d_enc[:, 12:44].float()).sum().backward()
+    return table.grad.reshape(-1)
+
+
 def test_encode_from_rays_and_backward(H):
     bound, L = 1.0, 16
     e = H.make_enc_desc('hg+freq', bound)
@@ -236,17 +252,11 @@ def test_encode_from_rays_and_backward(H):
     want = model.params['grid'].grad
     grad = torch.zeros(cfg.grid.n_entries * 2, device='cuda')
     ded = d_enc.cuda()
-    H.call('aln_encode_bwd', C.byref(e), H.ptr(rod), H.ptr(rdd), H.ptr(zd), None, rows, S, H.ptr(ded), H.ptr(grad), H.stream())
+    _binned_bwd(H, e, rod, rdd, zd, rows, rows, S, S, ded, grad)
     got = grad.cpu().view(-1, 2)
     assert torch.equal(got != 0, want != 0), 'touched-entry sets must be identical (indexing bit-exact)'
-    # fp32 atomics: order-dependent rounding only
-    assert (got - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
-
-
-def _binned_bwd(H, e, ro, rd, z, rows, rows1, s1, s2, d_enc, grad, lo=0, hi=None, flag=None):
-    ws = torch.empty(max(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), 16), dtype=torch.uint8, device='cuda')
-    H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows1, s1, s2, H.ptr(d_enc), H.ptr(grad),
-           H.ptr(ws), lo, int(e.grid.n_levels) if hi is None else hi, H.ptr(flag), H.stream())
+    # every record is rounded to fp16 once (rel 2^-11); their sum is exact
+    assert (got - want).abs().max() <= 2.0 ** -10 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize('N,S', [(37, 24), (1, 5), (300, 13), (64, 128)])
@@ -279,17 +289,15 @@ def test_binned_encode_backward_matches_oracle(H, N, S):
     # records may cancel exactly); the sum of the records itself is exact (64-bit fixed point)
     assert ((got - want).abs() <= 2.0 ** -10 * want.abs().max()).all()
     assert (got - want).norm() <= 1e-3 * want.norm()
-    # exact integer accumulation: the result does not depend on the order the records arrive in
-    if int(e.grid.n_levels) > 3:
-        a = int(e.grid.offset[3]) * 2
-        again = torch.zeros_like(grad)
-        _binned_bwd(H, e, ro.cuda(), rd.cuda(), z.cuda().reshape(-1), rows, rows, S, S, d_enc.cuda(), again)
-        assert torch.equal(again[a:], grad[a:]), 'hashed levels must be bit-reproducible'
+    # exact integer accumulation, one owner block per table entry: the result does not depend on the order the records arrive in
+    again = torch.zeros_like(grad)
+    _binned_bwd(H, e, ro.cuda(), rd.cuda(), z.cuda().reshape(-1), rows, rows, S, S, d_enc.cuda(), again)
+    assert torch.equal(again, grad), 'every level must be bit-reproducible'
 
 
 def test_binned_encode_backward_two_passes_and_level_groups(H):
-    """Coarse + fine pass in ONE launch (rows_pass1 / two strides) and the data-parallel level groups give the gradient of the
-    fp32-atomic kernel launched per pass; a non-finite upstream gradient raises found_inf."""
+    """Coarse + fine pass in ONE launch (rows_pass1 / two strides) and the data-parallel level groups give the gradient fp32
+    autograd computes for the two passes; a non-finite upstream gradient raises found_inf."""
     bound = 2.0
     e = H.make_enc_desc('hg+freq', bound)
     N, S1, S2 = 700, 24, 40       # rows not a multiple of the 512-row tile; tiles straddle the pass boundary
@@ -302,9 +310,8 @@ def test_binned_encode_backward_two_passes_and_level_groups(H):
     d_enc = torch.zeros(M, e.enc_pad, dtype=torch.float16, device='cuda')
     d_enc[:, 12:44] = (torch.randn(M, 32, generator=g) * 0.05).half().cuda()
     n = int(e.grid.n_entries) * 2
-    ref = torch.zeros(n, device='cuda')
-    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M1, S1, H.ptr(d_enc), H.ptr(ref), H.stream())
-    H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, M - M1, S2, H.ptr(d_enc[M1:]), H.ptr(ref), H.stream())
+    ray_of_row = torch.cat([torch.arange(N, device='cuda').repeat_interleave(S1), torch.arange(N, device='cuda').repeat_interleave(S2)])
+    ref = _grid_grad_reference(O.ModelConfig(bound=bound), ro, rd, z, ray_of_row, d_enc, bound)
     got = torch.zeros(n, device='cuda')
     _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, got)
     assert (got - ref).norm().item() <= 1e-3 * ref.norm().item()
@@ -312,7 +319,7 @@ def test_binned_encode_backward_two_passes_and_level_groups(H):
     grouped = torch.zeros(n, device='cuda')
     for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
         _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, grouped, lo, hi)
-    assert (grouped - got).abs().max().item() <= 1e-5 * max(1.0, got.abs().max().item())
+    assert torch.equal(grouped, got), 'level groups must reproduce the single launch bit for bit'
     # accumulation semantics: a second call adds to the table
     _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, grouped)
     assert (grouped - 2 * got).abs().max().item() <= 2e-5 * max(1.0, got.abs().max().item())
@@ -329,7 +336,7 @@ MLP_SHAPES = [('sigma', 48, 128, 16, 2), ('color', 32, 128, 16, 2), ('semf', 16,
               ('semo_c32', 80, 64, 32, 1)]
 
 
-def _mlp_setup(H, n_in, hid, n_out, nh, seed=0, dw_ws=True):
+def _mlp_setup(H, n_in, hid, n_out, nh, seed=0):
     g = torch.Generator().manual_seed(seed)
     shapes = [(hid, n_in)] + [(hid, hid)] * (nh - 1) + [(n_out, hid)]
     Ws = [((torch.rand(o, i, generator=g) * 2 - 1) * (6.0 / (o + i)) ** 0.5) for o, i in shapes]
@@ -340,17 +347,16 @@ def _mlp_setup(H, n_in, hid, n_out, nh, seed=0, dw_ws=True):
     wb = torch.zeros(nb, dtype=torch.float16, device='cuda')
     wr = torch.zeros((H.lib().aln_mlp_rowmajor_halves(n_in, hid, n_out, nh) + 7) // 8 * 8, dtype=torch.float16, device='cuda')
     H.call('aln_mlp_repack', H.ptr(flat), n_in, hid, n_out, nh, H.ptr(wf), H.ptr(wb), H.ptr(wr), H.stream())
-    nws = H.lib().aln_mlp_dw_ws_bytes(n_in, hid, n_out, nh) if dw_ws else 0
-    ws = torch.empty(max(nws // 4, 1), device='cuda')      # per-block weight-gradient partial sums (None: atomic flush)
-    desc = H.AlnMlpDesc(n_in, hid, n_out, nh, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(), ws.data_ptr() if dw_ws else None, nws)
+    nws = H.lib().aln_mlp_dw_ws_bytes(n_in, hid, n_out, nh)
+    ws = torch.empty(max(nws // 4, 1), device='cuda')      # per-block weight-gradient partial sums of the recompute backward
+    desc = H.AlnMlpDesc(n_in, hid, n_out, nh, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(), ws.data_ptr(), nws)
     return Ws, desc, (flat, wf, wb, wr, ws)
 
 
-@pytest.mark.parametrize('dw_ws', [True, False], ids=['dw_slabs', 'dw_atomics'])
 @pytest.mark.parametrize('name,n_in,hid,n_out,nh', MLP_SHAPES)
-def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh, dw_ws):
+def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh):
     rows = 1000  # ragged: not a multiple of 32
-    Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh, dw_ws=dw_ws)
+    Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(rows, n_in, generator=g).half()
     xo = x.float().requires_grad_(True)
@@ -390,23 +396,29 @@ def test_mlp_forward_backward(H, name, n_in, hid, n_out, nh, dw_ws):
     assert flag.item() == 0
     assert (d_in2.float() - d_in.float()).abs().max().item() <= 2e-3 * gi.abs().max().item() + 1e-5, name
     assert (dW2 - dW).abs().max().item() <= 2e-3 * dW.abs().max().item() + 1e-5, name
-    if dw_ws:   # slabs + fixed-order reduction: the weight gradient is bit-reproducible, and it accumulates into dW (+=)
-        dW3 = dW2.clone()
-        H.call('aln_mlp_bwd', C.byref(desc), H.ptr(xd), None, None, H.ptr(dod), rows, None, None, None, H.ptr(d_in2), H.ptr(dW3),
+    # slabs + fixed-order reduction: the weight gradient is bit-reproducible, and it accumulates into dW (+=)
+    dW3 = dW2.clone()
+    H.call('aln_mlp_bwd', C.byref(desc), H.ptr(xd), None, None, H.ptr(dod), rows, None, None, None, H.ptr(d_in2), H.ptr(dW3),
+           H.ptr(flag), H.stream())
+    assert torch.equal(dW3, 2 * dW2), name
+    # without the slab workspace the recompute backward refuses to run (no atomic flush left)
+    bare = H.AlnMlpDesc(n_in, hid, n_out, nh, desc.wf, desc.wb, desc.wr, None, 0)
+    with pytest.raises(RuntimeError, match='dw_ws'):
+        H.call('aln_mlp_bwd', C.byref(bare), H.ptr(xd), None, None, H.ptr(dod), rows, None, None, None, H.ptr(d_in2), H.ptr(dW3),
                H.ptr(flag), H.stream())
-        assert torch.equal(dW3, 2 * dW2), name
 
 
-def test_mlp_recompute_backward_many_tiles_slabs_match_atomics(H):
-    """70 000 rows (547 tiles: every one of the 256 / 512 blocks owns tiles, ragged tail): slab flush vs atomic flush."""
+def test_mlp_recompute_backward_many_tiles_is_reproducible_and_matches_fp32(H):
+    """70 000 rows (547 tiles: every one of the 256 / 512 blocks owns tiles, ragged tail): two launches agree bit for bit and
+    the weight gradient matches an fp32 torch evaluation of the same fp16 network on the device."""
     rows = 70000
     for (n_in, hid, n_out, nh) in [(48, 128, 16, 2), (16, 64, 64, 2), (80, 64, 16, 1)]:
+        Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh)
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(rows, n_in, generator=g).half().cuda()
+        d_out = (torch.randn(rows, n_out, generator=g) * 0.05).half().cuda()
         res = []
-        for dw_ws in (True, False):
-            Ws, desc, keep = _mlp_setup(H, n_in, hid, n_out, nh, dw_ws=dw_ws)
-            g = torch.Generator().manual_seed(11)
-            x = torch.randn(rows, n_in, generator=g).half().cuda()
-            d_out = (torch.randn(rows, n_out, generator=g) * 0.05).half().cuda()
+        for _ in range(2):
             d_in = torch.zeros(rows, n_in, dtype=torch.float16, device='cuda')
             dW = torch.zeros(sum(w.numel() for w in Ws), device='cuda')
             flag = torch.zeros(1, dtype=torch.int32, device='cuda')
@@ -414,8 +426,11 @@ def test_mlp_recompute_backward_many_tiles_slabs_match_atomics(H):
                    H.ptr(flag), H.stream())
             assert flag.item() == 0
             res.append((d_in.clone(), dW.clone()))
-        assert torch.equal(res[0][0], res[1][0])
-        assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-4 * res[1][1].abs().max().item()
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        Wd = [w.cuda().requires_grad_(True) for w in Ws]
+        (O.mlp_forward(x.float(), Wd, half_sim=True) * d_out.float()).sum().backward()
+        want = torch.cat([w.grad.reshape(-1) for w in Wd])
+        assert (res[0][1] - want).norm().item() <= 5e-3 * want.norm().item()
 
 
 def test_mlp_device_row_count_and_inf_flag(H):
@@ -519,45 +534,34 @@ def test_sample_fine_matches_sample_pdf(H, perturb):
 
 
 def test_fused_semantic_heads_forward_is_bit_identical_to_two_launches(H):
-    """k_sem_fwd_fused keeps f in a wave-private LDS tile; same fragments, same k-order -> same bits as the two-kernel path."""
+    """k_sem_fwd_fused keeps f in a wave-private LDS tile; same fragments, same k-order -> same bits as the per-head kernels fed
+    with materialised inputs (aln_build_sem_in + aln_mlp_fwd)."""
     _, dF, keepF = _mlp_setup(H, 16, 64, 64, 2, seed=3)
     _, dO, keepO = _mlp_setup(H, 80, 64, 16, 1, seed=4)
     rows = 5000 + 17                       # ragged: not a multiple of 32
     g = torch.Generator().manual_seed(5)
     sigma_out = (torch.randn(rows, 16, generator=g)).half().cuda()
-    outs = []
-    for unfused in (False, True):
-        if unfused:
-            os.environ['ALN_SEM_FWD_UNFUSED'] = '1'
-        try:
-            feat = torch.zeros(rows, 64, dtype=torch.float16, device='cuda')
-            logits = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
-            H.call('aln_sem_heads_fwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, 15, H.ptr(feat), H.ptr(logits), H.stream())
-            torch.cuda.synchronize()
-            outs.append((feat.cpu(), logits.cpu()))
-        finally:
-            os.environ.pop('ALN_SEM_FWD_UNFUSED', None)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert outs[0][0].abs().max() > 0 and outs[0][1].abs().max() > 0
+    feat = torch.zeros(rows, 64, dtype=torch.float16, device='cuda')
+    logits = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
+    H.call('aln_sem_heads_fwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, 15, H.ptr(feat), H.ptr(logits), H.stream())
+    fin = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
+    oin = torch.zeros(rows, 80, dtype=torch.float16, device='cuda')
+    feat2, logits2 = torch.zeros_like(feat), torch.zeros_like(logits)
+    H.call('aln_build_sem_in', H.ptr(sigma_out), None, rows, 64, 15, 16, 80, H.ptr(fin), None, H.stream())
+    H.call('aln_mlp_fwd', C.byref(dF), H.ptr(fin), rows, None, None, None, H.ptr(feat2), H.stream())
+    H.call('aln_build_sem_in', H.ptr(sigma_out), H.ptr(feat2), rows, 64, 15, 16, 80, None, H.ptr(oin), H.stream())
+    H.call('aln_mlp_fwd', C.byref(dO), H.ptr(oin), rows, None, None, None, H.ptr(logits2), H.stream())
+    assert torch.equal(feat, feat2) and torch.equal(logits, logits2)
+    assert feat.abs().max() > 0 and logits.abs().max() > 0
 
 
 @pytest.mark.parametrize('N,S1,S2,Ccls,out_pad,G', [(37, 24, 20, 7, 16, 15), (41, 128, 0, 20, 32, 15), (300, 64, 64, 40, 48, 7),
                                                      (64, 128, 128, 64, 64, 15)])
-def test_fused_semantic_heads_backward_matches_two_launches_and_fp32(H, N, S1, S2, Ccls, out_pad, G):
-    """k_sem_bwd_fused5 (both heads, one five-layer chain, f recomputed) against the two-launch recompute path on the same
-    inputs, and against fp32 autograd of models.py:248-256 (half_sim oracle MLPs): d(geo_feat), all five weight gradients."""
+def test_semantic_heads_backward_matches_fp32(H, N, S1, S2, Ccls, out_pad, G):
+    """aln_sem_heads_bwd (both heads, inputs and output gradients built on the fly, f re-read) against fp32 autograd of
+    models.py:248-256 (half_sim oracle MLPs): d(geo_feat), all five weight gradients; fold_geo; the overflow watch."""
     Wf, dF, keepF = _mlp_setup(H, 16, 64, 64, 2, seed=3)
     Wo, dO, keepO = _mlp_setup(H, 80, 64, out_pad, 1, seed=4)
-    assert H.lib().aln_sem_heads_bwd_fused_ok(C.byref(dF), C.byref(dO), 64) == 0      # off by default (slower than two launches)
-    os.environ['ALN_SEM_BWD_FUSED5'] = '1'
-    try:
-        assert H.lib().aln_sem_heads_bwd_fused_ok(C.byref(dF), C.byref(dO), 64) == 1
-        _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G)
-    finally:
-        os.environ.pop('ALN_SEM_BWD_FUSED5', None)
-
-
-def _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G):
     rows = N * (S1 + S2)
     g = torch.Generator().manual_seed(9)
     sigma_out = torch.randn(rows, 16, generator=g).half().cuda()
@@ -569,28 +573,19 @@ def _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G):
     H.call('aln_sem_heads_fwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, G, H.ptr(feat), H.ptr(logits), H.stream())
     nf, no = sum(w.numel() for w in Wf), sum(w.numel() for w in Wo)
     flag = torch.zeros(1, dtype=torch.int32, device='cuda')
-    # two launches
     d_oin = torch.zeros(rows, 80, dtype=torch.float16, device='cuda')
     d_fin = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
-    dWf2, dWo2 = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
+    dWf, dWo = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
     H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf2), H.ptr(dWo2), 0, H.ptr(flag), H.stream())
-    want_geo = d_fin.float() + d_oin[:, 64:80].float()
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf), H.ptr(dWo), 0, H.ptr(flag), H.stream())
+    d_geo = d_fin.float() + d_oin[:, 64:80].float()
     # fold_geo = 1: the same sum leaves the second launch directly (one rounding instead of two)
-    d_fin_f = torch.zeros_like(d_fin); dWf3, dWo3 = torch.zeros_like(dWf2), torch.zeros_like(dWo2)
+    d_fin_f = torch.zeros_like(d_fin); dWf3, dWo3 = torch.zeros_like(dWf), torch.zeros_like(dWo)
     H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
            N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, H.ptr(flag), H.stream())
-    assert (d_fin_f.float() - want_geo).abs().max().item() <= 2e-3 * want_geo.abs().max().item() + 1e-6
-    assert torch.equal(dWf3, dWf2) and torch.equal(dWo3, dWo2)
-    # one launch
-    d_geo = torch.full((rows, 16), 7.0, dtype=torch.float16, device='cuda')
-    dWf, dWo = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
-    H.call('aln_sem_heads_bwd_fused', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_geo), H.ptr(dWf), H.ptr(dWo), H.ptr(flag), H.stream())
     assert flag.item() == 0
-    tol = lambda a: 4e-3 * a.abs().max().item() + 1e-6      # fp16 intermediates rounded at different points
-    assert (d_geo.float() - want_geo).abs().max().item() <= tol(want_geo)
-    assert (dWf - dWf2).abs().max().item() <= tol(dWf2) and (dWo - dWo2).abs().max().item() <= tol(dWo2)
+    assert (d_fin_f.float() - d_geo).abs().max().item() <= 2e-3 * d_geo.abs().max().item() + 1e-6
+    assert torch.equal(dWf3, dWf) and torch.equal(dWo3, dWo)
     # fp32 autograd through the half_sim oracle MLPs
     x = sigma_out.cpu().float()
     geo = torch.cat([x[:, 1:1 + G], torch.ones(rows, 16 - G)], 1).requires_grad_(True)
@@ -602,7 +597,7 @@ def _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G):
     wr = w_row.cpu()
     loss = (lo[:, :Ccls] * (wr[:, None] * g_sem.cpu()[ray])).sum() + (f * (wr[:, None] * g_feat.cpu()[ray])).sum()
     loss.backward()
-    assert (d_geo.cpu().float() - geo.grad).abs().max().item() <= 1e-2 * geo.grad.abs().max().item() + 1e-5
+    assert (d_fin_f.cpu().float() - geo.grad).abs().max().item() <= 1e-2 * geo.grad.abs().max().item() + 1e-5
     o = 0
     for w in Wfo:
         assert (dWf[o:o + w.numel()].cpu().view_as(w) - w.grad).abs().max().item() <= 1e-2 * w.grad.abs().max().item() + 1e-5
@@ -614,8 +609,8 @@ def _fused5_case(H, Wf, dF, Wo, dO, N, S1, S2, Ccls, out_pad, G):
     # overflow watch: an inf per-ray gradient must raise the flag
     g_bad = g_feat.clone(); g_bad[0, 3] = float('inf')
     w2 = w_row.clone(); w2[0] = 1.0
-    H.call('aln_sem_heads_bwd_fused', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(w2), H.ptr(g_sem), H.ptr(g_bad),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_geo), H.ptr(dWf), H.ptr(dWo), H.ptr(flag), H.stream())
+    H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w2), H.ptr(g_sem), H.ptr(g_bad),
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, H.ptr(flag), H.stream())
     assert flag.item() == 1
 
 
@@ -685,12 +680,12 @@ def test_density_grid_update_and_untrained_mask_match_oracle(H):
     sigma = (g.random(n) ** 4 * 5).astype(np.float32)
     grid_w, bits_w, mean_w = MO.grid_update(want, sigma, 0.95, 1.0, 0.01)
     gd = dev(want.copy())
-    stats, nset = torch.zeros(2, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+    stats, nset = torch.zeros(2, dtype=torch.int64, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
     bits = torch.zeros((n + 31) // 32, dtype=torch.int32, device='cuda')
     sd = dev(sigma)
     H.call('aln_grid_update', H.ptr(gd), H.ptr(sd), G, 0.95, 1.0, 0.01, H.ptr(stats), H.ptr(bits), H.ptr(nset), H.stream())
     assert np.array_equal(gd.cpu().numpy(), grid_w)
-    assert abs(stats[0].item() / stats[1].item() - mean_w) < 1e-5 * max(mean_w, 1.0)
+    assert abs(stats[0].item() / 65536.0 / stats[1].item() - mean_w) < 1e-4 * max(mean_w, 1.0)   # fixed-point sum (2^-16), integer count
     unpacked = ((bits.cpu().numpy().view(np.uint32)[:, None] >> np.arange(32, dtype=np.uint32)[None]) & 1).astype(bool).reshape(-1)[:n]
     th = min(mean_w, 0.01)
     near_th = np.abs(grid_w - th) < 1e-6

@@ -178,7 +178,7 @@ def test_lseg_width_heads_match_oracle(D, C_):
     oracle, pipe, cfg = build_pair(L=4, D=D, C_=C_)
     nets = pipe.L.nets
     assert (nets['semf'].wide or nets['semo'].wide) and not nets['sigma'].wide and pipe.L.sem_wide
-    assert not any(n.lib for n in nets.values()) and not pipe.L.sem_lib, 'no head may go to a library GEMM'
+    assert pipe.L.sem_wide and not hasattr(pipe, '_lib_fwd'), 'the wide heads run on wide.hip: there is no library-GEMM path'
     N, S1, S2, Cf = 24, 32, 32, min(D, 512)
     o, d, norms = make_rays(N, seed=3)
     g = torch.Generator().manual_seed(5)
