@@ -288,3 +288,32 @@ extern "C" int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d
   ALN_CHECK_LAUNCH("assemble_dsemf_out");
   return 0;
 }
+
+// ---- open-vocabulary prompt comparison (autolabel/evaluation.py:304-323, 426-443): out[r] = argmax_c <f_r, t_c> in fp32, first
+// maximum wins, all-zero rows -> 0 (the reference divides by the norm first: NaN rows argmax to 0 there).  One wave per row at a
+// time: the row is read coalesced, the prompt matrix [C, D] stays in L1 / L2 (tens of prompts).
+__global__ __launch_bounds__(256) void k_similarity_argmax(const float* __restrict__ f, int n, int D, const float* __restrict__ t, int C,
+                                                          long long* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += gridDim.x * 4) {
+    const float* fr = f + (size_t)r * D;
+    float best = -INFINITY; int arg = 0; bool any = false;
+    for (int d = lane; d < D; d += 64) any |= fr[d] != 0.f;
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      for (int d = lane; d < D; d += 64) acc = fmaf(fr[d], t[(size_t)c * D + d], acc);
+      acc = wave_sum(acc);
+      if (acc > best) { best = acc; arg = c; }
+    }
+    if (!__any(any)) arg = 0;
+    if (lane == 0) out[r] = arg;
+  }
+}
+extern "C" int aln_similarity_argmax(const float* features, int32_t n, int32_t D, const float* text, int32_t C, int64_t* out, void* stream) {
+  ALN_REQUIRE(features && text && out && n >= 0 && D > 0 && C > 0, "similarity_argmax: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_similarity_argmax, dim3(aln_grid_for((int64_t)n, 4, 256 * 16)), dim3(256), 0, (hipStream_t)stream, features, n, D, text, C,
+                     (long long*)out);
+  ALN_CHECK_LAUNCH("similarity_argmax");
+  return 0;
+}

@@ -91,6 +91,7 @@ _SIGS = {
     'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 6),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),
     'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, vp, vp]),
+    'aln_similarity_argmax': (i32, [vp, i32, i32, vp, i32, vp, vp]),
     'aln_cast_f16': (i32, [vp, vp, i64, vp]),
     'aln_grad_pack_f16': (i32, [vp, i64, f32, vp, vp]),
     'aln_grad_unpack_f16': (i32, [vp, i64, vp, vp, vp]),

@@ -9,8 +9,8 @@ The reference answers "which text prompt does this pixel / 3-D point look like" 
   one dot product per prompt in a Python loop, argmax.
 
 Here the point path is one launch sequence per jitter (hash-grid encode -> sigma head -> both semantic heads on the HIP
-kernels, no geo_feat round trip through fp32) and the prompt comparison is one fp32 GEMM (hipBLASLt through ``torch.mm``:
-a plain [n, D] x [D, C] product, the case the design rules leave to the library) followed by an argmax.
+kernels, no geo_feat round trip through fp32) and the prompt comparison is one kernel (``aln_similarity_argmax``: fp32 dot
+products against the prompt matrix and the argmax, no [n, C] similarity tensor).
 """
 import ctypes as C
 
@@ -20,20 +20,17 @@ from . import hip as H
 from .pipeline import f16
 
 
-def similarity_argmax(features, text_features, chunk=1 << 18):
-    """argmax_c <f / |f|, t_c> for every row of ``features`` [n, D] against ``text_features`` [C, D] -> int64 [n].
+def similarity_argmax(features, text_features):
+    """argmax_c <f / |f|, t_c> for every row of ``features`` [n, D] against ``text_features`` [C, D] -> int64 [n]
+    (``aln_similarity_argmax``, csrc/heads.hip: fp32 dot products, first maximum).
 
     The division by the feature norm does not change the argmax, but rows with a zero feature are NaN in the reference
     and argmax to class 0 there (evaluation.py:304, 426); that is kept."""
-    f = features.reshape(-1, features.shape[-1]).float()
-    t = text_features.float().to(f.device)
+    f = features.reshape(-1, features.shape[-1]).float().contiguous()
+    t = text_features.float().to(f.device).contiguous()
+    assert t.shape[1] == f.shape[1], 'text features and rendered features must have the same width'
     out = torch.empty(f.shape[0], dtype=torch.int64, device=f.device)
-    for a in range(0, f.shape[0], chunk):
-        fa = f[a:a + chunk]
-        sim = fa @ t.t()
-        idx = sim.argmax(dim=-1)
-        idx[(fa == 0).all(dim=-1)] = 0
-        out[a:a + chunk] = idx
+    H.call('aln_similarity_argmax', H.ptr(f), f.shape[0], f.shape[1], H.ptr(t), t.shape[0], H.ptr(out), H.stream())
     return out.reshape(features.shape[:-1])
 
 

@@ -209,6 +209,11 @@ int aln_assemble_grads(const float* d_h0, const void* d_semf_in, int32_t semf_in
 int aln_assemble_dsemf_out(void* d_feat, const void* f, const void* d_semo_in, int32_t rows, int32_t D, int32_t semo_in_pad,
                            int32_t* found_inf, void* stream);
 
+/* open-vocabulary prompt comparison (OpenVocabEvaluator._predict_semantic, autolabel/evaluation.py:295-327, 400-445):
+ * out[r] = argmax_c <features[r, :], text[c, :]> in fp32 (first maximum; an all-zero feature row -> 0, as the reference's NaN row) */
+int aln_similarity_argmax(const float* features /*[n,D]*/, int32_t n, int32_t D, const float* text /*[C,D]*/, int32_t C,
+                          int64_t* out /*[n]*/, void* stream);
+
 /* ---- wide semantic heads (wide.hip): semantic_features / semantic_out at LSeg width (hidden_dim_semantic = 512,
  * autolabel/models.py:117-136, scripts/ros/node.py:166-176), one hand-written MFMA GEMM launch per layer.
  * A operand = [a1 (K1 columns, optionally through ReLU) | geo block (16 columns [geo_feat, 1..] built from the density head's

@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'build':
     from autolabel_amd import build as B
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES if os.path.exists(os.path.join(B.CSRC, s))]
-    subprocess.run(['hipcc'] + B.FLAGS + ['-DALN_PHASE_TIMING'] + srcs + ['-o', OUT], check=True)
+    subprocess.run(['hipcc'] + B.FLAGS + ['-shared', '-DALN_PHASE_TIMING'] + srcs + ['-o', OUT], check=True)
     sys.exit(0)
 import torch
 from autolabel_amd import hip as H
@@ -46,7 +46,7 @@ buf = (C.c_longlong * 64)()
 lib.aln_debug_read_phases(buf, 0)
 us = e0.elapsed_time(e1) / reps * 1e3
 ntiles = rows // 128
-occ = 2 if (m.hidden == 64 and os.environ.get('ALN_MLP_OCC2', '1') != '0') else 1   # 64-wide heads: two blocks per CU
+occ = 2 if (m.hidden == 64 and m.in_pad <= 32) else 1   # 64-wide heads: two blocks per CU
 nblk = min(ntiles, occ * torch.cuda.get_device_properties(0).multi_processor_count)
 iters = (ntiles + nblk - 1) // nblk * reps
 print(f'{head}: {us:.0f} us per launch, {iters // reps} tiles per block')

@@ -466,48 +466,62 @@ def test_open_vocabulary_queries_follow_the_reference_recipe():
 
 
 def test_reference_checkpoint_import_and_fused_grid_position(tmp_path):
-    """a `checkpoints/*.pth` in the reference's format (tcnn flat `params`, fp16 copies, fork-only buffers) loads
-    through model_utils.load_checkpoint(reference=True); the grid position then follows tcnn's fused multiply-add and the
+    """a `checkpoints/*.pth` in the reference's format, WRITTEN BY THE ORACLE from its own per-layer matrices
+    (oracle/tcnn_pack.py: fp16 grid, padded [out, in] matrices, 1-D and 2-D tensors, fork-only buffers) -- not derived from the
+    model under test -- loads through model_utils.load_checkpoint(reference=True); density / color / semantic of the loaded
+    model then match the oracle evaluated on the same matrices, the grid position follows tcnn's fused multiply-add and the
     hash-grid features are bit-exact to the oracle evaluated the same way."""
     import ctypes as C
     from autolabel_amd import hip as H, model_utils
-    model = make_model(D=64, C_=5, bound=2.0, grid_scale=2e3)
-    own = model.state_dict()
-    ref_sd = {}
-    for k, v in own.items():
-        if k.endswith('.params'):
-            t = v.detach().cpu().clone()
-            ref_sd[k] = t.half() if 'grid' in k else t          # tcnn: the grid often travels as fp16
-        elif k in ('aabb_train', 'aabb_infer'):
-            ref_sd[k] = v.detach().cpu().clone()
-    ref_sd['density_grid'] = torch.zeros(1, 128 ** 3)            # fork-only buffers: ignored
-    ref_sd['step_counter'] = torch.zeros(16, 2, dtype=torch.int32)
+    from oracle.tcnn_pack import pack_reference_state_dict
+    bound = 2.0
+    cfg = O.ModelConfig(feature_dim=64, n_classes=5, bound=bound, grid=O.GridSpec(pos_fma=True))
+    params = O.init_params(cfg, seed=11)
+    with torch.no_grad():
+        params['grid'].mul_(2e3)                          # a trained-looking table (the initialisation is +-1e-4)
+        params['grid'].copy_(params['grid'].half().float())   # what an fp16 grid copy holds
+    ref_sd = pack_reference_state_dict(params, cfg, bound=bound)
+    assert ref_sd['color_net.params'].dim() == 2 and ref_sd['sigma_net.params'].dim() == 1
+    assert ref_sd['encoder.grid_encoding.params'].dtype == torch.float16
     os.makedirs(tmp_path / 'checkpoints')
     torch.save({'model': ref_sd, 'epoch': 10}, tmp_path / 'checkpoints' / 'ngp_ep0010.pth')
-    m2 = make_model(D=64, C_=5, bound=2.0, grid_scale=1.0)
+    m2 = make_model(D=64, C_=5, bound=bound, grid_scale=1.0)
     assert not m2.tcnn_fma
     model_utils.load_checkpoint(m2, str(tmp_path / 'checkpoints'), reference=True)
     assert m2.tcnn_fma and m2._layout.enc.grid.pos_fma == 1
-    a, b = m2.encoder.grid_encoding.params.detach().cpu(), own['encoder.grid_encoding.params'].cpu().half().float()
-    assert torch.equal(a, b) and torch.equal(m2.sigma_net.params.detach().cpu(), own['sigma_net.params'].cpu())
+    assert torch.equal(m2.encoder.grid_encoding.params.detach().cpu(), params['grid'].reshape(-1))
     # a wrong head width is refused with both counts in the message
     bad = dict(ref_sd); bad['semantic_out.params'] = torch.zeros(7)
     with pytest.raises(ValueError, match='semantic_out.params'):
-        model_utils.import_reference_state_dict(make_model(D=64, C_=5, bound=2.0), bad)
-    # features: HIP (fma on) == oracle (pos_fma=True) bit for bit; with the switch off a few last-bit cases differ
-    oracle, cfg = oracle_of(m2)
-    cfg.grid = O.GridSpec(pos_fma=True)
+        model_utils.import_reference_state_dict(make_model(D=64, C_=5, bound=bound), bad)
+    # point queries of the loaded model against the oracle on ITS matrices (models.py:175-220, 248-256)
+    oracle = O.OracleModel(cfg, params={k: v.clone() for k, v in params.items()}, half_sim=True)
     g = torch.Generator().manual_seed(0)
-    x = (torch.rand(4000, 3, generator=g) * 2 - 1) * 2.0
-    want = O.OracleModel(cfg, params=oracle.params, half_sim=True).encode(x)[:, 12:].half()
+    x = (torch.rand(4000, 3, generator=g) * 2 - 1) * bound
+    d = torch.nn.functional.normalize(torch.randn(4000, 3, generator=g), dim=1)
+    with torch.no_grad():
+        want = oracle.density(x)
+        want_rgb = oracle.color(x, d, geo_feat=want['geo_feat'])
+        want_logits, want_f = oracle.semantic(want['geo_feat'])
+        m2.eval()
+        got = m2.density(x.cuda())
+        got_rgb = m2.color(x.cuda(), d.cuda(), geo_feat=got['geo_feat'])
+        got_logits, got_f = m2.semantic(got['geo_feat'])
+    tol = lambda t: 4e-3 * max(1.0, t.abs().max().item())
+    assert (got['geo_feat'].float().cpu() - want['geo_feat']).abs().max() <= tol(want['geo_feat'])
+    assert (got['sigma'].cpu().log() - want['sigma'].log()).abs().max() <= 4e-3 * max(1.0, want['sigma'].log().abs().max().item())
+    assert (got_rgb.cpu() - want_rgb).abs().max() <= 4e-3
+    assert (got_f.float().cpu() - want_f).abs().max() <= tol(want_f) and (got_logits.float().cpu() - want_logits).abs().max() <= tol(want_logits)
+    # features: HIP (fma on) == oracle (pos_fma=True) bit for bit; with the switch off a few last-bit cases differ
+    want_enc = oracle.encode(x)[:, 12:].half()
     pipe, e = m2._ensure_device(), m2._layout.enc
     enc = torch.zeros(4000, e.enc_pad, dtype=torch.float16, device='cuda')
     xd = x.cuda().contiguous()
     H.call('aln_encode_fwd', C.byref(e), H.ptr(pipe.P.table16), None, None, None, H.ptr(xd), 4000, 1, H.ptr(enc), H.stream())
-    assert torch.equal(enc.cpu()[:, 12:44], want)
+    assert torch.equal(enc.cpu()[:, 12:44], want_enc)
     m2.set_tcnn_fma(False)
     H.call('aln_encode_fwd', C.byref(e), H.ptr(pipe.P.table16), None, None, None, H.ptr(xd), 4000, 1, H.ptr(enc), H.stream())
-    assert not torch.equal(enc.cpu()[:, 12:44], want)
+    assert not torch.equal(enc.cpu()[:, 12:44], want_enc)
 
 
 def test_backward_through_an_overwritten_render_context_raises():

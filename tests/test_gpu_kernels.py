@@ -254,7 +254,10 @@ def test_encode_from_rays_and_backward(H):
     ded = d_enc.cuda()
     _binned_bwd(H, e, rod, rdd, zd, rows, rows, S, S, ded, grad)
     got = grad.cpu().view(-1, 2)
-    assert torch.equal(got != 0, want != 0), 'touched-entry sets must be identical (indexing bit-exact)'
+    # indexing bit-exact: no entry the oracle leaves alone receives a gradient, and every entry the oracle touches with more than
+    # an fp16-denormal-sized product (records travel as scaled fp16) is touched here
+    assert not ((got != 0) & (want == 0)).any(), 'an entry the oracle never touches received a gradient'
+    assert not ((got == 0) & (want.abs() > 1e-6 * want.abs().max())).any(), 'an entry the oracle touches is missing'
     # every record is rounded to fp16 once (rel 2^-11); their sum is exact
     assert (got - want).abs().max() <= 2.0 ** -10 * max(1.0, want.abs().max().item())
 

@@ -1,11 +1,15 @@
 """Matched-quality gate ("at fixed quality": held-out PSNR within +-0.2 dB and mIoU within +-0.5 pt of the
-oracle trained with identical seeds / iterations).  The HIP engine (fp16 MFMA heads, fp16 table shadow, loss scaling, fused
-Adam) and the CPU oracle (PyTorch; fp16 rounding points of the reference's tcnn arithmetic simulated) train the same model from the same initialisation on the same batches and the same random
-numbers for 1000 Adam steps on a reduced S1 room scene; both are then scored on held-out frames by the SAME metric code
-(autolabel_amd.quality: PSNR / depth L1 / mIoU as the reference computes it, autolabel/evaluation.py:21-29,
-scripts/evaluate.py:100-105).  The measured numbers are written to gpurun_out/quality_gate.json."""
+oracle trained with identical seeds / iterations).
+
+Three HIP trainees (fp16 MFMA heads, fp16 table shadow, loss scaling, fused Adam; sample-noise seeds 7, 8, 9) and two oracle
+trainees (plain PyTorch ops with the fp16 rounding points of the reference's tcnn arithmetic; seeds 7, 8 -- the same counter-RNG
+numbers as the HIP runs with those seeds) start from the same initialisation and see the same host-generated batches of a reduced
+S1 room scene.  All are scored on held-out frames by the SAME metric code (autolabel_amd.quality: PSNR / depth L1 / mIoU as the
+reference computes it, autolabel/evaluation.py:21-29, scripts/evaluate.py:100-105).  The gate compares the MEANS over the
+seeds with the survey's tolerances as they stand -- no best-of, no widening -- in a regime where the field is actually trained
+(the oracle must pass 22 dB).  The oracle runs on the GPU box's device through torch's own kernels (never this library), which
+is what makes a run of this length affordable inside the suite.  The measured numbers go to gpurun_out/quality_gate.json."""
 import json
-import math
 import os
 import random
 
@@ -18,7 +22,10 @@ pytestmark = pytest.mark.gpu
 from oracle import nerf_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STEPS, B, S1, S2 = 1000, 512, 24, 24
+
+# the regime of the gate (scripts/dev/quality_gate_probe.py sweeps these)
+GATE = dict(steps=2500, batch=1024, s1=48, s2=48, n_frames=40, w=96, h=72, levels=12, log2_T=17, hip_seeds=(7, 8, 9), oracle_seeds=(7, 8))
+TOL_PSNR_DB, TOL_MIOU_PT, MIN_ORACLE_PSNR_DB = 0.2, 0.5, 22.0
 
 
 class _Frames:
@@ -34,17 +41,17 @@ class _Frames:
                 'pixels': f('pixels').reshape(-1, 3), 'depth': f('depth').reshape(-1), 'semantic': f('semantic', torch.int64).reshape(-1)}
 
 
-def test_hip_training_reaches_the_quality_of_the_fp32_oracle():
+def run_gate(steps, batch, s1, s2, n_frames, w, h, levels, log2_T, hip_seeds, oracle_seeds, oracle_device='cuda', half_sim=True):
     from test_gpu_pipeline import build_pair
     from autolabel_amd import synthetic
     from autolabel_amd.dataset import ArrayDataset
     from autolabel_amd.engine import TrainEngine
     from autolabel_amd.quality import heldout_metrics, pipe_renderer
-    torch.set_num_threads(min(32, max(1, len(os.sched_getaffinity(0)))))
-    scene = synthetic.make_room_scene(n_frames=30, w=64, h=48, fx=32.0, fy=32.0, cx=31.5, cy=23.5, feat_dim=16, feat_hw=(6, 8),
-                                      labelled_every=2)
-    held = [4, 11, 18, 25]
-    train_ids = [i for i in range(30) if i not in held]
+    B, S1, S2 = batch, s1, s2
+    scene = synthetic.make_room_scene(n_frames=n_frames, w=w, h=h, fx=w / 2.0, fy=w / 2.0, cx=(w - 1) / 2.0, cy=(h - 1) / 2.0, feat_dim=16,
+                                      feat_hw=(max(h // 8, 2), max(w // 8, 2)), labelled_every=2)
+    held = list(range(4, n_frames, 7))
+    train_ids = [i for i in range(n_frames) if i not in held]
     cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in scene.items()}
     tr = dict(cpu, images=cpu['images'][train_ids], depths=cpu['depths'][train_ids], semantics=cpu['semantics'][train_ids],
               features=cpu['features'][train_ids], T_CW=cpu['T_CW'][train_ids])
@@ -53,67 +60,87 @@ def test_hip_training_reaches_the_quality_of_the_fp32_oracle():
     ds, ds_test = ArrayDataset(tr, batch_size=B), ArrayDataset(te, batch_size=B, split='test')
     bound = float(((ds.max_bounds - ds.min_bounds) - (ds.min_bounds + ds.max_bounds) * 0.5).max())
     C_ = scene['n_classes']
-    oracle, pipe, cfg = build_pair(L=8, D=64, C_=C_, bound=bound, grid_scale=1.0, log2_T=14)
-    _, pipe2, _ = build_pair(L=8, D=64, C_=C_, bound=bound, grid_scale=1.0, log2_T=14)     # second HIP run, other noise seed
-    # The comparator keeps the oracle's fp16 rounding points (half_sim): that is the arithmetic the REFERENCE trains in
-    # (tcnn FullyFusedMLP: fp16 weights / activations, fp32 accumulate; fp16 grid features).  Measured with this protocol
-    # (scripts/dev/quality_gate_variants.py -> profiles/r02_quality_gate_variants.json): plain fp32 oracle 13.65 dB, half_sim
-    # oracle 13.05 dB, HIP 12.94 dB (binned scatter) / 12.91 dB (fp32-atomic scatter): the 0.6 dB to plain fp32 is the price of
-    # fp16 arithmetic itself, not of this implementation.
-    eng = TrainEngine(pipe, num_steps=S1, upsample_steps=S2, feature_loss=True)
-    eng2 = TrainEngine(pipe2, num_steps=S1, upsample_steps=S2, feature_loss=True)
-    st = {k: [torch.zeros_like(v), torch.zeros_like(v), 0] for k, v in oracle.params.items()}
+    # every trainee starts from the same parameters (seed 0); the comparator keeps the oracle's fp16 rounding points (half_sim):
+    # that is the arithmetic the REFERENCE trains in (tcnn FullyFusedMLP: fp16 weights / activations, fp32 accumulate; fp16 grid)
+    hips = []
+    for s in hip_seeds:
+        _, pipe, cfg = build_pair(L=levels, D=64, C_=C_, bound=bound, grid_scale=1.0, log2_T=log2_T)
+        hips.append((s, pipe, TrainEngine(pipe, num_steps=S1, upsample_steps=S2, feature_loss=True)))
+    oracles = []
+    for s in oracle_seeds:
+        o, _, cfg = build_pair(L=levels, D=64, C_=C_, bound=bound, grid_scale=1.0, log2_T=log2_T)
+        o = O.OracleModel(cfg, params=o.params, half_sim=half_sim, device=oracle_device)
+        oracles.append((s, o, {k: [torch.zeros_like(v), torch.zeros_like(v), 0] for k, v in o.params.items()}))
     np.random.seed(0); random.seed(0)
     lh, lo = [], []
-    for it in range(STEPS):
-        lr = 5e-3 * 0.5 ** (it // 250)       # StepLR of scripts/train.py:70-75 compressed to this run length
+    sched = lambda it: 5e-3 * (1.0 if it < 0.6 * steps else (0.5 if it < 0.8 * steps else 0.25))   # StepLR of scripts/train.py:70-75, compressed
+    for it in range(steps):
+        lr = sched(it)
         b = ds._next_train()
         bt = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()}
         dev = {k: v.cuda().float().contiguous() for k, v in bt.items() if k != 'semantic'}
         dev['semantic'] = bt['semantic'].int().cuda()
-        eng.lr = eng2.lr = lr
-        eng.step(dev, seed=7, step=it)
-        eng2.step(dev, seed=8, step=it)
-        noise = torch.from_numpy(O.rand_uniform(7, O.STREAM_PERTURB, it, np.arange(B * S1))).view(B, S1)
-        u = torch.from_numpy(O.rand_uniform(7, O.STREAM_PDF, it, np.arange(B * S2))).view(B, S2)
-        out = oracle.run(bt['rays_o'], bt['rays_d'], bt['direction_norms'], S1, S2, perturb=True, noise_coarse=noise, u_fine=u)
-        loss, _ = O.loss_fn(out, {'pixels': bt['pixels'], 'depth': bt['depth'], 'semantic': bt['semantic'], 'features': bt['features'].float()},
-                            feature_loss=True)
-        for p in oracle.params.values():
-            p.grad = None
-        loss.backward()
-        with torch.no_grad():
-            for k, p in oracle.params.items():
-                if p.grad is None:
-                    continue
-                st[k][2] += 1
-                O.adam_update(p, p.grad, st[k][0], st[k][1], st[k][2], lr, weight_decay=0.0 if k == 'grid' else 1e-6)
-        if it % 50 == 49:
-            lh.append(eng.terms[4].item()); lo.append(loss.item())
-    assert eng.state_i[0].item() == STEPS, 'no step may be skipped by the loss scaler in this run'
+        for s, pipe, eng in hips:
+            eng.lr = lr
+            eng.step(dev, seed=s, step=it)
+        od = oracle_device
+        ob = {'pixels': bt['pixels'].to(od), 'depth': bt['depth'].to(od), 'semantic': bt['semantic'].to(od), 'features': bt['features'].float().to(od)}
+        ro, rd, dn = bt['rays_o'].to(od), bt['rays_d'].to(od), bt['direction_norms'].to(od)
+        for s, oracle, st in oracles:
+            noise = torch.from_numpy(O.rand_uniform(s, O.STREAM_PERTURB, it, np.arange(B * S1))).view(B, S1).to(od)
+            u = torch.from_numpy(O.rand_uniform(s, O.STREAM_PDF, it, np.arange(B * S2))).view(B, S2).to(od)
+            out = oracle.run(ro, rd, dn, S1, S2, perturb=True, noise_coarse=noise, u_fine=u)
+            loss, _ = O.loss_fn(out, ob, feature_loss=True)
+            for p in oracle.params.values():
+                p.grad = None
+            loss.backward()
+            with torch.no_grad():
+                for k, p in oracle.params.items():
+                    if p.grad is None:
+                        continue
+                    st[k][2] += 1
+                    O.adam_update(p, p.grad, st[k][0], st[k][1], st[k][2], lr, weight_decay=0.0 if k == 'grid' else 1e-6)
+        if it % 100 == 99:
+            lh.append(hips[0][2].terms[4].item()); lo.append(loss.item())
+    for s, pipe, eng in hips:
+        assert eng.state_i[0].item() == steps, 'no step may be skipped by the loss scaler in this run'
+    test_h = _Frames(ds_test, list(range(len(held))), 'cuda')
+    test_o = _Frames(ds_test, list(range(len(held))), oracle_device)
+    q_h = [dict(heldout_metrics(pipe_renderer(pipe, num_steps=96, upsample_steps=0), test_h, C_), seed=s) for s, pipe, _ in hips]
 
-    def oracle_render(ro, rd, dn):
-        with torch.no_grad():
-            return oracle.run(ro, rd, dn.reshape(-1, 1), 64, 0, perturb=False)
-    q_h = heldout_metrics(pipe_renderer(pipe, num_steps=64, upsample_steps=0), _Frames(ds_test, list(range(len(held))), 'cuda'), C_)
-    q_h2 = heldout_metrics(pipe_renderer(pipe2, num_steps=64, upsample_steps=0), _Frames(ds_test, list(range(len(held))), 'cuda'), C_)
-    q_o = heldout_metrics(oracle_render, _Frames(ds_test, list(range(len(held))), 'cpu'), C_)
-    rec = {'steps': STEPS, 'batch': B, 'samples': [S1, S2], 'scene': 'S1 room, 30 frames 64x48, 4 held out, labels on every 2nd frame, 16-d features',
-           'model': 'hg+freq L=8 T=2^14, D=64', 'lr': '5e-3 halved every 250 steps', 'hip': q_h, 'oracle_half_sim': q_o,
-           'hip_other_noise_seed': q_h2,
-           'run_to_run': {'psnr_db': abs(q_h['psnr_db'] - q_h2['psnr_db']), 'miou_pt': 100 * abs(q_h['miou'] - q_h2['miou']),
-                          'note': 'two HIP runs, same batches, different sample-noise seed: the spread any single comparison carries'}, 'loss_hip_every_50': lh, 'loss_oracle_every_50': lo,
-           'delta_psnr_db': q_h['psnr_db'] - q_o['psnr_db'], 'delta_miou_pt': 100 * (q_h['miou'] - q_o['miou']),
-           'delta_depth_l1_m': q_h['depth_l1_m'] - q_o['depth_l1_m']}
+    def oracle_render(oracle):
+        def render(ro, rd, dn):
+            with torch.no_grad():
+                parts = [oracle.run(ro[a:a + 2048], rd[a:a + 2048], dn[a:a + 2048].reshape(-1, 1), 96, 0, perturb=False) for a in range(0, ro.shape[0], 2048)]
+                return {k: torch.cat([p[k] for p in parts]) for k in ('image', 'depth', 'semantic')}
+        return render
+    q_o = [dict(heldout_metrics(oracle_render(o), test_o, C_), seed=s) for s, o, _ in oracles]
+    mean = lambda qs, k: float(np.mean([q[k] for q in qs]))
+    rec = {'steps': steps, 'batch': B, 'samples': [S1, S2],
+           'scene': f'S1 room, {n_frames} frames {w}x{h}, {len(held)} held out, labels on every 2nd frame, 16-d features',
+           'model': f'hg+freq L={levels} T=2^{log2_T}, D=64', 'lr': '5e-3, halved at 60 % and 80 % of the steps',
+           'oracle': ('half_sim' if half_sim else 'fp32') + f' on {oracle_device}', 'hip': q_h, 'oracle_runs': q_o,
+           'mean_hip': {k: mean(q_h, k) for k in ('psnr_db', 'depth_l1_m', 'miou')},
+           'mean_oracle': {k: mean(q_o, k) for k in ('psnr_db', 'depth_l1_m', 'miou')},
+           'spread_hip_psnr_db': float(np.ptp([q['psnr_db'] for q in q_h])), 'spread_oracle_psnr_db': float(np.ptp([q['psnr_db'] for q in q_o])),
+           'loss_hip_every_100': lh, 'loss_oracle_every_100': lo}
+    rec['delta_psnr_db'] = rec['mean_hip']['psnr_db'] - rec['mean_oracle']['psnr_db']
+    rec['delta_miou_pt'] = 100 * (rec['mean_hip']['miou'] - rec['mean_oracle']['miou'])
+    rec['delta_depth_l1_m'] = rec['mean_hip']['depth_l1_m'] - rec['mean_oracle']['depth_l1_m']
+    return rec
+
+
+def test_hip_training_matches_the_quality_of_the_oracle_on_means_over_seeds():
+    rec = run_gate(**GATE)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'quality_gate.json'), 'w') as f:
         json.dump(rec, f, indent=1)
-    print(json.dumps(rec))
-    assert lo[-1] < 0.5 * lo[0] and lh[-1] < 0.5 * lh[0], 'both runs must have trained'
-    # +-0.2 dB PSNR, +-0.5 pt mIoU -- widened to the measured run-to-run spread of this short run when that is
-    # larger (two HIP runs that differ only in the sample noise); the better of the two HIP runs is what parity is about:
-    # a systematic deficit of the fp16 path would show in both
-    best_psnr, best_miou = max(q_h['psnr_db'], q_h2['psnr_db']), max(q_h['miou'], q_h2['miou'])
-    assert best_psnr > q_o['psnr_db'] - max(0.2, rec['run_to_run']['psnr_db']), rec
-    assert 100 * best_miou > 100 * q_o['miou'] - max(0.5, rec['run_to_run']['miou_pt']), rec
-    assert min(q_h['depth_l1_m'], q_h2['depth_l1_m']) < q_o['depth_l1_m'] + 0.02, rec
+    print(json.dumps({k: v for k, v in rec.items() if not k.startswith('loss_')}))
+    lh, lo = rec['loss_hip_every_100'], rec['loss_oracle_every_100']
+    assert lo[-1] < 0.5 * lo[0] and lh[-1] < 0.5 * lh[0], 'both sides must have trained'
+    assert rec['mean_oracle']['psnr_db'] >= MIN_ORACLE_PSNR_DB, 'the gate only discriminates on a trained field'
+    # SURVEY 8(d), as written: means over the seeds, +-0.2 dB PSNR, +-0.5 pt mIoU (a HIP side that is BETTER by more than the
+    # tolerance is not a parity failure of the hot path: the bound is one-sided there, the number is in the record)
+    assert rec['delta_psnr_db'] >= -TOL_PSNR_DB, rec
+    assert rec['delta_miou_pt'] >= -TOL_MIOU_PT, rec
+    assert rec['delta_depth_l1_m'] <= 0.01, rec
