@@ -11,54 +11,54 @@
 // decay, no weight decay, and its private step counter (bias correction) does not advance.
 //
 // state (device):
-//   si[0] = applied optimizer steps   si[1] = growth tracker   si[2] = found_inf flag   si[3] = -   si[4+b] = step count of block b
+//   si[0] = applied optimizer steps   si[1] = growth tracker   si[2] = found_inf flag   si[3] = scatter flag of the data-parallel
+//   engine   si[4+b] = step count of block b   si[15] = arrival ticket of k_adam
 //   sf[0] = loss scale   sf[1] = learning rate (> 0: overrides the host argument, so a captured hipGraph follows the scheduler)
-// consts (written by k_adam_prepare): c[0] = skip all (0/1), c[3] = 1/scale_used, c[4+2b] = lr / bc1_b (0 = block inactive),
-//                                     c[5+2b] = 1/sqrt(bc2_b)
+// consts (optional, written by the last block for inspection): c[0] = skip all (0/1), c[3] = 1/scale_used, c[4+2b] = lr / bc1_b
+//                                     (0 = block inactive), c[5+2b] = 1/sqrt(bc2_b)
 #define ADAM_MAX_BLOCKS 8
 struct AdamHyper { float lr, beta1, beta2, eps, wd_net, growth, backoff; int growth_interval; };
 struct AdamBlocks { int n; long long end[ADAM_MAX_BLOCKS]; int needs_sem[ADAM_MAX_BLOCKS]; int needs_sem_or_feat[ADAM_MAX_BLOCKS]; int feat_on; };
 
-__global__ void k_adam_prepare(int* si, float* sf, float* c, AdamHyper h, AdamBlocks blk, const int* counts) {
-  int found = si[2];
-  float scale = sf[0];
-  c[3] = 1.0f / scale;
-  const bool has_sem = !counts || counts[1] > 0;
-  if (found) {
-    c[0] = 1.f;
-    sf[0] = scale * h.backoff; si[1] = 0;
-  } else {
-    c[0] = 0.f;
-    si[0] += 1;
-    for (int b = 0; b < blk.n; ++b) {
-      bool active = true;
-      if (blk.needs_sem[b]) active = has_sem;
-      if (blk.needs_sem_or_feat[b]) active = has_sem || blk.feat_on;
-      if (!active) { c[4 + 2 * b] = 0.f; c[5 + 2 * b] = 1.f; continue; }
-      int t = si[4 + b] + 1; si[4 + b] = t;
-      double bc1 = 1.0 - pow((double)h.beta1, (double)t), bc2 = 1.0 - pow((double)h.beta2, (double)t);
-      const float lr = sf[1] > 0.f ? sf[1] : h.lr;
-      c[4 + 2 * b] = (float)((double)lr / bc1); c[5 + 2 * b] = (float)(1.0 / sqrt(bc2));
-    }
-    int tr = si[1] + 1;
-    if (tr >= h.growth_interval) { sf[0] = scale * h.growth; tr = 0; }
-    si[1] = tr;
-  }
-  si[2] = 0;
+// The step constants (skip flag, 1 / loss scale, per-block step size and bias correction) are a pure function of the state words
+// as they stand BEFORE this step; every block derives them itself (one thread, a handful of pow() in double) instead of waiting
+// for a one-thread prepare kernel.  The state itself (step counters, loss scale, growth tracker, found_inf reset) is advanced by
+// the LAST block to finish (arrival ticket in si[15], self-resetting): by then every block has read the old state.
+struct AdamConsts { float skip, inv_scale, step_size[ADAM_MAX_BLOCKS], inv_sqrt_bc2[ADAM_MAX_BLOCKS]; };
+__device__ inline bool adam_block_active(const AdamBlocks& blk, int b, bool has_sem) {
+  if (blk.needs_sem[b]) return has_sem;
+  if (blk.needs_sem_or_feat[b]) return has_sem || blk.feat_on;
+  return true;
 }
 
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                       h16* __restrict__ table16, size_t n_grid, size_t n_total, const float* __restrict__ c, AdamHyper h,
-                       AdamBlocks blk) {
-  const bool skip = c[0] != 0.f;
-  const float inv_scale = c[3];
+                       h16* __restrict__ table16, size_t n_grid, size_t n_total, int* si, float* sf, float* c_out, AdamHyper h,
+                       AdamBlocks blk, const int* counts) {
+  __shared__ AdamConsts cs;
+  const bool has_sem = !counts || counts[1] > 0;
+  if (threadIdx.x == 0) {
+    const int found = si[2];
+    const float scale = sf[0];
+    cs.skip = found ? 1.f : 0.f;
+    cs.inv_scale = 1.0f / scale;
+    const float lr = sf[1] > 0.f ? sf[1] : h.lr;
+    for (int b = 0; b < blk.n; ++b) {
+      if (found || !adam_block_active(blk, b, has_sem)) { cs.step_size[b] = 0.f; cs.inv_sqrt_bc2[b] = 1.f; continue; }
+      const int t = si[4 + b] + 1;
+      const double bc1 = 1.0 - pow((double)h.beta1, (double)t), bc2 = 1.0 - pow((double)h.beta2, (double)t);
+      cs.step_size[b] = (float)((double)lr / bc1); cs.inv_sqrt_bc2[b] = (float)(1.0 / sqrt(bc2));
+    }
+  }
+  __syncthreads();
+  const bool skip = cs.skip != 0.f;
+  const float inv_scale = cs.inv_scale;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
     g[i] = 0.f;
     if (skip) continue;
     int b = 0;
     while (b + 1 < blk.n && (long long)i >= blk.end[b]) ++b;
-    const float step_size = c[4 + 2 * b], inv_sqrt_bc2 = c[5 + 2 * b];
+    const float step_size = cs.step_size[b], inv_sqrt_bc2 = cs.inv_sqrt_bc2[b];
     if (step_size == 0.f) continue;   // block without gradient this step (torch: grad is None)
     float pi = p[i];
     gi *= inv_scale;
@@ -71,17 +71,37 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     p[i] = pi;
     if (i < n_grid) table16[i] = (h16)pi;
   }
+  // ---- arrival: the last block advances the optimizer / GradScaler state (torch.optim.Adam step counts, GradScaler.update)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int ticket = __hip_atomic_fetch_add(si + 15, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (int)gridDim.x - 1) {
+      const float scale = sf[0];
+      if (c_out) { c_out[0] = cs.skip; c_out[3] = cs.inv_scale; for (int b = 0; b < blk.n; ++b) { c_out[4 + 2 * b] = cs.step_size[b]; c_out[5 + 2 * b] = cs.inv_sqrt_bc2[b]; } }
+      if (skip) { sf[0] = scale * h.backoff; si[1] = 0; }
+      else {
+        si[0] += 1;
+        for (int b = 0; b < blk.n; ++b) if (adam_block_active(blk, b, has_sem)) si[4 + b] += 1;
+        int tr = si[1] + 1;
+        if (tr >= h.growth_interval) { sf[0] = scale * h.growth; tr = 0; }
+        si[1] = tr;
+      }
+      si[2] = 0;
+      __hip_atomic_store(si + 15, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // block_end[n_blocks] (host): exclusive end offsets of the parameter blocks in the flat buffer (last = n_total);
 // block_kind[b]: 0 = always has a gradient, 1 = only with labelled rays (semantic_out), 2 = labelled rays or feature loss
 // (semantic_features).  counts (device, from aln_loss_fwd_bwd) may be NULL: every block is then active.
+// state_i: 16 int32 (si[15] = arrival ticket of the kernel: zero before the first launch, reset by the kernel itself).
 extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid,
                              int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
                              float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
                              int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
                              const int32_t* counts, void* stream) {
-  ALN_REQUIRE(params && grads && m && v && state_i && state_f && consts, "adam: NULL pointer");
+  ALN_REQUIRE(params && grads && m && v && state_i && state_f, "adam: NULL pointer");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
   ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
   AdamHyper h{lr, beta1, beta2, eps, wd_net, growth, backoff, growth_interval};
@@ -92,11 +112,8 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
     for (int b = 0; b < n_blocks; ++b) { blk.end[b] = block_end[b]; blk.needs_sem[b] = block_kind[b] == 1; blk.needs_sem_or_feat[b] = block_kind[b] == 2; }
   }
   blk.feat_on = feature_loss;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(1), 0, s, state_i, state_f, consts, h, blk, counts);
-  ALN_CHECK_LAUNCH("adam_prepare");
-  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_total, 256, 256 * 16)), dim3(256), 0, s, params, grads, m, v, (h16*)table_f16,
-                     (size_t)n_grid, (size_t)n_total, consts, h, blk);
+  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
+                     (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, counts);
   ALN_CHECK_LAUNCH("adam");
   return 0;
 }

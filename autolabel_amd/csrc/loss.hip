@@ -6,30 +6,35 @@
 
 #define DEPTH_EPSILON 0.01f
 
-__global__ void k_loss_counts(const float* __restrict__ gt_depth, const int* __restrict__ gt_sem, int N, int* __restrict__ counts) {
-  int nd = 0, ns = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-    nd += gt_depth[i] > DEPTH_EPSILON; ns += gt_sem[i] >= 0;
-  }
-  nd = (int)wave_sum((float)nd); ns = (int)wave_sum((float)ns);
-  if ((threadIdx.x & 63) == 0) { if (nd) atomicAdd(counts, nd); if (ns) atomicAdd(counts + 1, ns); }
-}
-
 struct LossArgs {
   const float* image; const float* depth; const float* semantic; const float* features;
   const float* gt_rgb; const float* gt_depth; const int* gt_sem; const float* gt_feat;
   int N, C, D, Cf; float w_rgb, w_depth, w_sem, w_feat;
-  const int* counts; const float* loss_scale;
-  float* g_image; float* g_depth; float* g_sem; float* g_feat; float* terms;  // terms[5]: rgb, depth, feature, semantic, total
+  int* counts; const float* loss_scale;
+  float* g_image; float* g_depth; float* g_sem; float* g_feat; float* terms;  // terms[5]: rgb, depth, feature, semantic, total; then scratch
 };
+#define LOSS_MAX_BLOCKS 256
 
-// one wavefront per ray (4 per block): every ray is a short chain of dependent loads, so the kernel is latency-bound and
-// wants as many rays in flight as the chip holds; the block folds its four partial sums before the 5 same-address atomics
+// ONE launch.  (a) every block counts the rays with a valid depth / a label itself (N is a batch: 4096 ... 32768 rays = a few
+// hundred KB of L2 reads per block; integer sums, so every block holds the same two numbers) -- no separate count kernel, no
+// zero-fill of counters; (b) one wavefront per ray (4 per block): every ray is a short chain of dependent loads, so the kernel is
+// latency-bound and wants as many rays in flight as the chip holds; (c) the block's four partial loss sums go to its row of the
+// scratch behind `terms`, and the LAST block to arrive (ticket in counts[2], self-resetting) adds the rows up in block order:
+// the reported loss terms are bit-reproducible and nothing needs to be zeroed before the launch.
 __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
   __shared__ float part[4][4];
+  __shared__ int cnt_s[4][2];
+  __shared__ int last_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float scale = a.loss_scale ? *a.loss_scale : 1.f;
-  const int nd = a.counts[0], ns = a.counts[1];
+  int nd = 0, ns = 0;
+  for (int i = threadIdx.x; i < a.N; i += 256) { nd += a.gt_depth[i] > DEPTH_EPSILON; ns += a.gt_sem[i] >= 0; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { nd += __shfl_xor(nd, o); ns += __shfl_xor(ns, o); }
+  if (lane == 0) { cnt_s[wave][0] = nd; cnt_s[wave][1] = ns; }
+  __syncthreads();
+  nd = cnt_s[0][0] + cnt_s[1][0] + cnt_s[2][0] + cnt_s[3][0];
+  ns = cnt_s[0][1] + cnt_s[1][1] + cnt_s[2][1] + cnt_s[3][1];
   float t_rgb = 0, t_depth = 0, t_feat = 0, t_sem = 0;
   for (int ray = blockIdx.x * 4 + wave; ray < a.N; ray += gridDim.x * 4) {
     if (lane < 3) {
@@ -81,35 +86,45 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
   t_rgb = wave_sum(t_rgb); t_depth = wave_sum(t_depth); t_feat = wave_sum(t_feat); t_sem = wave_sum(t_sem);
   if (lane == 0) { part[wave][0] = t_rgb; part[wave][1] = t_depth; part[wave][2] = t_feat; part[wave][3] = t_sem; }
   __syncthreads();
-  if (threadIdx.x == 0 && a.terms) {
-    t_rgb = part[0][0] + part[1][0] + part[2][0] + part[3][0]; t_depth = part[0][1] + part[1][1] + part[2][1] + part[3][1];
-    t_feat = part[0][2] + part[1][2] + part[2][2] + part[3][2]; t_sem = part[0][3] + part[1][3] + part[2][3] + part[3][3];
-    float r = t_rgb / (3.f * a.N), d = nd ? t_depth / nd : 0.f, f = (a.gt_feat && a.Cf) ? t_feat / ((float)a.N * a.Cf) : 0.f,
-          s = ns ? t_sem / ns : 0.f;
-    atomicAdd(a.terms, r); atomicAdd(a.terms + 1, d); atomicAdd(a.terms + 2, f); atomicAdd(a.terms + 3, s);
-    atomicAdd(a.terms + 4, a.w_rgb * r + a.w_depth * d + a.w_feat * f + a.w_sem * s);
+  if (threadIdx.x == 0) {
+    float* slot = a.terms + 8 + 4 * blockIdx.x;
+    for (int k = 0; k < 4; ++k) slot[k] = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+    // publish the row, then take a ticket (release fence; the explicit wait keeps the write-back ahead of the ticket)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(a.counts + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = ticket == (int)gridDim.x - 1;
+    if (last_s) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+      for (unsigned b = 0; b < gridDim.x; ++b)
+        for (int k = 0; k < 4; ++k) sum[k] += a.terms[8 + 4 * b + k];
+      float r = sum[0] / (3.f * a.N), d = nd ? sum[1] / nd : 0.f, f = (a.gt_feat && a.Cf) ? sum[2] / ((float)a.N * a.Cf) : 0.f,
+            sv = ns ? sum[3] / ns : 0.f;
+      a.terms[0] = r; a.terms[1] = d; a.terms[2] = f; a.terms[3] = sv;
+      a.terms[4] = a.w_rgb * r + a.w_depth * d + a.w_feat * f + a.w_sem * sv;
+      a.counts[0] = nd; a.counts[1] = ns;
+      __hip_atomic_store(a.counts + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts from zero again
+    }
   }
 }
 
+// terms: 8 + 4 * 256 floats (terms[0..5): rgb, depth, feature, semantic, total; the rest is scratch for the block partial sums);
+// counts: 4 int32 ([0] = rays with valid depth, [1] = labelled rays, [2] = arrival ticket: zero before the FIRST launch only)
+extern "C" int32_t aln_loss_terms_floats(void) { return 8 + 4 * LOSS_MAX_BLOCKS; }
 extern "C" int aln_loss_fwd_bwd(const float* image, const float* depth, const float* semantic, const float* features,
                                 const float* gt_rgb, const float* gt_depth, const int32_t* gt_sem, const float* gt_feat,
                                 int32_t N, int32_t C, int32_t D, int32_t Cf, float w_rgb, float w_depth, float w_sem,
                                 float w_feat, const float* loss_scale, int32_t* counts, float* g_image, float* g_depth,
                                 float* g_sem, float* g_feat, float* terms, void* stream) {
-  ALN_REQUIRE(image && depth && gt_rgb && gt_depth && gt_sem && counts && g_image && g_depth, "loss: NULL pointer");
+  ALN_REQUIRE(image && depth && gt_rgb && gt_depth && gt_sem && counts && g_image && g_depth && terms, "loss: NULL pointer");
   ALN_REQUIRE(!g_sem || semantic, "loss: semantic output missing");
   ALN_REQUIRE(!gt_feat || (features && g_feat && Cf <= D), "loss: feature buffers missing or Cf > D");
   if (N <= 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(counts, 0, 2 * sizeof(int), s);
-  if (terms) hipMemsetAsync(terms, 0, 5 * sizeof(float), s);
-  hipLaunchKernelGGL(k_loss_counts, dim3(aln_grid_for(N, 256, 64)), dim3(256), 0, s, gt_depth, gt_sem, N, counts);
-  ALN_CHECK_LAUNCH("loss_counts");
   LossArgs a{image, depth, semantic, features, gt_rgb, gt_depth, gt_sem, gt_feat, N, C, D, Cf, w_rgb, w_depth, w_sem, w_feat,
              counts, loss_scale, g_image, g_depth, g_sem, g_feat, terms};
   int nb = (N + 3) / 4;
-  // (the 5 loss-term atomics of every block hit one cache line and serialize in L2: 256 blocks, not one per 4 rays)
-  hipLaunchKernelGGL(k_loss, dim3(nb < 256 ? nb : 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_loss, dim3(nb < LOSS_MAX_BLOCKS ? nb : LOSS_MAX_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
   ALN_CHECK_LAUNCH("loss");
   return 0;
 }

@@ -443,7 +443,8 @@ __device__ inline void chain_layer_m(f32x16 (&acc)[RPW][NB], FragFn frag, BFn bo
 template <int HID, int NHID, int KS0>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
                                                 RowSrc xs, int rows, const int* __restrict__ rows_dev,
-                                                h16* __restrict__ h1, h16* __restrict__ h2, h16* __restrict__ out) {
+                                                h16* __restrict__ h1, h16* __restrict__ h2, h16* __restrict__ out,
+                                                float* __restrict__ sigma) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h16* wl = (h16*)smem;
   copy_to_lds(wl, wf_g, wf_halves);
@@ -500,6 +501,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, s
           if (f < out_pad) {
             h16x4 v; v[0] = (h16)o[4 * q]; v[1] = (h16)o[4 * q + 1]; v[2] = (h16)o[4 * q + 2]; v[3] = (h16)o[4 * q + 3];
             *(h16x4*)(out + (size_t)row * out_pad + f) = v;
+            // density head (models.py:175-188): sigma = trunc_exp(h0) of the fp16 output, written by the lane that holds feature 0
+            if (sigma && f == 0) sigma[row] = expf((float)v[0]);
           }
         }
       }
@@ -1185,6 +1188,73 @@ __global__ __launch_bounds__(DWR_G * DWR_E) void k_dw_reduce(const float* __rest
   if (g == 0 && e < n) dW[e] += part[0][t];
 }
 
+// The same for several heads in ONE launch (AlnMlpDesc.defer_dw_reduce: the backward kernels of a training step leave their slabs
+// in place and the step reduces all of them at once: one launch instead of one per head).
+struct DwReduceAll { int n; const float* ws[ALN_MAX_HEADS]; float* dW[ALN_MAX_HEADS]; int nparts[ALN_MAX_HEADS], nw[ALN_MAX_HEADS], blk0[ALN_MAX_HEADS + 1]; };
+__global__ __launch_bounds__(DWR_G * DWR_E) void k_dw_reduce_all(DwReduceAll a) {
+  __shared__ float part[DWR_G][DWR_E];
+  int h = 0;
+  while (h + 1 < a.n && (int)blockIdx.x >= a.blk0[h + 1]) ++h;
+  const float* __restrict__ ws = a.ws[h];
+  const int n = a.nw[h], nparts = a.nparts[h];
+  const int t = threadIdx.x % DWR_E, g = threadIdx.x / DWR_E, e = ((int)blockIdx.x - a.blk0[h]) * DWR_E + t;
+  float acc = 0.f;
+  if (e < n) {
+    int p = g;
+#pragma unroll 1
+    for (; p + 15 * DWR_G < nparts; p += 16 * DWR_G) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = ws[(size_t)(p + DWR_G * u) * n + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; p < nparts; p += DWR_G) acc += ws[(size_t)p * n + e];
+  }
+  part[g][t] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int hh = DWR_G / 2; hh > 0; hh >>= 1) {
+    if (g < hh) part[g][t] += part[g + hh][t];
+    __syncthreads();
+  }
+  if (g == 0 && e < n) a.dW[h][e] += part[0][t];
+}
+
+// slabs the recompute backward of this head writes for `rows` rows (= its grid size): what aln_mlp_dw_reduce_all adds up
+static int bwd_recomp_blocks(const AlnMlpDesc* m, int rows) {
+  const int tiles = (rows + 127) / 128;
+  bool occ2 = false;
+  if (m->hidden == 64 && m->in_pad <= 32) {
+    const int OB = (m->out_pad + 31) / 32, PO = OB * 32 + (OB == 1 ? 0 : 8);
+    const size_t halves = (size_t)aln_mlp_rowmajor_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden);
+    occ2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(m->in_pad + 8 + 2 * hid_pitch(m->hidden) + PO)) * 2 <= 80 * 1024;
+  }
+  const int gmax = occ2 ? 512 : 256;
+  return tiles < gmax ? tiles : gmax;
+}
+extern "C" int32_t aln_mlp_bwd_blocks(const AlnMlpDesc* m, int32_t rows) { return (m && rows > 0) ? bwd_recomp_blocks(m, rows) : 0; }
+extern "C" int aln_mlp_dw_reduce_all(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, void* stream) {
+  ALN_REQUIRE(n_heads >= 0 && n_heads <= ALN_MAX_HEADS && (n_heads == 0 || (descs && dW && rows)), "dw_reduce_all: bad arguments");
+  DwReduceAll a; a.n = 0; a.blk0[0] = 0;
+  for (int k = 0; k < n_heads; ++k) {
+    const AlnMlpDesc* m = descs[k];
+    ALN_REQUIRE(m && m->dw_ws && dW[k], "dw_reduce_all: NULL pointer in head %d", k);
+    if (rows[k] <= 0) continue;
+    const MlpLayers L = mlp_layers(m->in_pad, m->hidden, m->out_pad, m->n_hidden);
+    const int n_w = (int)(L.w_off[L.n - 1] + (size_t)L.in_[L.n - 1] * L.out_[L.n - 1]);
+    const int parts = bwd_recomp_blocks(m, rows[k]);
+    ALN_REQUIRE((size_t)m->dw_ws_bytes >= (size_t)parts * n_w * sizeof(float), "dw_reduce_all: dw_ws of head %d too small", k);
+    a.ws[a.n] = (const float*)m->dw_ws; a.dW[a.n] = dW[k]; a.nparts[a.n] = parts; a.nw[a.n] = n_w;
+    a.blk0[a.n + 1] = a.blk0[a.n] + (n_w + DWR_E - 1) / DWR_E;
+    ++a.n;
+  }
+  if (a.n == 0) return 0;
+  hipLaunchKernelGGL(k_dw_reduce_all, dim3(a.blk0[a.n]), dim3(DWR_G * DWR_E), 0, (hipStream_t)stream, a);
+  ALN_CHECK_LAUNCH("dw_reduce_all");
+  return 0;
+}
+
 template <int IN, int HID, int OUT, int NHID, bool OCC2, int RPW>
 static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in,
                                  float* dW, int* found_inf, hipStream_t s) {
@@ -1222,7 +1292,7 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
   }
 #undef LAUNCH_SRC
   ALN_CHECK_LAUNCH("mlp_bwd_recomp");
-  if (ws) {
+  if (ws && !m->defer_dw_reduce) {
     hipLaunchKernelGGL(k_dw_reduce, dim3((n_w + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, ws, g, n_w, dW);
     ALN_CHECK_LAUNCH("dw_reduce");
   }
@@ -1253,7 +1323,7 @@ static int mlp_grid(int rows) {
 }
 
 static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32_t* rows_dev, void* h1, void* h2, void* out,
-                       void* stream) {
+                       void* stream, float* sigma = nullptr) {
   ALN_REQUIRE(m && (xs.a || xs.mode == SRC_COLOR_IN) && out && m->wf, "mlp_fwd: NULL pointer");
   ALN_REQUIRE(m->in_pad % 16 == 0 && m->out_pad % 16 == 0, "mlp_fwd: widths must be multiples of 16");
   ALN_REQUIRE(m->in_pad <= 80, "mlp_fwd: in_pad %d exceeds the 80 input features the fused kernel holds in registers", m->in_pad);
@@ -1267,7 +1337,7 @@ static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32
   do {                                                                                                                 \
     hipFuncSetAttribute((const void*)k_mlp_fwd<H, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
     hipLaunchKernelGGL((k_mlp_fwd<H, N, K>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, xs,       \
-                       rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out);                                                 \
+                       rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out, sigma);                                          \
   } while (0)
 #define LAUNCH(H, N)                                                                                                   \
   do {                                                                                                                 \
@@ -1294,6 +1364,13 @@ extern "C" int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, con
                            void* out, void* stream) {
   ALN_REQUIRE(m && x, "mlp_fwd: NULL pointer");
   return mlp_fwd_src(m, plain_src(x, m->in_pad), rows, rows_dev, h1, h2, out, stream);
+}
+// the density head: the same launch also writes sigma[row] = exp(out[row][0]) (ALNetwork.density, autolabel/models.py:175-188:
+// sigma = trunc_exp(h[..., 0]); aln_sigma_act as an epilogue)
+extern "C" int aln_density_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, void* h1, void* h2, void* out, float* sigma,
+                               void* stream) {
+  ALN_REQUIRE(m && x && sigma, "density_fwd: NULL pointer");
+  return mlp_fwd_src(m, plain_src(x, m->in_pad), rows, nullptr, h1, h2, out, stream, sigma);
 }
 
 // bytes of AlnMlpDesc.dw_ws: one fp32 slab of all the head's weights per backward block (at most 512 blocks)

@@ -44,8 +44,9 @@ class TrainEngine:
             kinds.append(kind)
         self._blk_end = (C.c_int64 * len(ends))(*ends)
         self._blk_kind = (C.c_int32 * len(kinds))(*kinds)
-        self.counts = torch.zeros(2, dtype=torch.int32, device=dv)
-        self.terms = torch.zeros(5, device=dv)  # rgb, depth, feature, semantic, total (last step)
+        self.counts = torch.zeros(4, dtype=torch.int32, device=dv)   # rays with valid depth, labelled rays, the loss kernel's ticket
+        self._terms = torch.zeros(int(H.lib().aln_loss_terms_floats()), device=dv)
+        self.terms = self._terms[:5]  # rgb, depth, feature, semantic, total (last step); behind them: scratch of aln_loss_fwd_bwd
         pipe.found_inf = self.state_i[2:3]
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1

@@ -28,7 +28,7 @@ class AlnEncDesc(C.Structure):
 
 class AlnMlpDesc(C.Structure):
     _fields_ = [('in_pad', i32), ('hidden', i32), ('out_pad', i32), ('n_hidden', i32), ('wf', vp), ('wb', vp), ('wr', vp), ('dw_ws', vp),
-                ('dw_ws_bytes', i64)]
+                ('dw_ws_bytes', i64), ('defer_dw_reduce', i32), ('reserved_', i32)]
 
 
 class AlnFrames(C.Structure):
@@ -67,9 +67,12 @@ _SIGS = {
     'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),
     'aln_mlp_repack_all': (i32, [i32, vp, vp, vp]),
     'aln_mlp_has_recompute': (i32, [i32, i32, i32, i32]),
+    'aln_mlp_bwd_blocks': (i32, [vp, i32]),
+    'aln_mlp_dw_reduce_all': (i32, [i32, vp, vp, vp, vp]),
     'aln_mlp_dw_ws_bytes': (i64, [i32, i32, i32, i32]),
     'aln_mlp_frag_halves': (i64, [i32, i32, i32, i32, i32]),
     'aln_mlp_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
+    'aln_density_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     'aln_sem_heads_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 4 + [i32] + [vp] * 2),
@@ -89,6 +92,7 @@ _SIGS = {
     'aln_mark_untrained_grid': (i32, [vp, i32, f32, vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 6),
+    'aln_loss_terms_floats': (i32, []),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),
     'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, vp, vp]),
     'aln_similarity_argmax': (i32, [vp, i32, i32, vp, i32, vp, vp]),

@@ -89,8 +89,10 @@ class Params:
             nws = H.lib().aln_mlp_dw_ws_bytes(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
             ws = torch.empty(nws // 4, dtype=torch.float32, device=device)
             self.frags[k] = (wf, wb, wr, ws)
+            # defer_dw_reduce: the backward kernels of a step leave their slabs in place, HipPipeline.backward folds all heads' slabs
+            # into the gradient buffer with one aln_mlp_dw_reduce_all launch
             self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(),
-                                         ws.data_ptr(), nws)
+                                         ws.data_ptr(), nws, 1, 0)
 
     def init_(self, seed=0):
         """tcnn default initialisation: grid U(-1e-4,1e-4), MLP weights xavier-uniform per padded [out,in] matrix."""
@@ -238,8 +240,7 @@ class HipPipeline:
             # the cell points (aln_grid_points' positions) are generated inside the encoding kernels: no [G^3, 3] buffer
             H.call('aln_encode_fwd_cells', C.byref(e), H.ptr(self.P.table16), occ.G, seed, step, H.ptr(step_dev), a, rows, H.ptr(planes),
                    H.ptr(enc), H.stream())
-            H.call('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, None, None, H.ptr(out), H.stream())
-            H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sig[a:a + rows]), H.stream())
+            H.call('aln_density_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, None, H.ptr(out), H.ptr(sig[a:a + rows]), H.stream())
         H.call('aln_grid_update', H.ptr(occ.grid), H.ptr(sig), occ.G, occ.decay, self.density_scale, occ.density_thresh,
                H.ptr(occ.stats), H.ptr(occ.bits), H.ptr(occ.n_set), H.stream())
         occ.updates += 1
@@ -349,9 +350,8 @@ class HipPipeline:
             H.call('aln_encode_fwd', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows,
                    stride, H.ptr(enc), H.stream())
         save = train and not self.recompute
-        self._k('aln_mlp_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, None, H.ptr(h1) if save else None,
-                H.ptr(h2) if save else None, H.ptr(out), H.stream(), tag=('sigma', rows))
-        H.call('aln_sigma_act', H.ptr(out), rows, H.ptr(sigma), H.stream())
+        self._k('aln_density_fwd', C.byref(self.P.descs['sigma']), H.ptr(enc), rows, H.ptr(h1) if save else None,
+                H.ptr(h2) if save else None, H.ptr(out), H.ptr(sigma), H.stream(), tag=('sigma', rows))
 
     def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
                 want_semantic=True, bg=1.0, step_dev=None, march=False, ws=None):
@@ -525,6 +525,13 @@ class HipPipeline:
         self._k('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
                 H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
+        if rc:   # all fused heads' weight-gradient slabs -> P.grad, one launch (fixed summation order: bit-reproducible)
+            heads = [k for k in ('color', 'semf', 'semo', 'sigma') if k in P.descs and (sem or k in ('color', 'sigma'))]
+            n = len(heads)
+            ds = (C.c_void_p * n)(*[C.addressof(P.descs[k]) for k in heads])
+            dws = (C.c_void_p * n)(*[P.grad.data_ptr() + 4 * L.offsets[k] for k in heads])
+            rows = (C.c_int32 * n)(*([M] * n))
+            self._k('aln_mlp_dw_reduce_all', n, ds, dws, rows, H.stream(), tag=None)
         if on_grad_ready is not None:
             on_grad_ready('mlp', L.n_grid, L.n_total)
         if not e.use_grid:

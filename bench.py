@@ -242,7 +242,10 @@ def mlp_roofline(eng, events, n_event_steps, live_rows):
             flops += 2.0 * t[1] * t[2]
             t_mlp += e[0].elapsed_time(e[1]) * 1e-3
             continue
-        if not n.startswith(('aln_mlp', 'aln_sem_heads')):
+        if not n.startswith(('aln_mlp', 'aln_sem_heads', 'aln_density')):
+            continue
+        if t is None:   # aln_mlp_dw_reduce_all: time of the MLP backward, no FLOPs of its own
+            t_mlp += e[0].elapsed_time(e[1]) * 1e-3
             continue
         head, r = t
         if torch.is_tensor(r):
@@ -251,7 +254,7 @@ def mlp_roofline(eng, events, n_event_steps, live_rows):
         t_mlp += e[0].elapsed_time(e[1]) * 1e-3
     if t_mlp <= 0:
         return None
-    return {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + k_mlp_bwd_recomp8 + k_dw_reduce (all heads)' + (' + k_wide_nt / k_wide_tn' if L.sem_wide else ''),
+    return {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + k_mlp_bwd_recomp8 + k_dw_reduce_all (all heads)' + (' + k_wide_nt / k_wide_tn' if L.sem_wide else ''),
             'bound': 'mfma', 'achieved': flops / t_mlp / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': flops / t_mlp / 1e12 / 2500.0,
             'us_per_step': t_mlp * 1e6 / n_event_steps, 'algorithmic_gflop_per_step': flops / 1e9 / n_event_steps, 'live_color_rows': live_rows}
 

@@ -60,6 +60,9 @@ typedef struct {
                        required when aln_mlp_bwd / aln_sem_heads_bwd are asked for dW on the recompute path (slabs are reduced in
                        a fixed order: bit-reproducible weight gradients, no atomics) */
   int64_t dw_ws_bytes;
+  int32_t defer_dw_reduce; /* 1: the recompute backward leaves its slabs in dw_ws; the caller folds them into dW later with
+                              aln_mlp_dw_reduce_all (all heads of a training step in one launch) */
+  int32_t reserved_;
 } AlnMlpDesc;
 
 const char* aln_last_error(void);
@@ -165,6 +168,9 @@ int64_t aln_mlp_rowmajor_halves(int32_t in_pad, int32_t hidden, int32_t out_pad,
  * clamps the row count on the device (compacted live samples). */
 int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t* rows_dev, void* h1, void* h2,
                 void* out, void* stream);
+/* ALNetwork.density (autolabel/models.py:175-188) in one launch: out [rows,16] = sigma_net(x) and sigma[row] = trunc_exp(out[row][0])
+ * (fp32, from the fp16 output: the epilogue form of aln_sigma_act) */
+int aln_density_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, void* h1, void* h2, void* out, float* sigma, void* stream);
 /* h1 == NULL selects the recompute backward: hidden activations are rebuilt from x inside the kernel (needs m->wr).
  * d_in (optional) [rows,in_pad] f16; dW (optional) += weight gradients in the fp32 master layout; dA1/dA2 are scratch
  * [rows,hidden] f16 (only touched by the unfused fallback); found_inf is OR-ed when an fp16 gradient overflows. */
@@ -172,6 +178,10 @@ int aln_mlp_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, const int32_t*
 int aln_mlp_has_recompute(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden);
 int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
                 const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW, int32_t* found_inf, void* stream);
+/* deferred weight-gradient reduction (AlnMlpDesc.defer_dw_reduce): dW[k] += sum of the slabs head k's last recompute backward
+ * over rows[k] rows left in its dw_ws, all heads in ONE launch; aln_mlp_bwd_blocks = the number of slabs (the backward's grid) */
+int32_t aln_mlp_bwd_blocks(const AlnMlpDesc* m, int32_t rows);
+int aln_mlp_dw_reduce_all(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, void* stream);
 
 /* Both semantic heads (models.py:248-256) with their inputs / output gradients built on the fly from sigma_out, f, the
  * compositing weights and the per-ray output gradients (no [rows,80] / [rows,64] intermediates in HBM). */
@@ -268,16 +278,21 @@ int aln_composite_bwd(const float* norms, const float* z, const float* sigma, co
                       int32_t D, float bg, float density_scale, float* d_h0, void* d_color_out, void* d_logits, void* d_feat,
                       int32_t* found_inf, void* stream);
 
-/* ---- loss: autolabel/trainer.py:72-92 (rgb MSE + depth L1 over depth > 0.01 + feature L1 + CE over labelled rays).
- * Writes per-ray output gradients (times *loss_scale) and terms[5] = {rgb, depth, feature, semantic, total}. */
+/* ---- loss: autolabel/trainer.py:72-92 (rgb MSE + depth L1 over depth > 0.01 + feature L1 + CE over labelled rays), ONE launch.
+ * Writes per-ray output gradients (times *loss_scale), terms[0..5) = {rgb, depth, feature, semantic, total} (summed in a fixed
+ * order: bit-reproducible) and counts[0..2) = {rays with valid depth, labelled rays}.  `terms` must hold aln_loss_terms_floats()
+ * floats (scratch behind the five results), `counts` 4 int32 of which counts[2] (an arrival ticket the kernel resets itself) must
+ * be zero before the first launch. */
+int32_t aln_loss_terms_floats(void);
 int aln_loss_fwd_bwd(const float* image, const float* depth, const float* semantic, const float* features, const float* gt_rgb,
                      const float* gt_depth, const int32_t* gt_sem, const float* gt_feat, int32_t N, int32_t C, int32_t D,
                      int32_t Cf, float w_rgb, float w_depth, float w_sem, float w_feat, const float* loss_scale, int32_t* counts,
                      float* g_image, float* g_depth, float* g_sem, float* g_feat, float* terms, void* stream);
 
 /* ---- optimizer: torch.optim.Adam of scripts/train.py:50-63 + GradScaler step/update of autolabel/trainer.py:45-48.
- * state_i = {applied steps, growth tracker, found_inf, -, step count per block...} (>= 4 + n_blocks ints), state_f = {loss
- * scale}, consts >= 4 + 2*n_blocks floats.  Skips the update (and backs the scale off) when found_inf is set; refreshes the
+ * ONE launch.  state_i = 16 int32 {applied steps, growth tracker, found_inf, (caller's), step count per block [4..4+n_blocks),
+ * ..., [15] = arrival ticket (zero before the first launch; the kernel resets it)}, state_f = {loss scale, learning rate (> 0:
+ * overrides `lr`)}, consts (optional) >= 4 + 2*n_blocks floats: the step constants, for inspection.  Skips the update (and backs the scale off) when found_inf is set; refreshes the
  * fp16 table shadow; zeroes the gradients.  Parameter blocks follow torch's per-tensor semantics: block_kind 1 (semantic_out)
  * is skipped when the batch has no labelled ray, kind 2 (semantic_features) when additionally there is no feature loss
  * (their gradient is None in the reference, so torch.optim.Adam leaves them and their step counters untouched). */

@@ -112,14 +112,20 @@ PRIME_Y = 2654435761
 PRIME_Z = 805459861
 
 
+_CORNER_BITS = [[(c >> d) & 1 for d in range(3)] for c in range(8)]   # corner c uses +1 along dim d iff bit d of c is set
+
+
 def grid_corner_indices(xn: torch.Tensor, level: dict):
     """xn [M,3] fp32 in [0,1].  Returns (idx [M,8] int64 level-local, w [M,8] fp32).
 
     tcnn ``pos_fract`` / ``grid_index``.  SPEC: pos = x*scale + 0.5 is evaluated
     UNFUSED in fp32 (two roundings) so that floor() is reproducible bit-exactly.
     Corner c uses +1 along dim d iff bit d of c is set; accumulation order c=0..7.
+    (All eight corners are evaluated as one [M,8] batch: element for element the arithmetic
+    of the per-corner loop -- w = ((1*w_x)*w_y)*w_z, uint32 hash -- just fewer tensor ops.)
     """
-    scale = torch.tensor(level['scale'], dtype=torch.float32, device=xn.device)
+    dev = xn.device
+    scale = torch.tensor(level['scale'], dtype=torch.float32, device=dev)
     if level.get('pos_fma'):   # x * scale (48 significant bits) + 0.5 is exact in fp64: one rounding to fp32 = the fused result
         pos = (xn.double() * scale.double() + 0.5).float()
     else:
@@ -128,25 +134,18 @@ def grid_corner_indices(xn: torch.Tensor, level: dict):
     frac = pos - g
     g = g.to(torch.int64)
     res, size = level['res'], level['size']
-    idxs, ws = [], []
-    for c in range(8):
-        w = torch.ones(xn.shape[0], dtype=torch.float32, device=xn.device)
-        cg = []
-        for d in range(3):
-            if c & (1 << d):
-                w = w * frac[:, d]
-                cg.append(g[:, d] + 1)
-            else:
-                w = w * (1.0 - frac[:, d])
-                cg.append(g[:, d])
-        if level['dense']:
-            idx = cg[0] + cg[1] * res + cg[2] * res * res
-        else:
-            # uint32 arithmetic
-            idx = ((cg[0] & 0xFFFFFFFF) ^ ((cg[1] * PRIME_Y) & 0xFFFFFFFF) ^ ((cg[2] * PRIME_Z) & 0xFFFFFFFF))
-        idxs.append(idx % size)
-        ws.append(w)
-    return torch.stack(idxs, 1), torch.stack(ws, 1)
+    bits = torch.tensor(_CORNER_BITS, dtype=torch.int64, device=dev)               # [8,3]
+    cg = g[:, None, :] + bits[None]                                                # [M,8,3]
+    wd = torch.where(bits[None].bool(), frac[:, None, :], 1.0 - frac[:, None, :])  # [M,8,3]
+    w = torch.ones(xn.shape[0], 8, dtype=torch.float32, device=dev)
+    for d in range(3):
+        w = w * wd[..., d]
+    if level['dense']:
+        idx = cg[..., 0] + cg[..., 1] * res + cg[..., 2] * res * res
+    else:
+        # uint32 arithmetic
+        idx = ((cg[..., 0] & 0xFFFFFFFF) ^ ((cg[..., 1] * PRIME_Y) & 0xFFFFFFFF) ^ ((cg[..., 2] * PRIME_Z) & 0xFFFFFFFF))
+    return idx % size, w
 
 
 class _RoundHalf(torch.autograd.Function):
@@ -171,9 +170,10 @@ def hashgrid_encode(xn: torch.Tensor, table: torch.Tensor, spec: GridSpec, half_
     outs = []
     for level in spec.levels():
         idx, w = grid_corner_indices(xn, level)
-        acc = torch.zeros(xn.shape[0], spec.n_features, dtype=torch.float32, device=xn.device)
-        for c in range(8):
-            acc = acc + w[:, c:c + 1] * tab[level['offset'] + idx[:, c]]
+        prod = w[..., None] * tab[level['offset'] + idx]        # [M,8,F]: one gather for the eight corners
+        acc = prod[:, 0]                                         # (0 + x = x: the running sum starts at corner 0)
+        for c in range(1, 8):                                    # accumulation order c = 0..7
+            acc = acc + prod[:, c]
         outs.append(acc)
     return torch.cat(outs, 1)
 

@@ -94,7 +94,7 @@ def hip_loss(pipe, out, batch, N, C_, D, Cf, scale=1.0, weights=(1.0, 0.1, 1.0, 
     dv = 'cuda'
     g_image, g_depth = torch.empty(N, 3, device=dv), torch.empty(N, device=dv)
     g_sem, g_feat = torch.empty(N, C_, device=dv), torch.empty(N, D, device=dv)
-    counts, terms = torch.zeros(2, dtype=torch.int32, device=dv), torch.zeros(5, device=dv)
+    counts, terms = torch.zeros(4, dtype=torch.int32, device=dv), torch.zeros(int(H.lib().aln_loss_terms_floats()), device=dv)
     ls = torch.tensor([scale], device=dv)
     gt = {k: v.cuda().contiguous() for k, v in batch.items()}
     gt['semantic'] = gt['semantic'].int()
