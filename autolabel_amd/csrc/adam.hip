@@ -33,7 +33,7 @@ __device__ inline bool adam_block_active(const AdamBlocks& blk, int b, bool has_
 
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        h16* __restrict__ table16, size_t n_grid, size_t n_total, int* si, float* sf, float* c_out, AdamHyper h,
-                       AdamBlocks blk, const int* counts) {
+                       AdamBlocks blk, const int* counts, uint32_t* step_dev) {
   __shared__ AdamConsts cs;
   const bool has_sem = !counts || counts[1] > 0;
   if (threadIdx.x == 0) {
@@ -87,6 +87,7 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
         si[1] = tr;
       }
       si[2] = 0;
+      if (step_dev) *step_dev += 1u;   // the device-resident step number the RNG-consuming kernels of a captured step add to theirs
       __hip_atomic_store(si + 15, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -100,7 +101,7 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
                              int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
                              float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
                              int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
-                             const int32_t* counts, void* stream) {
+                             const int32_t* counts, uint32_t* step_dev, void* stream) {
   ALN_REQUIRE(params && grads && m && v && state_i && state_f, "adam: NULL pointer");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
   ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
@@ -113,7 +114,7 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
   }
   blk.feat_on = feature_loss;
   hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
-                     (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, counts);
+                     (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, counts, step_dev);
   ALN_CHECK_LAUNCH("adam");
   return 0;
 }
@@ -127,6 +128,17 @@ extern "C" int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_cast_f16, dim3(aln_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, src, (h16*)dst, (size_t)n);
   ALN_CHECK_LAUNCH("cast_f16");
+  return 0;
+}
+
+__global__ void k_cast_f32(const h16* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+extern "C" int aln_cast_f32(const void* src_f16, float* dst, int64_t n, void* stream) {
+  ALN_REQUIRE(src_f16 && dst, "cast_f32: NULL pointer");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_cast_f32, dim3(aln_grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const h16*)src_f16, dst, (size_t)n);
+  ALN_CHECK_LAUNCH("cast_f32");
   return 0;
 }
 

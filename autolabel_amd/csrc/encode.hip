@@ -403,15 +403,17 @@ __device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
 
 __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   __shared__ uint2 sorted[BIN_CHUNK];                        // 32 KB
+  __shared__ uint32_t gws[8][BIN_TILE];                      // 16 KB: the rows' gradient words of eight levels (column = thread)
   __shared__ uint32_t cnt[2][BIN_MAX_SLICES], base[BIN_MAX_SLICES], total_s, vmax_s[2], shift_s;
   const EncParams& p = b.p;
   const int tid = threadIdx.x, lane = tid & 63;
   const int tile = blockIdx.x;
   const int row0 = tile * BIN_TILE;
   const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq;
-  // The row's gradient word of a level (fp16x2) is read straight from d_enc, one level ahead: its 64 grid bytes are one or two
-  // cache lines that stay in L1 / L2 over the 16 levels.  (Staging all levels of the tile in LDS first cost 32 KB per block and
-  // held the kernel at two blocks per CU; without it three fit -- the kernel is bound by LDS and barrier latency, not by loads.)
+  // The row's gradient words (fp16x2 per level) are fetched eight levels at a time -- 32 contiguous bytes of the row -- and parked
+  // in a thread-private LDS column.  (Round 2 read one word per level straight from d_enc "because the lines stay in L1 / L2":
+  // the PMC pass of round 3 says they do not -- FETCH_SIZE 679 MB per launch for 100 MB of d_enc, the 48 KB tiles of the ~100
+  // resident blocks of an XCD thrash its 4 MB L2 between two levels.  Staging all 16 levels at once costs 32 KB and a block per CU.)
   if (tid < 2 * BIN_MAX_SLICES) cnt[0][tid] = 0;
   if (tid < 2) vmax_s[tid] = 0u;
   const int row = row0 + tid;
@@ -420,13 +422,27 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   if (valid) bin_row_position(b, row, x);
   normalize_pos(x, p.e.bound, true, xn);
   const uint32_t* const grow = (const uint32_t*)(b.d_enc + (size_t)(valid ? row : 0) * pad + fdim);
-  uint32_t gw_next = (valid && p.level_lo < p.level_hi) ? grow[p.level_lo] : 0u;
+  const bool al8 = (fdim * 2) % 8 == 0 && (pad * 2) % 8 == 0;   // 8-byte loads when the grid part starts 8-byte aligned in every row
   __syncthreads();
   for (int l = p.level_lo; l < p.level_hi; ++l) {
     const int par = l & 1;
     const uint32_t sl = b.slice_log2[l], slot_mask = (1u << sl) - 1u;
-    const uint32_t gw = gw_next;
-    if (valid && l + 1 < p.level_hi) gw_next = grow[l + 1];
+    const int k8 = (l - p.level_lo) & 7;
+    if (k8 == 0) {   // words of levels l .. l + 7 -> this thread's column (nobody else touches it: no barrier)
+      const int nw = min(8, p.level_hi - l);
+      if (al8 && (l & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          uint2 w2 = make_uint2(0u, 0u);
+          if (valid && j < nw) { if (j + 1 < nw) w2 = *(const uint2*)(grow + l + j); else w2.x = grow[l + j]; }
+          gws[j][tid] = w2.x; gws[j + 1][tid] = w2.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gws[j][tid] = (valid && j < nw) ? grow[l + j] : 0u;
+      }
+    }
+    const uint32_t gw = gws[k8][tid];
     const h16x2 g = *(const h16x2*)&gw;
     const float g0 = (float)g[0], g1 = (float)g[1];
     uint32_t idx[8]; float w[8]; uint32_t cell[3];

@@ -351,13 +351,14 @@ __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
     }
     // channel sums: `lpr` lanes share a row (one 16-byte chunk each), so one wave instruction reads 64 / lpr whole rows;
     // every lane keeps 8 channel sums over its rows and the row groups are folded with cross-lane adds at the end
-    if (p.logits) {
-      const int nch_f = p.D / 8, nch_l = p.Cpad / 8;
+    if (p.logits || p.feat) {
+      const int nch_f = p.feat ? p.D / 8 : 0, nch_l = p.logits ? p.Cpad / 8 : 0;
       int lpr = 1;
       while (lpr < 64 && lpr < max(nch_f, nch_l)) lpr <<= 1;
       const int cg = lane & (lpr - 1), rg = lane / lpr, rpi = 64 / lpr;
       for (int pass = 0; pass < 2; ++pass) {
         const h16* src = pass ? p.feat : p.logits;
+        if (!src) continue;    // (feature-only compositing: the linear LSeg path sums hidden activations, no logits)
         const int ld = pass ? p.D : p.Cpad, nch = pass ? nch_f : nch_l, nout = pass ? p.D : p.C;
         float* dst = (pass ? p.features : p.semantic) + (size_t)ray * nout;
         for (int ch = cg; ch < nch; ch += lpr) {
@@ -389,8 +390,8 @@ extern "C" int aln_composite_out(const float* w_row, const int32_t* cidx_row, co
                                  int32_t Cpad, int32_t D, float bg, float* image, float* semantic, float* features,
                                  void* stream) {
   ALN_REQUIRE(w_row && cidx_row && color_out && wsum && image, "composite_out: NULL pointer");
-  ALN_REQUIRE(!logits || (feat && semantic && features), "composite_out: semantic buffers missing");
-  ALN_REQUIRE(!logits || (Cpad % 8 == 0 && D % 8 == 0), "composite_out: Cpad and D must be multiples of 8");
+  ALN_REQUIRE((!logits || semantic) && (!feat || features), "composite_out: semantic / feature output buffers missing");
+  ALN_REQUIRE((!logits || Cpad % 8 == 0) && (!feat || D % 8 == 0), "composite_out: Cpad and D must be multiples of 8");
   if (N <= 0) return 0;
   CompOut p{w_row, cidx_row, (const h16*)color_out, (const h16*)logits, (const h16*)feat, wsum, N, S1, S2, C, Cpad, D, bg,
             image, semantic, features};
@@ -405,7 +406,7 @@ struct CompBwd {
   const uint16_t* perm; const float* w_row; const float* T_row; const float* delta_row;
   const int* cidx_row; const h16* color_out; const h16* logits; const h16* feat; const h16* sigma_out;  // [M,16], col 0 = h0
   const float* g_image; const float* g_depth; const float* g_sem; const float* g_feat;  // per ray, already loss-scaled
-  int N, S1, S2, C, Cpad, D, D_used; float bg, density_scale;
+  int N, S1, S2, C, Cpad, D, mask_feat; float bg, density_scale;   // mask_feat: d_feat rows *= (feat > 0) (feat = a post-ReLU activation)
   float* d_h0;         // [M] fp32
   h16* d_color_out;    // [n_live,16]
   h16* d_logits;       // [M,Cpad]
@@ -425,17 +426,17 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
   bool bad = false;
   // the <logits, g_sem> + <f, g_feat> dot products (and, for the library-GEMM heads, the d_logits / d_feat rows = w * g)
   // run row-major with `lpr` lanes per row (16-byte chunks, whole rows per instruction) instead of one strided row per lane
-  const bool rowmajor_dots = p.logits != nullptr;
-  const int nch_f = p.D / 8, nch_l = p.Cpad / 8;
+  const bool rowmajor_dots = p.logits != nullptr || p.feat != nullptr;
+  const int nch_f = p.feat ? p.D / 8 : 0, nch_l = p.logits ? p.Cpad / 8 : 0;
   int lpr = 1;
   while (lpr < 64 && lpr < max(nch_f, nch_l)) lpr <<= 1;
   const int cg = lane & (lpr - 1), rg = lane / lpr, rpi = 64 / lpr;
   for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
     const float gi0 = p.g_image[3 * (size_t)ray], gi1 = p.g_image[3 * (size_t)ray + 1], gi2 = p.g_image[3 * (size_t)ray + 2];
     const float gd = p.g_depth[ray] / p.norms[ray];
-    if (p.logits) {
-      for (int c = lane; c < p.Cpad; c += 64) gs[c] = c < p.C ? p.g_sem[(size_t)ray * p.C + c] : 0.f;
-      for (int d = lane; d < p.D; d += 64) gf[d] = p.g_feat ? p.g_feat[(size_t)ray * p.D + d] : 0.f;
+    if (rowmajor_dots) {
+      for (int c = lane; c < p.Cpad; c += 64) gs[c] = (p.logits && c < p.C) ? p.g_sem[(size_t)ray * p.C + c] : 0.f;
+      for (int d = lane; d < p.D; d += 64) gf[d] = (p.feat && p.g_feat) ? p.g_feat[(size_t)ray * p.D + d] : 0.f;
     }
     __syncthreads();
     if (rowmajor_dots) {
@@ -461,9 +462,13 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
             *(h16x8*)(p.d_logits + row * p.Cpad + 8 * ch) = o8;
           }
           for (int ch = cg; ch < nch_f && p.d_feat; ch += lpr) {
-            h16x8 o8;
+            h16x8 o8, fv;
+            if (p.mask_feat) fv = *(const h16x8*)(p.feat + row * p.D + 8 * ch);   // (just read for the dot product: L1 hit)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { o8[j] = (h16)(w * gf[8 * ch + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
+            for (int j = 0; j < 8; ++j) {
+              o8[j] = (p.mask_feat && !((float)fv[j] > 0.f)) ? (h16)0.f : (h16)(w * gf[8 * ch + j]);
+              bad |= !(fabsf((float)o8[j]) <= 65504.f);
+            }
             *(h16x8*)(p.d_feat + row * p.D + 8 * ch) = o8;
           }
         }
@@ -516,14 +521,14 @@ extern "C" int aln_composite_bwd(const float* norms, const float* z, const float
                                  const float* g_image, const float* g_depth, const float* g_sem, const float* g_feat,
                                  int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad, int32_t D, float bg,
                                  float density_scale, float* d_h0, void* d_color_out, void* d_logits, void* d_feat,
-                                 int32_t* found_inf, void* stream) {
+                                 int32_t mask_feat, int32_t* found_inf, void* stream) {
   ALN_REQUIRE(norms && z && sigma && perm && w_row && T_row && delta_row && cidx_row && color_out && sigma_out && g_image &&
                   g_depth && d_h0 && d_color_out, "composite_bwd: NULL pointer");
-  ALN_REQUIRE(!logits || (feat && g_sem), "composite_bwd: semantic buffers missing");
+  ALN_REQUIRE((!logits || g_sem) && (!feat || g_feat), "composite_bwd: semantic / feature gradient buffers missing");
   ALN_REQUIRE(Cpad % 8 == 0 && D % 8 == 0, "composite_bwd: Cpad and D must be multiples of 8");
   if (N <= 0) return 0;
   CompBwd p{norms, z, sigma, perm, w_row, T_row, delta_row, cidx_row, (const h16*)color_out, (const h16*)logits,
-            (const h16*)feat, (const h16*)sigma_out, g_image, g_depth, g_sem, g_feat, N, S1, S2, C, Cpad, D, D, bg,
+            (const h16*)feat, (const h16*)sigma_out, g_image, g_depth, g_sem, g_feat, N, S1, S2, C, Cpad, D, mask_feat, bg,
             density_scale, d_h0, (h16*)d_color_out, (h16*)d_logits, (h16*)d_feat, found_inf};
   int S = S1 + S2;
   size_t lds = (size_t)(4 * S + Cpad + D) * sizeof(float);

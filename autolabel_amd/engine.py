@@ -27,6 +27,9 @@ class TrainEngine:
         self._lr, self.betas, self.eps, self.wd = float(lr), betas, float(eps), float(weight_decay_net)
         self.weights = (float(rgb_weight), float(depth_weight), float(semantic_weight), float(feature_weight))
         self.feature_loss = feature_loss
+        # LSeg-style training (scripts/ros/node.py:166-176: feature_dim 512, semantic_weight 0.0): no loss reaches the class logits,
+        # so the wide heads take the linear path (pipeline.forward: sem_linear)
+        self.sem_linear = bool(self.L.sem_wide and feature_loss and float(semantic_weight) == 0.0)
         self.S1, self.S2 = int(num_steps), int(upsample_steps)
         sc = dict(SCALER_DEFAULTS, **(scaler or {}))
         self.scaler_cfg = sc
@@ -88,7 +91,8 @@ class TrainEngine:
         L, pipe = self.L, self.pipe
         N = batch['rays_o'].shape[0]
         out, ctx = pipe.forward(batch['rays_o'], batch['rays_d'], batch['direction_norms'].reshape(-1), self.S1, self.S2, True,
-                                train=True, seed=seed, step=step, noise=noise, u=u, step_dev=step_dev, march=self.march, ws=self.ws)
+                                train=True, seed=seed, step=step, noise=noise, u=u, step_dev=step_dev, march=self.march, ws=self.ws,
+                                sem_linear=self.sem_linear)
         gt_feat = batch.get('features') if self.feature_loss else None
         Cf = gt_feat.shape[1] if gt_feat is not None else 0
         g_image, g_depth = self._gbuf('g_image', (N, 3)), self._gbuf('g_depth', (N,))
@@ -162,12 +166,12 @@ class TrainEngine:
                 allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts, n_grid=self.L.n_grid,
                                     payload=self.grad_payload, scratch=self._wire(self.L.n_grid))
 
-    def optimizer_step(self):
+    def optimizer_step(self, step_dev=None):
         P, L, sc = self.P, self.L, self.scaler_cfg
         H.call('aln_adam_step', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
                H.ptr(self.state_i), H.ptr(self.state_f), H.ptr(self.consts), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), len(self._blk_kind), self._blk_end,
-               self._blk_kind, int(bool(self.feature_loss)), H.ptr(self.counts), H.stream())
+               self._blk_kind, int(bool(self.feature_loss)), H.ptr(self.counts), H.ptr(step_dev), H.stream())
         P.refresh_shadows(grid=False)
 
     def maybe_update_grid(self):
@@ -182,7 +186,7 @@ class TrainEngine:
             self.maybe_update_grid()
         out = self.forward_backward(batch, seed, step, noise, u, step_dev)
         self.all_reduce_grads()
-        self.optimizer_step()
+        self.optimizer_step(step_dev)    # (advances the device step counter of a captured step: no separate increment launch)
         return out
 
     def graphed(self, frames, batch, data_seed, seed, frame_range=None, first_step=0, warmup=3):
@@ -264,8 +268,7 @@ class GraphedStep:
         return self.alt_body is not None and self.steps % self.alt_every == 0
 
     def _once(self, alt):
-        (self.alt_body if alt else self.body)(self.counter)
-        self.counter.add_(1)
+        (self.alt_body if alt else self.body)(self.counter)    # the body's last launch (aln_adam_step) increments the counter
 
     def __call__(self):
         if not self.valid():

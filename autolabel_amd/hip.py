@@ -91,12 +91,13 @@ _SIGS = {
     'aln_bitfield_count': (i32, [vp, i64, vp, vp]),
     'aln_mark_untrained_grid': (i32, [vp, i32, f32, vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
     'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
-    'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 6),
+    'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 4 + [i32] + [vp] * 2),
     'aln_loss_terms_floats': (i32, []),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),
-    'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, vp, vp]),
+    'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, vp, vp, vp]),
     'aln_similarity_argmax': (i32, [vp, i32, i32, vp, i32, vp, vp]),
     'aln_cast_f16': (i32, [vp, vp, i64, vp]),
+    'aln_cast_f32': (i32, [vp, vp, i64, vp]),
     'aln_grad_pack_f16': (i32, [vp, i64, f32, vp, vp]),
     'aln_grad_unpack_f16': (i32, [vp, i64, vp, vp, vp]),
     'aln_lzf_decompress': (i64, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),

@@ -354,7 +354,11 @@ class HipPipeline:
                 H.ptr(h2) if save else None, H.ptr(out), H.ptr(sigma), H.stream(), tag=('sigma', rows))
 
     def forward(self, rays_o, rays_d, norms, S1, S2, perturb, train, seed=0, step=0, noise=None, u=None,
-                want_semantic=True, bg=1.0, step_dev=None, march=False, ws=None):
+                want_semantic=True, bg=1.0, step_dev=None, march=False, ws=None, sem_linear=False):
+        """``sem_linear`` (training of the wide / LSeg heads with semantic_weight = 0, scripts/ros/node.py:166-176): the class
+        logits carry no loss, so semantic_out is skipped, and the last layer of semantic_features -- linear, no activation -- is
+        applied ONCE PER RAY to the composited hidden activation instead of once per sample: sum_s w_s (W3 h2_s) = W3 (sum_s w_s h2_s)
+        (autolabel/models.py:123, 248-256).  out['semantic'] is then zeros."""
         L, P = self.L, self.P
         ws = self.ws if ws is None else ws     # (the training engine passes its own: see Workspace)
         N = rays_o.shape[0]
@@ -428,7 +432,15 @@ class HipPipeline:
             fs, os_ = nets['semf'], nets['semo']
             c['sem_fused'] = self.recompute and not L.sem_wide
             c['sem_wide'] = L.sem_wide
-            if c['sem_wide']:
+            c['sem_linear'] = bool(sem_linear and L.sem_wide and train)
+            if c['sem_linear']:
+                Wf = P.wide_w['semf']
+                h1, h2 = g('wide_h1', (M, fs.hidden), f16), g('wide_h2', (M, fs.hidden), f16)
+                self._nt(M, fs.hidden, Wf[0], h1, geo=sout, relu=1, tag=('sem', M))
+                self._nt(M, fs.hidden, Wf[1], h2, a1=h1, K1=fs.hidden, relu=1, tag=('sem', M))
+                c['wide_saved'] = (h1, h2, None)
+                c['feat'], c['logits'] = h2, None      # what the compositing kernels sum / differentiate: the hidden activation
+            elif c['sem_wide']:
                 logits, feat, c['wide_saved'] = self.wide_sem_fwd(sout, M, lambda n, shp: g(n, shp, f16))
                 c['feat'], c['logits'] = feat, logits
             elif c['sem_fused']:  # inputs are built inside the kernels from sigma_out / f (no semf_in / semo_in tensors)
@@ -452,6 +464,19 @@ class HipPipeline:
                        H.ptr(logits), H.stream())
             out['semantic'] = torch.empty((N, L.C), dtype=f32_, device=dev)
             out['semantic_features'] = torch.empty((N, L.D), dtype=f32_, device=dev)
+        if c.get('sem_linear'):
+            # composite the hidden activation per ray, then ONE [N, hidden] x [hidden, D] GEMM for the whole batch
+            fs = nets['semf']
+            h2r = c['h2_ray32'] = g('h2_ray32', (N, fs.hidden), f32_)
+            h2r16 = c['h2_ray16'] = g('h2_ray16', (N, fs.hidden), f16)
+            f16r = g('feat_ray16', (N, fs.out_pad), f16)
+            H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), None, H.ptr(c['feat']), H.ptr(out['weights_sum']),
+                   N, S1, S2, L.C, L.Cpad, fs.hidden, float(bg), H.ptr(out['image']), None, H.ptr(h2r), H.stream())
+            H.call('aln_cast_f16', H.ptr(h2r), H.ptr(h2r16), h2r.numel(), H.stream())
+            self._nt(N, fs.out_pad, P.wide_w['semf'][2], f16r, a1=h2r16, K1=fs.hidden, tag=('sem', N))
+            H.call('aln_cast_f32', H.ptr(f16r), H.ptr(out['semantic_features']), f16r.numel(), H.stream())
+            out['semantic'].zero_()
+            return out, c
         H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(logits), H.ptr(feat), H.ptr(out['weights_sum']),
                N, S1, S2, L.C, L.Cpad, L.D, float(bg), H.ptr(out['image']), H.ptr(out.get('semantic')),
                H.ptr(out.get('semantic_features')), H.stream())
@@ -476,21 +501,41 @@ class HipPipeline:
         nets, e = L.nets, L.enc
         g = lambda n, shp, dt: ws.get(n, shp, dt)
         sem = c['want_semantic'] and g_sem is not None
+        lin = sem and c.get('sem_linear', False)
         fi = H.ptr(self.found_inf)
         gp = lambda k: C.c_void_p(P.grad.data_ptr() + 4 * L.offsets[k])
         d_h0 = g('d_h0', (M,), f32_)
         cs = nets['color']
         d_cout = g('d_color_out', (M, cs.out_pad), f16)
         sem_fused = sem and c.get('sem_fused', False)
-        d_logits = g('d_logits', (M, L.Cpad), f16) if sem and not sem_fused else None
-        d_feat = g('d_feat', (M, L.D), f16) if sem and not sem_fused else None
+        d_logits = g('d_logits', (M, L.Cpad), f16) if sem and not sem_fused and not c.get('sem_linear') else None
+        d_feat = g('d_feat', (M, L.D), f16) if sem and not sem_fused and not c.get('sem_linear') else None
         if sem and g_feat is None:
             g_feat = torch.zeros((N, L.D), dtype=f32_, device=g_image.device)
-        H.call('aln_composite_bwd', H.ptr(c['norms']), H.ptr(c['z']), H.ptr(c['sigma']), H.ptr(c['perm']), H.ptr(c['w_row']),
-               H.ptr(c['T_row']), H.ptr(c['delta_row']), H.ptr(c['cidx_row']), H.ptr(c['color_out']),
-               H.ptr(c['logits']) if sem else None, H.ptr(c['feat']) if sem else None, H.ptr(c['sigma_out']), H.ptr(g_image),
-               H.ptr(g_depth), H.ptr(g_sem) if sem else None, H.ptr(g_feat) if sem else None, N, S1, S2, L.C, L.Cpad, L.D,
-               c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), H.ptr(d_logits), H.ptr(d_feat), fi, H.stream())
+        if lin:
+            # per ray: dW3 += dF^T H2 ; dH2 = dF W3 ; per sample (inside the compositing backward): d h2_s = w_s relu'(h2_s) dH2[ray],
+            # d w_s += <h2_s, dH2[ray]>
+            fs = nets['semf']
+            of = L.offsets['semf']
+            n0, n1 = fs.shapes[0][0] * fs.shapes[0][1], fs.shapes[1][0] * fs.shapes[1][1]
+            dF16 = g('d_feat_ray16', (N, fs.out_pad), f16)
+            dH16 = g('d_h2_ray16', (N, fs.hidden), f16)
+            dH32 = g('d_h2_ray32', (N, fs.hidden), f32_)
+            H.call('aln_cast_f16', H.ptr(g_feat), H.ptr(dF16), g_feat.numel(), H.stream())
+            self._tn(N, fs.out_pad, dF16, of + n0 + n1, fs.hidden, a1=c['h2_ray16'], K1=fs.hidden, tag=('sem', N))
+            self._nt(N, fs.hidden, P.wide_wt['semf'][2], dH16, a1=dF16, K1=fs.out_pad, watch=True, tag=('sem', N))
+            H.call('aln_cast_f32', H.ptr(dH16), H.ptr(dH32), dH16.numel(), H.stream())
+            d_feat = g('wide_dh2', (M, fs.hidden), f16)    # = d h2 (masked): what the remaining layers back-propagate
+            H.call('aln_composite_bwd', H.ptr(c['norms']), H.ptr(c['z']), H.ptr(c['sigma']), H.ptr(c['perm']), H.ptr(c['w_row']),
+                   H.ptr(c['T_row']), H.ptr(c['delta_row']), H.ptr(c['cidx_row']), H.ptr(c['color_out']), None, H.ptr(c['feat']),
+                   H.ptr(c['sigma_out']), H.ptr(g_image), H.ptr(g_depth), None, H.ptr(dH32), N, S1, S2, L.C, L.Cpad, fs.hidden,
+                   c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), None, H.ptr(d_feat), 1, fi, H.stream())
+        else:
+            H.call('aln_composite_bwd', H.ptr(c['norms']), H.ptr(c['z']), H.ptr(c['sigma']), H.ptr(c['perm']), H.ptr(c['w_row']),
+                   H.ptr(c['T_row']), H.ptr(c['delta_row']), H.ptr(c['cidx_row']), H.ptr(c['color_out']),
+                   H.ptr(c['logits']) if sem else None, H.ptr(c['feat']) if sem else None, H.ptr(c['sigma_out']), H.ptr(g_image),
+                   H.ptr(g_depth), H.ptr(g_sem) if sem else None, H.ptr(g_feat) if sem else None, N, S1, S2, L.C, L.Cpad, L.D,
+                   c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), H.ptr(d_logits), H.ptr(d_feat), 0, fi, H.stream())
         # color head
         rc = self.recompute
         hp = (lambda t: None) if rc else H.ptr   # saved activations are not passed on the recompute path
@@ -506,6 +551,20 @@ class HipPipeline:
                     H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_oin), H.ptr(d_fin),
                     gp('semf'), gp('semo'), 1, fi, H.stream(), tag=('sem', M))
             d_oin = None     # fold_geo = 1: its geo_feat columns are already inside d_fin
+        elif lin:
+            # semantic_features layers 2 and 1 from d h2 (the last layer was handled per ray above; semantic_out took no part)
+            fs = nets['semf']
+            Wft = P.wide_wt['semf']
+            h1, h2, _ = c['wide_saved']
+            of = L.offsets['semf']
+            n0 = fs.shapes[0][0] * fs.shapes[0][1]
+            dh1 = g('wide_dh1', (M, fs.hidden), f16)
+            self._nt(M, fs.hidden, Wft[1], dh1, a1=d_feat, K1=fs.hidden, mask=h1, watch=True, tag=('sem', M))
+            self._tn(M, fs.hidden, d_feat, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=('sem', M))
+            d_fin = g('d_semf_in', (M, fs.in_pad), f16)
+            self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=('sem', M))
+            self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=c['sigma_out'], tag=('sem', M))
+            d_oin = None
         elif sem and c.get('sem_wide'):
             d_fin, d_oin = self.wide_sem_bwd(c['sigma_out'], M, c['feat'], c['wide_saved'], d_logits, d_feat, lambda n, shp: g(n, shp, f16))
         elif sem:
@@ -518,7 +577,7 @@ class HipPipeline:
             H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
                    None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
         d_sout = g('d_sigma_out', (M, 16), f16)
-        wide = sem and c.get('sem_wide')   # the wide path hands over the 16 geo columns of d(semo_in) only
+        wide = sem and c.get('sem_wide') and not lin   # the wide path hands over the 16 geo columns of d(semo_in) only
         H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), 16 if wide else nets['semo'].in_pad,
                0 if wide else L.D, H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
         d_enc = g('d_enc', (M, e.enc_pad), f16)

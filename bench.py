@@ -101,7 +101,7 @@ class Workload:
         self.bound = float(((hi - lo) - (lo + hi) * 0.5).max())  # autolabel/model_utils.py:62-63
         self.n_classes = scene['n_classes']
 
-    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None):
+    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None, semantic_weight=1.0):
         from autolabel_amd.engine import TrainEngine
         from autolabel_amd.parallel import broadcast_parameters
         from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
@@ -117,7 +117,7 @@ class Workload:
             t = self.train
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)
             pipe.mark_untrained_grid(t.world_to_camera(), (t.desc.fx, t.desc.fy, t.desc.cx, t.desc.cy), size=(t.w, t.h))
-        return TrainEngine(pipe, feature_loss=True, process_group=pg)
+        return TrainEngine(pipe, feature_loss=True, process_group=pg, semantic_weight=semantic_weight)
 
     def renderer(self, eng, march):
         """render callable for quality.heldout_metrics: 256 rows per ray along the whole ray (dense) / 128 rows inside occupied cells."""
@@ -304,9 +304,13 @@ def timed_leg(wl, args, eng, B, dseed, mseed, frange, use_graph, world, sync):
     terms = eng.terms.tolist()
     events = []
     if args.event_steps > 0:
-        if graphed is not None:   # the eager steps continue the step numbering of the replays
-            graphed.counter.zero_()
+        # the eager steps continue the step numbering of the replays (absolute step numbers, the device counter is not used), and the
+        # replays afterwards continue theirs: the trained state does not depend on how --steps / --warmup / --event-steps split the run
+        eng._calls = done[0]     # (marching: the density-grid refresh of the eager steps follows the absolute step number too)
         events = event_steps(eng, eager_step, args.event_steps, sync)
+        if graphed is not None:
+            graphed.counter.fill_(done[0])
+            graphed.steps = done[0]
     return dt, terms, events, step, done
 
 
@@ -346,15 +350,17 @@ def lseg_leg(wl, args, B):
     import torch
     a2 = argparse.Namespace(**vars(args))
     a2.steps, a2.warmup, a2.event_steps = min(args.steps, 30), min(args.warmup, 10), min(args.event_steps, 5)
-    eng = wl.engine(SEEDS[0][0], feature_dim=512)
+    eng = wl.engine(SEEDS[0][0], feature_dim=512, semantic_weight=0.0)   # scripts/ros/node.py:166-176: feature_dim 512, semantic_weight 0.0
     sync = torch.cuda.synchronize
     dt, terms, events, step, done = timed_leg(wl, a2, eng, B, SEEDS[0][1], SEEDS[0][2], None, True, 1, sync)
     live = float(eng.ws.get('n_live', (1,), torch.int32).item())
     return {'value': B * a2.steps / dt, 'unit': 'rays/s', 'ms_per_step': 1000 * dt / a2.steps, 'steps': a2.steps, 'warmup': a2.warmup,
-            'feature_dim': 512, 'roofline_mlp': mlp_roofline(eng, events, a2.event_steps, live) if events else None,
+            'feature_dim': 512, 'semantic_weight': 0.0, 'linear_last_layer_per_ray': bool(eng.sem_linear), 'roofline_mlp': mlp_roofline(eng, events, a2.event_steps, live) if events else None,
             'loss_terms_last_timed_step': dict(zip(('rgb', 'depth', 'feature', 'semantic', 'total'), terms)),
-            'note': 'semantic_features 16->512->512->512 and semantic_out 528->64->C as one hand-written MFMA GEMM launch per layer '
-                    '(k_wide_nt / k_wide_tn); the 64-d DINO-like targets supervise the first 64 of the 512 feature channels'}
+            'note': 'the reference\'s LSeg training configuration (scripts/ros/node.py:166-176: feature_dim 512, semantic_weight 0.0): '
+                    'semantic_features 16->512->512 per sample on the hand-written MFMA GEMMs (k_wide_nt / k_wide_tn), its linear last '
+                    'layer once per RAY on the composited hidden activation, semantic_out skipped (no loss reaches it); the 64-d '
+                    'DINO-like targets supervise the first 64 of the 512 feature channels'}
 
 
 def pmc_traffic(args):

@@ -276,6 +276,7 @@ int aln_composite_bwd(const float* norms, const float* z, const float* sigma, co
                       const void* logits, const void* feat, const void* sigma_out, const float* g_image, const float* g_depth,
                       const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad,
                       int32_t D, float bg, float density_scale, float* d_h0, void* d_color_out, void* d_logits, void* d_feat,
+                      int32_t mask_feat /* 1: d_feat rows are zeroed where feat <= 0 (feat = a post-ReLU activation) */,
                       int32_t* found_inf, void* stream);
 
 /* ---- loss: autolabel/trainer.py:72-92 (rgb MSE + depth L1 over depth > 0.01 + feature L1 + CE over labelled rays), ONE launch.
@@ -300,8 +301,9 @@ int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f
                   int32_t* state_i, float* state_f, float* consts, float lr, float beta1, float beta2, float eps, float wd_net,
                   float growth, float backoff, int32_t growth_interval, int32_t n_blocks, const int64_t* block_end /*host*/,
                   const int32_t* block_kind /*host*/, int32_t feature_loss, const int32_t* counts /*device, optional*/,
-                  void* stream);
+                  uint32_t* step_dev /*optional: += 1 once per call (the step counter of aln_raygen_train & co. under graph replay)*/, void* stream);
 int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
+int aln_cast_f32(const void* src_f16, float* dst, int64_t n, void* stream);
 /* fp16 wire format of the data-parallel exchange of the hash-grid gradient block (the reference has no multi-GPU path; the
  * gradient it averages is what scripts/train.py:50-63's optimizer consumes): out = fp16(grad * mul), and back grad = fp32(in)
  * with *found_inf raised on a non-finite element.  Pointers 16-byte aligned. */

@@ -208,6 +208,45 @@ def test_lseg_width_heads_match_oracle(D, C_):
     assert rel(got[:L.n_grid], gw[:L.n_grid]) < 2e-2
 
 
+def test_lseg_linear_last_layer_per_ray_matches_the_per_sample_oracle():
+    """semantic_weight = 0 (scripts/ros/node.py:166-176): the wide heads skip semantic_out and apply the last, linear layer of
+    semantic_features once per ray to the composited hidden activation.  Outputs and every gradient against the oracle, which
+    evaluates the heads per sample (autolabel/models.py:248-256) under the same loss weights."""
+    D, C_ = 512, 5
+    oracle, pipe, cfg = build_pair(L=4, D=D, C_=C_)
+    N, S1, S2, Cf = 24, 32, 32, 512
+    o, d, norms = make_rays(N, seed=3)
+    g = torch.Generator().manual_seed(5)
+    noise, u = torch.rand(N, S1, generator=g), torch.rand(N, S2, generator=g)
+    batch = _batch(N, C_, Cf, seed=6)
+    od, dd, nd, nz, ud = o.cuda(), d.cuda(), norms.cuda().reshape(-1), noise.cuda(), u.cuda()
+    out, ctx = pipe.forward(od, dd, nd, S1, S2, True, train=True, noise=nz, u=ud, sem_linear=True)
+    assert ctx['sem_linear'] and out['semantic'].abs().max().item() == 0
+    want = oracle.run(o, d, norms, num_steps=S1, upsample_steps=S2, perturb=True, noise_coarse=noise, u_fine=u,
+                      z_fine_override=ctx['z'][N * S1:].view(N, S2).cpu())
+    assert (out['semantic_features'].cpu() - want['semantic_features']).abs().max() < 1e-2 * max(1.0, want['semantic_features'].abs().max().item())
+    assert (out['image'].cpu() - want['image']).abs().max() < 5e-3
+    loss, _ = O.loss_fn(want, batch, feature_loss=True, semantic_weight=0.0)
+    loss.backward()
+    gw = flat_grads(oracle, cfg)
+    scale = 256.0
+    gi, gd, gs, gf, t = hip_loss(pipe, out, batch, N, C_, D, Cf, scale=scale, weights=(1.0, 0.1, 0.0, 0.5))
+    assert gs.abs().max().item() == 0
+    pipe.P.grad.zero_()
+    pipe.backward(ctx, gi, gd, gs, gf)
+    torch.cuda.synchronize()
+    assert pipe.found_inf.item() == 0
+    L = pipe.L
+    got = pipe.P.grad[:L.n_total].cpu() / scale
+    assert rel(got[:L.n_grid], gw[:L.n_grid]) < 2e-2, 'hash-grid gradient'
+    for k in ['sigma', 'color', 'semf']:
+        a = L.offsets[k]
+        b = a + L.nets[k].n_params
+        assert rel(got[a:b], gw[a:b]) < 2e-2, k
+    a = L.offsets['semo']
+    assert got[a:a + L.nets['semo'].n_params].abs().max().item() == 0 and gw[a:a + L.nets['semo'].n_params].abs().max().item() == 0
+
+
 def test_training_converges_like_the_oracle():
     """Matched quality: the HIP engine and the fp32 CPU oracle train the same small model (S0 cube scene, L=4, T=2^14) from
     the same initialisation on the same batches / random numbers for 50 Adam steps; the loss trajectories and the PSNR of
@@ -280,7 +319,7 @@ def test_adam_step_matches_torch_adam_and_skips_on_inf():
 
     def step():
         H.call('aln_adam_step', H.ptr(p), H.ptr(gr), H.ptr(m), H.ptr(v), H.ptr(t16), n_grid, n, H.ptr(si), H.ptr(sf), H.ptr(cst),
-               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, H.ptr(counts), H.stream())
+               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, H.ptr(counts), None, H.stream())
     for it in range(4):
         gt = torch.randn(n, generator=g)
         pr = p_ref.detach().clone()

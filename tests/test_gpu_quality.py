@@ -24,7 +24,7 @@ from oracle import nerf_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # the regime of the gate (scripts/dev/quality_gate_probe.py sweeps these)
-GATE = dict(steps=2500, batch=1024, s1=48, s2=48, n_frames=40, w=96, h=72, levels=12, log2_T=17, hip_seeds=(7, 8, 9), oracle_seeds=(7, 8))
+GATE = dict(steps=4000, batch=1024, s1=48, s2=48, n_frames=40, w=96, h=72, levels=12, log2_T=17, hip_seeds=(7, 8, 9), oracle_seeds=(7, 8))
 TOL_PSNR_DB, TOL_MIOU_PT, MIN_ORACLE_PSNR_DB = 0.2, 0.5, 22.0
 
 
