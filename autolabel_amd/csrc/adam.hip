@@ -17,7 +17,7 @@
 // consts (optional, written by the last block for inspection): c[0] = skip all (0/1), c[3] = 1/scale_used, c[4+2b] = lr / bc1_b
 //                                     (0 = block inactive), c[5+2b] = 1/sqrt(bc2_b)
 #define ADAM_MAX_BLOCKS 8
-struct AdamHyper { float lr, beta1, beta2, eps, wd_net, growth, backoff; int growth_interval; };
+struct AdamHyper { float lr, beta1, beta2, eps, wd_net, growth, backoff; int growth_interval; double log_beta1, log_beta2; };
 struct AdamBlocks { int n; long long end[ADAM_MAX_BLOCKS]; int needs_sem[ADAM_MAX_BLOCKS]; int needs_sem_or_feat[ADAM_MAX_BLOCKS]; int feat_on; };
 
 // The step constants (skip flag, 1 / loss scale, per-block step size and bias correction) are a pure function of the state words
@@ -45,20 +45,24 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     for (int b = 0; b < blk.n; ++b) {
       if (found || !adam_block_active(blk, b, has_sem)) { cs.step_size[b] = 0.f; cs.inv_sqrt_bc2[b] = 1.f; continue; }
       const int t = si[4 + b] + 1;
-      const double bc1 = 1.0 - pow((double)h.beta1, (double)t), bc2 = 1.0 - pow((double)h.beta2, (double)t);
+      const double bc1 = 1.0 - exp((double)t * h.log_beta1), bc2 = 1.0 - exp((double)t * h.log_beta2);   // 1 - beta^t
       cs.step_size[b] = (float)((double)lr / bc1); cs.inv_sqrt_bc2[b] = (float)(1.0 / sqrt(bc2));
     }
   }
   __syncthreads();
   const bool skip = cs.skip != 0.f;
   const float inv_scale = cs.inv_scale;
+  float r_step[ADAM_MAX_BLOCKS], r_isb[ADAM_MAX_BLOCKS];   // (registers: the loop below must not go back to LDS per element)
+#pragma unroll
+  for (int b = 0; b < ADAM_MAX_BLOCKS; ++b) { r_step[b] = b < blk.n ? cs.step_size[b] : 0.f; r_isb[b] = b < blk.n ? cs.inv_sqrt_bc2[b] : 1.f; }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
     g[i] = 0.f;
     if (skip) continue;
-    int b = 0;
-    while (b + 1 < blk.n && (long long)i >= blk.end[b]) ++b;
-    const float step_size = cs.step_size[b], inv_sqrt_bc2 = cs.inv_sqrt_bc2[b];
+    float step_size = r_step[0], inv_sqrt_bc2 = r_isb[0];
+#pragma unroll
+    for (int b = 1; b < ADAM_MAX_BLOCKS; ++b)
+      if (b < blk.n && (long long)i >= blk.end[b - 1]) { step_size = r_step[b]; inv_sqrt_bc2 = r_isb[b]; }
     if (step_size == 0.f) continue;   // block without gradient this step (torch: grad is None)
     float pi = p[i];
     gi *= inv_scale;
@@ -105,7 +109,7 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
   ALN_REQUIRE(params && grads && m && v && state_i && state_f, "adam: NULL pointer");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
   ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
-  AdamHyper h{lr, beta1, beta2, eps, wd_net, growth, backoff, growth_interval};
+  AdamHyper h{lr, beta1, beta2, eps, wd_net, growth, backoff, growth_interval, log((double)beta1), log((double)beta2)};
   AdamBlocks blk{};
   if (n_blocks == 0) { blk.n = 1; blk.end[0] = n_total; }
   else {
@@ -113,7 +117,7 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
     for (int b = 0; b < n_blocks; ++b) { blk.end[b] = block_end[b]; blk.needs_sem[b] = block_kind[b] == 1; blk.needs_sem_or_feat[b] = block_kind[b] == 2; }
   }
   blk.feat_on = feature_loss;
-  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
+  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_total, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
                      (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, counts, step_dev);
   ALN_CHECK_LAUNCH("adam");
   return 0;

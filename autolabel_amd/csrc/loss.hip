@@ -28,7 +28,15 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float scale = a.loss_scale ? *a.loss_scale : 1.f;
   int nd = 0, ns = 0;
-  for (int i = threadIdx.x; i < a.N; i += 256) { nd += a.gt_depth[i] > DEPTH_EPSILON; ns += a.gt_sem[i] >= 0; }
+  {   // 16-byte loads over the aligned body of the two arrays, the tail element-wise
+    const int n4 = (((uintptr_t)a.gt_depth | (uintptr_t)a.gt_sem) & 15) == 0 ? a.N / 4 : 0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const float4 d4 = ((const float4*)a.gt_depth)[i]; const int4 s4 = ((const int4*)a.gt_sem)[i];
+      nd += (d4.x > DEPTH_EPSILON) + (d4.y > DEPTH_EPSILON) + (d4.z > DEPTH_EPSILON) + (d4.w > DEPTH_EPSILON);
+      ns += (s4.x >= 0) + (s4.y >= 0) + (s4.z >= 0) + (s4.w >= 0);
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < a.N; i += 256) { nd += a.gt_depth[i] > DEPTH_EPSILON; ns += a.gt_sem[i] >= 0; }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { nd += __shfl_xor(nd, o); ns += __shfl_xor(ns, o); }
   if (lane == 0) { cnt_s[wave][0] = nd; cnt_s[wave][1] = ns; }
@@ -94,11 +102,18 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ticket = __hip_atomic_fetch_add(a.counts + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_s = ticket == (int)gridDim.x - 1;
-    if (last_s) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      float sum[4] = {0.f, 0.f, 0.f, 0.f};
-      for (unsigned b = 0; b < gridDim.x; ++b)
-        for (int k = 0; k < 4; ++k) sum[k] += a.terms[8 + 4 * b + k];
+    if (last_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (last_s) {   // the whole block folds the rows: thread t takes row t, then a fixed tree (lanes, then waves): same sum every run
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < gridDim.x) v = *(const float4*)(a.terms + 8 + 4 * threadIdx.x);
+    v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);
+    if (lane == 0) { part[wave][0] = v.x; part[wave][1] = v.y; part[wave][2] = v.z; part[wave][3] = v.w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float sum[4];
+      for (int k = 0; k < 4; ++k) sum[k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
       float r = sum[0] / (3.f * a.N), d = nd ? sum[1] / nd : 0.f, f = (a.gt_feat && a.Cf) ? sum[2] / ((float)a.N * a.Cf) : 0.f,
             sv = ns ? sum[3] / ns : 0.f;
       a.terms[0] = r; a.terms[1] = d; a.terms[2] = f; a.terms[3] = sv;

@@ -440,8 +440,10 @@ __device__ inline void chain_layer_m(f32x16 (&acc)[RPW][NB], FragFn frag, BFn bo
   }
 }
 // ---------------------------------------------------------------- forward
+// (three 256-thread blocks per CU wherever the chain fits 168 VGPRs -- the 128-wide heads with up to 48 inputs: the register
+//  allocator is told so, one register over costs a third of the resident waves)
 template <int HID, int NHID, int KS0>
-__global__ __launch_bounds__(256) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HID == 128 && NHID == 2 && KS0 > 3) ? 2 : 3))) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
                                                 RowSrc xs, int rows, const int* __restrict__ rows_dev,
                                                 h16* __restrict__ h1, h16* __restrict__ h2, h16* __restrict__ out,
                                                 float* __restrict__ sigma) {

@@ -322,6 +322,12 @@ def marching_leg(wl, args, B):
     eng = wl.engine(SEEDS[0][0], march=True)
     occ = eng.pipe.occ
     sync = torch.cuda.synchronize
+    # every 16th step carries the density-grid refresh (2 M cells through the density head): the timed region of this leg is whole
+    # refresh periods, at least four of them, whatever --steps says for the headline leg
+    a2 = argparse.Namespace(**vars(args))
+    a2.steps = max(64, (args.steps + 15) // 16 * 16)
+    a2.warmup = max(args.warmup, 16)
+    args = a2
     dt, terms, events, step, done = timed_leg(wl, args, eng, B, SEEDS[0][1], SEEDS[0][2], None, True, 1, sync)
     rows = B * args.march_samples
     roof = scatter_roofline(eng, events, rows, args.event_steps) if events else None
@@ -335,7 +341,8 @@ def marching_leg(wl, args, B):
         q.update(steps=done[0], adam_steps_applied=int(eng.state_i[0].item()))
         quality = quality_runs(wl, args, q, march=True)
     render_mrays = wl.render_throughput(eng, True)[0] if args.render_frames > 0 else None
-    return {'value': B * args.steps / dt, 'unit': 'rays/s', 'ms_per_step': 1000 * dt / args.steps, 'samples_per_ray': args.march_samples,
+    return {'value': B * args.steps / dt, 'unit': 'rays/s', 'ms_per_step': 1000 * dt / args.steps, 'steps': args.steps, 'warmup': args.warmup,
+            'samples_per_ray': args.march_samples,
             'sample_rows_per_step': rows, 'grid': '128^3, one level', 'max_steps': 1024, 'density_thresh': args.march_thresh,
             'render_Mrays_per_s': render_mrays, 'render_rows_per_ray': max(args.march_samples, 128), 'occupied_fraction': occ.occupancy(),
             'roofline': roof, 'roofline_mlp': roof_mlp, 'quality': quality,
