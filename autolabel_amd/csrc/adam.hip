@@ -36,18 +36,18 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
                        AdamBlocks blk, const int* counts, uint32_t* step_dev) {
   __shared__ AdamConsts cs;
   const bool has_sem = !counts || counts[1] > 0;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < ADAM_MAX_BLOCKS) {   // lane b derives the constants of parameter block b (the lanes work side by side)
+    const int b = threadIdx.x;
     const int found = si[2];
-    const float scale = sf[0];
-    cs.skip = found ? 1.f : 0.f;
-    cs.inv_scale = 1.0f / scale;
+    if (b == 0) { cs.skip = found ? 1.f : 0.f; cs.inv_scale = 1.0f / sf[0]; }
     const float lr = sf[1] > 0.f ? sf[1] : h.lr;
-    for (int b = 0; b < blk.n; ++b) {
-      if (found || !adam_block_active(blk, b, has_sem)) { cs.step_size[b] = 0.f; cs.inv_sqrt_bc2[b] = 1.f; continue; }
+    float ss = 0.f, ib = 1.f;
+    if (b < blk.n && !found && adam_block_active(blk, b, has_sem)) {
       const int t = si[4 + b] + 1;
       const double bc1 = 1.0 - exp((double)t * h.log_beta1), bc2 = 1.0 - exp((double)t * h.log_beta2);   // 1 - beta^t
-      cs.step_size[b] = (float)((double)lr / bc1); cs.inv_sqrt_bc2[b] = (float)(1.0 / sqrt(bc2));
+      ss = (float)((double)lr / bc1); ib = (float)(1.0 / sqrt(bc2));
     }
+    cs.step_size[b] = ss; cs.inv_sqrt_bc2[b] = ib;
   }
   __syncthreads();
   const bool skip = cs.skip != 0.f;
@@ -60,9 +60,11 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     g[i] = 0.f;
     if (skip) continue;
     float step_size = r_step[0], inv_sqrt_bc2 = r_isb[0];
+    if ((long long)i >= blk.end[0]) {   // (14.2 M of the 14.3 M parameters are the first block, the hash grid: one compare for them)
 #pragma unroll
-    for (int b = 1; b < ADAM_MAX_BLOCKS; ++b)
-      if (b < blk.n && (long long)i >= blk.end[b - 1]) { step_size = r_step[b]; inv_sqrt_bc2 = r_isb[b]; }
+      for (int b = 1; b < ADAM_MAX_BLOCKS; ++b)
+        if (b < blk.n && (long long)i >= blk.end[b - 1]) { step_size = r_step[b]; inv_sqrt_bc2 = r_isb[b]; }
+    }
     if (step_size == 0.f) continue;   // block without gradient this step (torch: grad is None)
     float pi = p[i];
     gi *= inv_scale;

@@ -542,7 +542,9 @@ __device__ inline long long fx_from_half_d(h16 h, int e) {
 #define ACC_RB (12 / ACC_LPR)    // runs per batch in the accumulate loop (12 loads per batch: 16 spill at the 128-VGPR budget of 16 waves per CU)
 __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
-  long long* acc = (long long*)acc_smem;   // [slice entries][2] <= 128 KB
+  long long* acc = (long long*)acc_smem;   // [2 features][slice entries] <= 128 KB: one plane per feature -- with the two features of
+                                           // an entry side by side, a wave's 64 slots fell onto 16 bank quads (PMC: 65 % of the
+                                           // LDS cycles of this kernel were bank conflicts); a plane spreads them over 32 bank pairs
   __shared__ unsigned long long bound_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = ACC_THREADS / 64;
   int li = 0;
@@ -558,8 +560,9 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   // (records are then ROUNDED to it -- still one fixed integer per record, so the sums stay order-independent).  In training
   // this never triggers for the hashed levels; it is what lets the two coarsest levels (thousands of records per entry at the
   // largest loss scales) share the exact path.
+  const uint32_t plane = 1u << sl;   // entries per plane
   if (tid == 0) bound_s = 0ull;
-  for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) acc[i] = 0ll;
+  for (uint32_t i = tid; i < ne; i += ACC_THREADS) { acc[i] = 0ll; acc[plane + i] = 0ll; }
   __syncthreads();
   {
     unsigned long long bsum = 0ull;
@@ -576,8 +579,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   auto add = [&](uint2 r, int ex) {   // ex = U - shift of the run's tile
     const h16x2 hv = *(const h16x2*)&r.y;
     bad |= (r.y & 0x7C00u) == 0x7C00u || (r.y & 0x7C000000u) == 0x7C000000u;
-    atomicAdd((unsigned long long*)&acc[2 * r.x], (unsigned long long)fx_from_half_d(hv[0], ex));
-    atomicAdd((unsigned long long*)&acc[2 * r.x + 1], (unsigned long long)fx_from_half_d(hv[1], ex));
+    atomicAdd((unsigned long long*)&acc[r.x], (unsigned long long)fx_from_half_d(hv[0], ex));
+    atomicAdd((unsigned long long*)&acc[plane + r.x], (unsigned long long)fx_from_half_d(hv[1], ex));
   };
   {
     // the tiles are dealt out to the 16 waves in equal contiguous shares (all waves busy for any tile count); a wave walks its
@@ -625,8 +628,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   __syncthreads();
   float* g = a.grad + 2 * ((size_t)a.offset[l] + e0);
   const double unit = ldexp(1.0, -U);
-  for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) {
-    const long long q = acc[i];
+  for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) {   // g is [entry][feature]
+    const long long q = acc[(i & 1u) * plane + (i >> 1)];
     if (q != 0ll) g[i] += (float)((double)q * unit);    // one rounding of the exact sum; no other block owns this entry
   }
   if (bad) {   // poison the slice (torch's GradScaler looks at the gradient tensor itself) and raise the engine's flag
