@@ -35,36 +35,72 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
                        h16* __restrict__ table16, size_t n_grid, size_t n_total, int* si, float* sf, float* c_out, AdamHyper h,
                        AdamBlocks blk, const int* counts, uint32_t* step_dev) {
   __shared__ AdamConsts cs;
-  const bool has_sem = !counts || counts[1] > 0;
-  if (threadIdx.x < ADAM_MAX_BLOCKS) {   // lane b derives the constants of parameter block b (the lanes work side by side)
-    const int b = threadIdx.x;
-    const int found = si[2];
-    if (b == 0) { cs.skip = found ? 1.f : 0.f; cs.inv_scale = 1.0f / sf[0]; }
-    const float lr = sf[1] > 0.f ? sf[1] : h.lr;
-    float ss = 0.f, ib = 1.f;
-    if (b < blk.n && !found && adam_block_active(blk, b, has_sem)) {
-      const int t = si[4 + b] + 1;
-      const double bc1 = 1.0 - exp((double)t * h.log_beta1), bc2 = 1.0 - exp((double)t * h.log_beta2);   // 1 - beta^t
-      ss = (float)((double)lr / bc1); ib = (float)(1.0 / sqrt(bc2));
+  const size_t vec_end = (blk.n > 0 && (size_t)blk.end[0] <= n_grid) ? ((size_t)blk.end[0] & ~(size_t)3) : 0;
+  {   // lane b derives the constants of parameter block b (the lanes work side by side); all state words in ONE round trip
+    const int b = threadIdx.x & (ADAM_MAX_BLOCKS - 1);
+    const int found = si[2], t0 = si[4 + b], lab = counts ? counts[1] : 1;
+    const float scale = sf[0], lrw = sf[1];
+    if (threadIdx.x < ADAM_MAX_BLOCKS) {
+      const bool has_sem = lab > 0;
+      if (b == 0) { cs.skip = found ? 1.f : 0.f; cs.inv_scale = 1.0f / scale; }
+      const float lr = lrw > 0.f ? lrw : h.lr;
+      float ss = 0.f, ib = 1.f;
+      if (b < blk.n && !found && adam_block_active(blk, b, has_sem)) {
+        const int t = t0 + 1;
+        const double bc1 = 1.0 - exp((double)t * h.log_beta1), bc2 = 1.0 - exp((double)t * h.log_beta2);   // 1 - beta^t
+        ss = (float)((double)lr / bc1); ib = (float)(1.0 / sqrt(bc2));
+      }
+      cs.step_size[b] = ss; cs.inv_sqrt_bc2[b] = ib;
     }
-    cs.step_size[b] = ss; cs.inv_sqrt_bc2[b] = ib;
   }
   __syncthreads();
   const bool skip = cs.skip != 0.f;
   const float inv_scale = cs.inv_scale;
-  float r_step[ADAM_MAX_BLOCKS], r_isb[ADAM_MAX_BLOCKS];   // (registers: the loop below must not go back to LDS per element)
+  float r_step[ADAM_MAX_BLOCKS], r_isb[ADAM_MAX_BLOCKS];   // (registers: the loops below must not go back to LDS per element)
 #pragma unroll
   for (int b = 0; b < ADAM_MAX_BLOCKS; ++b) { r_step[b] = b < blk.n ? cs.step_size[b] : 0.f; r_isb[b] = b < blk.n ? cs.inv_sqrt_bc2[b] : 1.f; }
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
+  // Hash-grid block (14.2 M of the 14.3 M parameters; block 0 when it is the grid): four parameters per lane and trip, 16-byte
+  // accesses.  In the step this kernel runs at the rate HBM sustains for an even read / write mix (16 B read + 18 B written per
+  // parameter: 92-101 us = 4.8-5.3 TB/s; alone, with its 243 MB resident in the memory-side cache, 62-75 us:
+  // scripts/dev/probe_adam.hip).  More loads in flight made it SLOWER in the step (next group requested before the current one is
+  // written: 124 us; first group requested before the constants: 111 us): the limit is the DRAM bus turning around, not latency.
+  {
+    const float step_size = r_step[0], inv_sqrt_bc2 = r_isb[0];
+    const bool idle = skip || step_size == 0.f;
+    const float b1 = h.beta1, b2 = h.beta2, c1 = 1.f - h.beta1, c2 = 1.f - h.beta2;
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < vec_end / 4; q += (size_t)gridDim.x * blockDim.x) {
+      const float4 g4 = ((const float4*)g)[q];
+      float4 p4, m4, v4;
+      if (!idle) { p4 = ((const float4*)p)[q]; m4 = ((const float4*)m)[q]; v4 = ((const float4*)v)[q]; }
+      ((float4*)g)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idle) continue;
+      float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      h16x4 t4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gi = gg[k] * inv_scale;
+        const float mi = b1 * mm[k] + c1 * gi;
+        const float vi = b2 * vv[k] + c2 * gi * gi;
+        mm[k] = mi; vv[k] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + h.eps;
+        pp[k] -= step_size * (mi / denom);
+        t4[k] = (h16)pp[k];
+      }
+      ((float4*)m)[q] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      ((float4*)v)[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      ((float4*)p)[q] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      *(h16x4*)(table16 + 4 * q) = t4;
+    }
+  }
+  // the rest (MLP weights, a ragged grid tail): one parameter per lane, block looked up per element
+  for (size_t i = vec_end + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
     g[i] = 0.f;
     if (skip) continue;
     float step_size = r_step[0], inv_sqrt_bc2 = r_isb[0];
-    if ((long long)i >= blk.end[0]) {   // (14.2 M of the 14.3 M parameters are the first block, the hash grid: one compare for them)
 #pragma unroll
-      for (int b = 1; b < ADAM_MAX_BLOCKS; ++b)
-        if (b < blk.n && (long long)i >= blk.end[b - 1]) { step_size = r_step[b]; inv_sqrt_bc2 = r_isb[b]; }
-    }
+    for (int b = 1; b < ADAM_MAX_BLOCKS; ++b)
+      if (b < blk.n && (long long)i >= blk.end[b - 1]) { step_size = r_step[b]; inv_sqrt_bc2 = r_isb[b]; }
     if (step_size == 0.f) continue;   // block without gradient this step (torch: grad is None)
     float pi = p[i];
     gi *= inv_scale;
@@ -84,6 +120,7 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     if (ticket == (int)gridDim.x - 1) {
       const float scale = sf[0];
       if (c_out) { c_out[0] = cs.skip; c_out[3] = cs.inv_scale; for (int b = 0; b < blk.n; ++b) { c_out[4 + 2 * b] = cs.step_size[b]; c_out[5 + 2 * b] = cs.inv_sqrt_bc2[b]; } }
+      const bool has_sem = !counts || counts[1] > 0;
       if (skip) { sf[0] = scale * h.backoff; si[1] = 0; }
       else {
         si[0] += 1;
@@ -111,6 +148,8 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
   ALN_REQUIRE(params && grads && m && v && state_i && state_f, "adam: NULL pointer");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
   ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
+  ALN_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)table_f16 & 7) == 0,
+              "adam: parameter / gradient / moment buffers must be 16-byte aligned (fp16 shadow: 8)");
   AdamHyper h{lr, beta1, beta2, eps, wd_net, growth, backoff, growth_interval, log((double)beta1), log((double)beta2)};
   AdamBlocks blk{};
   if (n_blocks == 0) { blk.n = 1; blk.end[0] = n_total; }

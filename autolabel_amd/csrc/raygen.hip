@@ -52,6 +52,15 @@ struct RaygenArgs {
 };
 struct RaygenKeys { uint32_t k_frame, k_pix, k_jx, k_jy, k_cls; };
 
+// feature row of (frame, pix): nearest-cell lookup of dataset.py:231-240
+__device__ inline const h16* feature_row(const AlnFrames& fr, int frame, int64_t pix) {
+  int64_t x = pix % fr.w, y = (pix - x) / fr.w;
+  int fx_ = (int)((double)x * ((double)fr.feat_w / (double)fr.w));
+  int fy_ = (int)((double)y * ((double)fr.feat_h / (double)fr.h));
+  return (const h16*)fr.features + ((size_t)frame * fr.feat_w * fr.feat_h + (size_t)fy_ * fr.feat_w + fx_) * fr.feat_c;
+}
+
+template <bool FEATURES = true>
 __device__ inline void gather_pixel(const AlnFrames& fr, const AlnBatch& out, int b, int frame, int64_t pix) {
   size_t hw = (size_t)fr.w * fr.h;
   size_t src = (size_t)frame * hw + pix;
@@ -61,56 +70,83 @@ __device__ inline void gather_pixel(const AlnFrames& fr, const AlnBatch& out, in
   }
   if (out.depth) out.depth[b] = (float)((double)fr.depths[src] / 1000.0);       // dataset.py:220
   if (out.semantic) out.semantic[b] = (int)fr.semantics[src] - 1;                // dataset.py:221-222
-  if (out.features && fr.features) {                                            // dataset.py:231-240
-    int64_t x = pix % fr.w, y = (pix - x) / fr.w;
-    int fx_ = (int)((double)x * ((double)fr.feat_w / (double)fr.w));
-    int fy_ = (int)((double)y * ((double)fr.feat_h / (double)fr.h));
-    const h16* f = (const h16*)fr.features + ((size_t)frame * fr.feat_w * fr.feat_h + (size_t)fy_ * fr.feat_w + fx_) * fr.feat_c;
-    for (int c = 0; c < fr.feat_c; ++c) out.features[(size_t)b * fr.feat_c + c] = (float)f[c];
+  if constexpr (FEATURES) {
+    if (out.features && fr.features) {                                          // dataset.py:231-240
+      const h16* f = feature_row(fr, frame, pix);
+      for (int c = 0; c < fr.feat_c; ++c) out.features[(size_t)b * fr.feat_c + c] = (float)f[c];
+    }
   }
 }
 
-__global__ void k_raygen_train(RaygenArgs args) {
+// One lane per ray, 64 rays per block (a 4096-ray batch then covers 64 CUs instead of 16: the kernel is a chain of dependent
+// random loads per ray and took 21 us however small the batch).  The feature rows -- 64 halves -> 64 floats per ray -- are
+// copied by the whole block afterwards, 16 bytes per lane in, 32 bytes out, consecutive lanes on consecutive chunks.
+#define RG_BLOCK 64
+__global__ __launch_bounds__(RG_BLOCK) void k_raygen_train(RaygenArgs args) {
+  __shared__ const h16* frow[RG_BLOCK];
   const uint32_t st = args.step + (args.step_dev ? *args.step_dev : 0u);
   struct A : RaygenArgs, RaygenKeys {} a;
   (RaygenArgs&)a = args;
   a.k_frame = aln_rand_key(args.seed, ALN_STREAM_FRAME, st); a.k_pix = aln_rand_key(args.seed, ALN_STREAM_PIXEL, st);
   a.k_jx = aln_rand_key(args.seed, ALN_STREAM_JX, st); a.k_jy = aln_rand_key(args.seed, ALN_STREAM_JY, st);
   a.k_cls = aln_rand_key(args.seed, ALN_STREAM_CLASS, st);
-  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += gridDim.x * blockDim.x) {
-    int ch = b / a.chunk;
-    int frame; int64_t pix;
-    // class-weighted chunk (dataset.py:207-211): every ray of the chunk takes the same (class, frame) decision
-    bool labelled = !a.chunk_frames && !a.ray_idx && a.fr.n_classes > 0 && a.fr.sem_ratio > 0.f &&
-                    aln_rand_uniform(a.k_cls, 3u * (uint32_t)ch) < a.fr.sem_ratio;
-    if (labelled) {
-      int k = (int)(aln_rand_u32(a.k_cls, 3u * (uint32_t)ch + 1u) % (uint32_t)a.fr.n_classes);
-      const int* off = a.fr.cls_offsets + (size_t)k * (a.fr.n_frames + 1);
-      int lo_o = off[a.frame_lo], hi_o = off[a.frame_hi];
-      if (hi_o > lo_o) {
-        int r = lo_o + (int)(aln_rand_u32(a.k_cls, 3u * (uint32_t)ch + 2u) % (uint32_t)(hi_o - lo_o));
-        int f0 = a.frame_lo, f1 = a.frame_hi;      // largest f with off[f] <= r
-        while (f1 - f0 > 1) { int m = (f0 + f1) >> 1; if (off[m] <= r) f0 = m; else f1 = m; }
-        frame = f0;
-        pix = a.fr.cls_pixels[off[f0] + (int)(aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)(off[f0 + 1] - off[f0]))];
-      } else labelled = false;                     // this rank's frame shard has no pixel of that class
-    }
-    if (!labelled) {
-      frame = a.chunk_frames ? a.chunk_frames[ch]
-                             : a.frame_lo + (int)(aln_rand_u32(a.k_frame, (uint32_t)ch) % (uint32_t)(a.frame_hi - a.frame_lo));
-      pix = a.ray_idx ? a.ray_idx[b] : a.fr.pixel_indices[aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)a.fr.n_pix];
-    }
-    float jx = a.jitter ? a.jitter[2 * b] : aln_rand_uniform(a.k_jx, (uint32_t)b);
-    float jy = a.jitter ? a.jitter[2 * b + 1] : aln_rand_uniform(a.k_jy, (uint32_t)b);
-    float d[3], nn;
-    pixel_direction(a.fr.rotations + 9 * (size_t)frame, pix, a.fr.w, a.fr.fx, a.fr.fy, a.fr.cx, a.fr.cy, true, jx, jy, d, &nn);
+  const bool feats = a.out.features && a.fr.features;
+  for (int b0 = blockIdx.x * RG_BLOCK; b0 < a.B; b0 += gridDim.x * RG_BLOCK) {
+    const int b = b0 + threadIdx.x;
+    if (b < a.B) {
+      int ch = b / a.chunk;
+      int frame; int64_t pix;
+      // class-weighted chunk (dataset.py:207-211): every ray of the chunk takes the same (class, frame) decision
+      bool labelled = !a.chunk_frames && !a.ray_idx && a.fr.n_classes > 0 && a.fr.sem_ratio > 0.f &&
+                      aln_rand_uniform(a.k_cls, 3u * (uint32_t)ch) < a.fr.sem_ratio;
+      if (labelled) {
+        int k = (int)(aln_rand_u32(a.k_cls, 3u * (uint32_t)ch + 1u) % (uint32_t)a.fr.n_classes);
+        const int* off = a.fr.cls_offsets + (size_t)k * (a.fr.n_frames + 1);
+        int lo_o = off[a.frame_lo], hi_o = off[a.frame_hi];
+        if (hi_o > lo_o) {
+          int r = lo_o + (int)(aln_rand_u32(a.k_cls, 3u * (uint32_t)ch + 2u) % (uint32_t)(hi_o - lo_o));
+          int f0 = a.frame_lo, f1 = a.frame_hi;      // largest f with off[f] <= r
+          while (f1 - f0 > 1) { int m = (f0 + f1) >> 1; if (off[m] <= r) f0 = m; else f1 = m; }
+          frame = f0;
+          pix = a.fr.cls_pixels[off[f0] + (int)(aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)(off[f0 + 1] - off[f0]))];
+        } else labelled = false;                     // this rank's frame shard has no pixel of that class
+      }
+      if (!labelled) {
+        frame = a.chunk_frames ? a.chunk_frames[ch]
+                               : a.frame_lo + (int)(aln_rand_u32(a.k_frame, (uint32_t)ch) % (uint32_t)(a.frame_hi - a.frame_lo));
+        pix = a.ray_idx ? a.ray_idx[b] : a.fr.pixel_indices[aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)a.fr.n_pix];
+      }
+      if (feats) frow[threadIdx.x] = feature_row(a.fr, frame, pix);
+      float jx = a.jitter ? a.jitter[2 * b] : aln_rand_uniform(a.k_jx, (uint32_t)b);
+      float jy = a.jitter ? a.jitter[2 * b + 1] : aln_rand_uniform(a.k_jy, (uint32_t)b);
+      float d[3], nn;
+      pixel_direction(a.fr.rotations + 9 * (size_t)frame, pix, a.fr.w, a.fr.fx, a.fr.fy, a.fr.cx, a.fr.cy, true, jx, jy, d, &nn);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      a.out.rays_d[3 * (size_t)b + k] = d[k];
-      a.out.rays_o[3 * (size_t)b + k] = a.fr.origins[3 * (size_t)frame + k];
+      for (int k = 0; k < 3; ++k) {
+        a.out.rays_d[3 * (size_t)b + k] = d[k];
+        a.out.rays_o[3 * (size_t)b + k] = a.fr.origins[3 * (size_t)frame + k];
+      }
+      a.out.norms[b] = nn;
+      gather_pixel<false>(a.fr, a.out, b, frame, pix);
     }
-    a.out.norms[b] = nn;
-    gather_pixel(a.fr, a.out, b, frame, pix);
+    if (feats) {
+      __syncthreads();
+      const int Cf = a.fr.feat_c, nr = min(RG_BLOCK, a.B - b0);
+      float* const dst = a.out.features + (size_t)b0 * Cf;
+      if (Cf % 8 == 0 && ((uintptr_t)a.fr.features & 15) == 0 && ((uintptr_t)a.out.features & 15) == 0) {
+        const int nch = Cf / 8;
+        for (int i = threadIdx.x; i < nr * nch; i += RG_BLOCK) {
+          const int r = i / nch, c8 = i % nch;
+          const h16x8 v = *(const h16x8*)(frow[r] + 8 * c8);
+          float* o = dst + (size_t)r * Cf + 8 * c8;
+          *(float4*)o = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+          *(float4*)(o + 4) = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+        }
+      } else {
+        for (int i = threadIdx.x; i < nr * Cf; i += RG_BLOCK) dst[i] = (float)frow[i / Cf][i % Cf];
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -148,7 +184,7 @@ extern "C" int aln_raygen_train(const AlnFrames* fr, const AlnBatch* out, int32_
   ALN_REQUIRE(fr->n_classes == 0 || (fr->cls_offsets && fr->cls_pixels), "raygen_train: class index arrays missing");
   if (B <= 0) return 0;
   RaygenArgs a{*fr, *out, B, chunk, frame_lo, frame_hi, seed, step, step_dev, chunk_frames, ray_idx, jitter};
-  hipLaunchKernelGGL(k_raygen_train, dim3(aln_grid_for(B, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_raygen_train, dim3(aln_grid_for(B, RG_BLOCK)), dim3(RG_BLOCK), 0, (hipStream_t)stream, a);
   ALN_CHECK_LAUNCH("raygen_train");
   return 0;
 }

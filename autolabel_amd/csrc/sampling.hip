@@ -414,7 +414,16 @@ struct CompBwd {
   int* found_inf;
 };
 
-__global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
+#ifndef CB_KU
+#define CB_KU 4    // row trips requested together by a wave of k_composite_bwd (parts 2 / 3: one lane per row)
+#endif
+#ifndef CB_KU1
+#define CB_KU1 2   // ... part 1 (lpr lanes per row).  Measured (4096 / 1024 rays): old kernel 67 / 47 us; KU1 4 at 3 waves per SIMD 69 / 29; KU1 2 at 4 waves 53 / 31
+#endif
+#ifndef CB_WPE
+#define CB_WPE 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB_WPE))) void k_composite_bwd(CompBwd p) {
   extern __shared__ float sm[];
   const int S = p.S1 + p.S2, lane = threadIdx.x;
   float* P = sm;          // sorted dw*w [S]
@@ -439,76 +448,158 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompBwd p) {
       for (int d = lane; d < p.D; d += 64) gf[d] = (p.feat && p.g_feat) ? p.g_feat[(size_t)ray * p.D + d] : 0.f;
     }
     __syncthreads();
+    // One wave walks one ray, so the kernel's time is the length of this wave's dependent chain, not a byte count: with one row
+    // group per trip and the loads of a trip issued after the previous trip's shuffles, a ray took ~41 us however few rays there
+    // were (profiles/r03_train_kernel_stats_B1024: 47 us at 1024 rays, 67 us at 4096).  All three parts below therefore request the
+    // rows of CB_KU trips before touching any of them, and part 3's operands ride along with part 2's (same rows).
     if (rowmajor_dots) {
-      for (int k = rg; k < S; k += rpi) {   // S % rpi == 0 is not required: k only feeds loads and the final store
-        const size_t row = row_of(ray, k, p.N, p.S1, p.S2);
-        float acc = 0.f;
-        for (int ch = cg; ch < nch_l; ch += lpr) {
-          const h16x8 v = *(const h16x8*)(p.logits + row * p.Cpad + 8 * ch);
+      if (nch_l <= lpr && nch_f <= lpr) {   // one chunk of each kind per lane (always, up to 512 columns)
+        const bool hl = cg < nch_l, hfe = cg < nch_f;
+        float gsr[8], gfr[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc += (float)v[j] * gs[8 * ch + j];
-        }
-        for (int ch = cg; ch < nch_f; ch += lpr) {
-          const h16x8 v = *(const h16x8*)(p.feat + row * p.D + 8 * ch);
+        for (int j = 0; j < 8; ++j) { gsr[j] = hl ? gs[8 * cg + j] : 0.f; gfr[j] = hfe ? gf[8 * cg + j] : 0.f; }
+        const bool need_w = p.d_logits || p.d_feat;
+        for (int k0 = rg; k0 < S; k0 += CB_KU1 * rpi) {
+          h16x8 vl[CB_KU1], vf[CB_KU1]; float wv[CB_KU1]; size_t rowv[CB_KU1]; bool ok[CB_KU1];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc += (float)v[j] * gf[8 * ch + j];
-        }
-        if (p.d_logits || p.d_feat) {   // library-GEMM heads: d(logits) = w * g_sem, d(f) = w * g_feat as whole rows
-          const float w = p.w_row[row];
-          for (int ch = cg; ch < nch_l && p.d_logits; ch += lpr) {
-            h16x8 o8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { o8[j] = (h16)(w * gs[8 * ch + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
-            *(h16x8*)(p.d_logits + row * p.Cpad + 8 * ch) = o8;
+          for (int u = 0; u < CB_KU1; ++u) {
+            const int k = k0 + u * rpi;
+            ok[u] = k < S;
+            rowv[u] = row_of(ray, ok[u] ? k : 0, p.N, p.S1, p.S2);
+            const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            vl[u] = (hl && ok[u]) ? *(const h16x8*)(p.logits + rowv[u] * p.Cpad + 8 * cg) : zero;
+            vf[u] = (hfe && ok[u]) ? *(const h16x8*)(p.feat + rowv[u] * p.D + 8 * cg) : zero;
+            wv[u] = (need_w && ok[u]) ? p.w_row[rowv[u]] : 0.f;
           }
-          for (int ch = cg; ch < nch_f && p.d_feat; ch += lpr) {
-            h16x8 o8, fv;
-            if (p.mask_feat) fv = *(const h16x8*)(p.feat + row * p.D + 8 * ch);   // (just read for the dot product: L1 hit)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              o8[j] = (p.mask_feat && !((float)fv[j] > 0.f)) ? (h16)0.f : (h16)(w * gf[8 * ch + j]);
-              bad |= !(fabsf((float)o8[j]) <= 65504.f);
+          for (int u = 0; u < CB_KU1; ++u) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)vl[u][j] * gsr[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)vf[u][j] * gfr[j];
+            if (p.d_logits && hl && ok[u]) {   // library-GEMM heads: d(logits) = w * g_sem, d(f) = w * g_feat as whole rows
+              h16x8 o8;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { o8[j] = (h16)(wv[u] * gsr[j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
+              *(h16x8*)(p.d_logits + rowv[u] * p.Cpad + 8 * cg) = o8;
             }
-            *(h16x8*)(p.d_feat + row * p.D + 8 * ch) = o8;
+            if (p.d_feat && hfe && ok[u]) {
+              h16x8 o8;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                o8[j] = (p.mask_feat && !((float)vf[u][j] > 0.f)) ? (h16)0.f : (h16)(wv[u] * gfr[j]);
+                bad |= !(fabsf((float)o8[j]) <= 65504.f);
+              }
+              *(h16x8*)(p.d_feat + rowv[u] * p.D + 8 * cg) = o8;
+            }
+            for (int o = 1; o < lpr; o <<= 1) acc += __shfl_xor(acc, o);
+            if (cg == 0 && ok[u]) dsem[k0 + u * rpi] = acc;
           }
         }
-        for (int o = 1; o < lpr; o <<= 1) acc += __shfl_xor(acc, o);
-        if (cg == 0) dsem[k] = acc;
+      } else {
+        for (int k = rg; k < S; k += rpi) {   // S % rpi == 0 is not required: k only feeds loads and the final store
+          const size_t row = row_of(ray, k, p.N, p.S1, p.S2);
+          float acc = 0.f;
+          for (int ch = cg; ch < nch_l; ch += lpr) {
+            const h16x8 v = *(const h16x8*)(p.logits + row * p.Cpad + 8 * ch);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)v[j] * gs[8 * ch + j];
+          }
+          for (int ch = cg; ch < nch_f; ch += lpr) {
+            const h16x8 v = *(const h16x8*)(p.feat + row * p.D + 8 * ch);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)v[j] * gf[8 * ch + j];
+          }
+          if (p.d_logits || p.d_feat) {
+            const float w = p.w_row[row];
+            for (int ch = cg; ch < nch_l && p.d_logits; ch += lpr) {
+              h16x8 o8;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { o8[j] = (h16)(w * gs[8 * ch + j]); bad |= !(fabsf((float)o8[j]) <= 65504.f); }
+              *(h16x8*)(p.d_logits + row * p.Cpad + 8 * ch) = o8;
+            }
+            for (int ch = cg; ch < nch_f && p.d_feat; ch += lpr) {
+              h16x8 o8, fv;
+              if (p.mask_feat) fv = *(const h16x8*)(p.feat + row * p.D + 8 * ch);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                o8[j] = (p.mask_feat && !((float)fv[j] > 0.f)) ? (h16)0.f : (h16)(w * gf[8 * ch + j]);
+                bad |= !(fabsf((float)o8[j]) <= 65504.f);
+              }
+              *(h16x8*)(p.d_feat + row * p.D + 8 * ch) = o8;
+            }
+          }
+          for (int o = 1; o < lpr; o <<= 1) acc += __shfl_xor(acc, o);
+          if (cg == 0) dsem[k] = acc;
+        }
       }
       __syncthreads();
     }
-    for (int k = lane; k < S; k += 64) {
-      int id = p.perm[(size_t)ray * S + k];
-      size_t row = row_of(ray, id, p.N, p.S1, p.S2);
-      float w = p.w_row[row];
-      float dw = -p.bg * (gi0 + gi1 + gi2) + p.z[row] * gd;
-      if (rowmajor_dots) dw += dsem[id];
-      int ci = p.cidx_row[row];
-      if (ci >= 0) {
-        h16x4 o = *(const h16x4*)(p.color_out + (size_t)ci * 16);
-        float r0 = 1.f / (1.f + expf(-(float)o[0])), r1 = 1.f / (1.f + expf(-(float)o[1])), r2 = 1.f / (1.f + expf(-(float)o[2]));
-        dw += r0 * gi0 + r1 * gi1 + r2 * gi2;
-        h16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = lo;
-        lo[0] = (h16)(w * gi0 * r0 * (1.f - r0)); lo[1] = (h16)(w * gi1 * r1 * (1.f - r1)); lo[2] = (h16)(w * gi2 * r2 * (1.f - r2));
-        bad |= !(fabsf((float)lo[0]) <= 65504.f) | !(fabsf((float)lo[1]) <= 65504.f) | !(fabsf((float)lo[2]) <= 65504.f);
-        *(h16x8*)(p.d_color_out + (size_t)ci * 16) = lo;
-        *(h16x8*)(p.d_color_out + (size_t)ci * 16 + 8) = hi;
+    const int nit = (S + 63) >> 6;
+    const bool keep = nit <= CB_KU;    // part 3 visits the rows of part 2: its operands are requested here when they fit the registers
+    size_t krow[CB_KU]; float kdel[CB_KU], kT[CB_KU], ksig[CB_KU], kh0[CB_KU];
+    for (int i0 = 0; i0 < nit; i0 += CB_KU) {
+      int id[CB_KU]; size_t rowv[CB_KU]; bool ok[CB_KU]; float wv[CB_KU], zv[CB_KU]; int ci[CB_KU]; h16x4 ov[CB_KU];
+#pragma unroll
+      for (int u = 0; u < CB_KU; ++u) {
+        const int k = lane + 64 * (i0 + u);
+        ok[u] = k < S;
+        id[u] = ok[u] ? (int)p.perm[(size_t)ray * S + k] : 0;
       }
-      dws[k] = dw; P[k] = dw * w;
+#pragma unroll
+      for (int u = 0; u < CB_KU; ++u) {
+        rowv[u] = row_of(ray, id[u], p.N, p.S1, p.S2);
+        wv[u] = ok[u] ? p.w_row[rowv[u]] : 0.f;
+        zv[u] = ok[u] ? p.z[rowv[u]] : 0.f;
+        ci[u] = ok[u] ? p.cidx_row[rowv[u]] : -1;
+        if (keep) {
+          krow[u] = rowv[u];
+          kdel[u] = ok[u] ? p.delta_row[rowv[u]] : 0.f; kT[u] = ok[u] ? p.T_row[rowv[u]] : 0.f;
+          ksig[u] = ok[u] ? p.sigma[rowv[u]] : 0.f; kh0[u] = ok[u] ? (float)p.sigma_out[rowv[u] * 16] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CB_KU; ++u) { ov[u] = (h16x4){0, 0, 0, 0}; if (ci[u] >= 0) ov[u] = *(const h16x4*)(p.color_out + (size_t)ci[u] * 16); }
+#pragma unroll
+      for (int u = 0; u < CB_KU; ++u) {
+        if (!ok[u]) continue;
+        const int k = lane + 64 * (i0 + u);
+        const float w = wv[u];
+        float dw = -p.bg * (gi0 + gi1 + gi2) + zv[u] * gd;
+        if (rowmajor_dots) dw += dsem[id[u]];
+        if (ci[u] >= 0) {
+          const h16x4 o = ov[u];
+          float r0 = 1.f / (1.f + expf(-(float)o[0])), r1 = 1.f / (1.f + expf(-(float)o[1])), r2 = 1.f / (1.f + expf(-(float)o[2]));
+          dw += r0 * gi0 + r1 * gi1 + r2 * gi2;
+          h16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = lo;
+          lo[0] = (h16)(w * gi0 * r0 * (1.f - r0)); lo[1] = (h16)(w * gi1 * r1 * (1.f - r1)); lo[2] = (h16)(w * gi2 * r2 * (1.f - r2));
+          bad |= !(fabsf((float)lo[0]) <= 65504.f) | !(fabsf((float)lo[1]) <= 65504.f) | !(fabsf((float)lo[2]) <= 65504.f);
+          *(h16x8*)(p.d_color_out + (size_t)ci[u] * 16) = lo;
+          *(h16x8*)(p.d_color_out + (size_t)ci[u] * 16 + 8) = hi;
+        }
+        dws[k] = dw; P[k] = dw * w;
+      }
     }
     __syncthreads();
     scan_suffix_excl(P, R, S, lane);
     __syncthreads();
-    for (int k = lane; k < S; k += 64) {
-      int id = p.perm[(size_t)ray * S + k];
-      size_t row = row_of(ray, id, p.N, p.S1, p.S2);
-      float delta = p.delta_row[row], T = p.T_row[row];
-      float om = expf(-delta * p.density_scale * p.sigma[row]);  // 1 - alpha
+    auto finish = [&](int k, size_t row, float delta, float T, float sg, float h0) {
+      float om = expf(-delta * p.density_scale * sg);  // 1 - alpha
       float dsig = delta * p.density_scale * om * (dws[k] * T - R[k] / (om + 1e-15f));
-      float h0 = (float)p.sigma_out[row * 16];
       float g = dsig * expf(fminf(fmaxf(h0, -15.f), 15.f));
       bad |= !(fabsf(g) <= 65504.f);
       p.d_h0[row] = g;
+    };
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < CB_KU; ++u) { const int k = lane + 64 * u; if (k < S) finish(k, krow[u], kdel[u], kT[u], ksig[u], kh0[u]); }
+    } else {
+      for (int k = lane; k < S; k += 64) {
+        int id = p.perm[(size_t)ray * S + k];
+        size_t row = row_of(ray, id, p.N, p.S1, p.S2);
+        finish(k, row, p.delta_row[row], p.T_row[row], p.sigma[row], (float)p.sigma_out[row * 16]);
+      }
     }
     __syncthreads();
   }
