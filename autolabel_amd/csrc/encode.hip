@@ -374,7 +374,9 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
 #define BIN_MAX_SLICES 64       // slices per level (2^19 entries / 8192)
 #define BIN_CHUNK (BIN_TILE * 8)   // records per (tile, level) chunk of the pool
 #define BIN_MAX_SHIFT 11        // largest per-tile up-scaling of the fp16 record values
-#define BIN_DEDUPE_LEVELS 8     // levels below this run the in-wave run-dedupe (finer: consecutive samples practically never share a cell)
+#ifndef BIN_DEDUPE_LEVELS
+#define BIN_DEDUPE_LEVELS 8
+#endif                          // levels below this run the in-wave run-dedupe (finer: consecutive samples practically never share a cell)
 
 // entries per slice of a level = 2^slice_log2: the level is cut into at most BIN_MAX_SLICES slices of at most BIN_SLICE entries
 static inline int bin_slice_log2(uint32_t size) {
@@ -391,6 +393,8 @@ struct BinParams {
   uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  DESC_START | DESC_COUNT | DESC_SHIFT
   int ntiles;
   int rows1, stride2; // rows [0, rows1) use p.rays_stride samples per ray, the rest stride2 (coarse + fine pass in one launch)
+  const uint16_t* perm;   // optional [rays][stride1 + stride2]: sample ids of a ray in depth order (sampling.hip) -- the tile then walks the
+                          // samples in that order, so the coarse and the fine samples of one cell form ONE run of the in-wave dedupe
   uint8_t slice_log2[ALN_MAX_LEVELS];
 };
 
@@ -416,8 +420,13 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   // resident blocks of an XCD thrash its 4 MB L2 between two levels.  Staging all 16 levels at once costs 32 KB and a block per CU.)
   if (tid < 2 * BIN_MAX_SLICES) cnt[0][tid] = 0;
   if (tid < 2) vmax_s[tid] = 0u;
-  const int row = row0 + tid;
-  const bool valid = row < p.rows;
+  const bool valid = row0 + tid < p.rows;
+  int row = row0 + tid;
+  if (b.perm && valid) {   // position row0 + tid of the depth-ordered walk -> sample row (pass-major layout)
+    const int S1 = p.rays_stride, S = S1 + b.stride2, ray = row / S;
+    const int id = b.perm[row];
+    row = id < S1 ? ray * S1 + id : b.rows1 + ray * b.stride2 + (id - S1);
+  }
   float x[3] = {0, 0, 0}, xn[3];
   if (valid) bin_row_position(b, row, x);
   normalize_pos(x, p.e.bound, true, xn);
@@ -647,8 +656,8 @@ extern "C" int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t r
 
 extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
                                      const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
-                                     const void* d_enc, float* grad_table, void* ws, int32_t level_lo, int32_t level_hi,
-                                     int32_t* found_inf, void* stream) {
+                                     const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
+                                     int32_t level_hi, int32_t* found_inf, void* stream) {
   BinParams b;
   if (int rc = fill_params(b.p, e, nullptr, rays_o, rays_d, z, xyz, rows, stride1)) return rc;
   if (rows == 0 || !e->use_grid) return 0;
@@ -656,12 +665,15 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
               level_lo, level_hi);
   ALN_REQUIRE(d_enc && grad_table && ws, "encode_bwd_binned: NULL pointer");
   ALN_REQUIRE(0 <= rows_pass1 && rows_pass1 <= rows && (rows_pass1 == rows || stride2 > 0), "encode_bwd_binned: bad pass split");
+  ALN_REQUIRE(!perm || (!xyz && stride1 > 0 && rows_pass1 % stride1 == 0 && rows_pass1 < rows &&
+                        (int64_t)(rows_pass1 / stride1) * (stride1 + stride2) == rows),
+              "encode_bwd_binned: a depth order needs the two-pass row layout (rays x stride1, then rays x stride2)");
   ALN_REQUIRE(e->grid.log2_hashmap_size <= BIN_SLICE_LOG2 + 6, "encode_bwd_binned: tables above 2^19 entries are not supported");
   if (level_lo == level_hi) return 0;
   const int ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
   b.p.level_lo = level_lo; b.p.level_hi = level_hi;
   b.d_enc = (const h16*)d_enc; b.ntiles = ntiles; b.rows1 = rows_pass1; b.stride2 = stride2 > 0 ? stride2 : 1;
-  b.pool = (uint2*)ws;
+  b.pool = (uint2*)ws; b.perm = perm;
   b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * BIN_CHUNK * sizeof(uint2));
   AccParams a;
   for (int l = 0; l < ALN_MAX_LEVELS; ++l) b.slice_log2[l] = a.slice_log2[l] = (uint8_t)(l < nl ? bin_slice_log2(e->grid.size[l]) : 0);

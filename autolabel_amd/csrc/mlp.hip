@@ -236,8 +236,8 @@ __device__ inline bool nan_bad(h16x2 acc) { return !((float)acc[0] == 0.f) || !(
 enum { SRC_PLAIN = 0, SRC_SEMF_IN = 1, SRC_SEMO_IN = 2, SRC_DLOGITS = 3, SRC_DSEMF_OUT = 4, SRC_COLOR_IN = 5 };
 struct RowSrc {
   int mode;
-  const h16* a; int lda;      // PLAIN: x ; SEMF_IN: sigma_out (ld 16) ; SEMO_IN / DSEMF_OUT: f (ld D)
-  const h16* b; int ldb;      // SEMO_IN: sigma_out ; DSEMF_OUT: d_semo_in
+  const h16* a; int lda;      // PLAIN: x ; SEMF_IN: sigma_out (ld 16) ; SEMO_IN: f (ld D)
+  const h16* b; int ldb;      // SEMO_IN: sigma_out ; DSEMF_OUT: d_semo_in (its first D columns = dL/df, ReLU mask applied)
   const float* w_row; const float* g;   // DLOGITS / DSEMF_OUT: per-row weight, per-ray output gradient [N, gw]
   int N, S1, S2, D, G, gw;
   const int* idx;             // COLOR_IN: live_idx (compact row -> sample row) or NULL; b = sigma_out, g = directions
@@ -277,10 +277,9 @@ __device__ inline h16x8 load_chunk8(const RowSrc& s, int row, int c0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (h16)((c0 + j < s.gw) ? w * g[c0 + j] : 0.f);
       } else {
-        h16x8 f = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
-        h16x8 d = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);
+        h16x8 d = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);   // d(semantic_out) / d f, ReLU mask applied by its producer
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (h16)(w * g[c0 + j] + ((float)f[j] > 0.f ? (float)d[j] : 0.f));
+        for (int j = 0; j < 8; ++j) o[j] = (h16)(w * g[c0 + j] + (float)d[j]);
       }
       return o;
     }
@@ -340,10 +339,7 @@ __device__ inline void raw_load(RawChunk& r, const RowSrc& s, int row, int c0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) r.g[j] = (c0 + j < s.gw) ? g[c0 + j] : 0.f;
     }
-    if constexpr (MODE == SRC_DSEMF_OUT) {
-      r.a = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
-      r.b = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);
-    }
+    if constexpr (MODE == SRC_DSEMF_OUT) r.b = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);
   }
 }
 __device__ inline h16x8 geo_from(const h16x8& lo, const h16x8& hi, int j0, int G) {   // geo_chunk on loaded registers
@@ -383,7 +379,7 @@ __device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
       for (int j = 0; j < 8; ++j) o[j] = (h16)((c0 + j < s.gw) ? r.w * gl[j] : 0.f);
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (h16)(r.w * gl[j] + ((float)r.a[j] > 0.f ? (float)r.b[j] : 0.f));
+      for (int j = 0; j < 8; ++j) o[j] = (h16)(r.w * gl[j] + (float)r.b[j]);
     }
     return o;
   }
@@ -1095,6 +1091,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
                     if constexpr (FOLD) ov += (float)skip[u][q < 2 ? q : 0][r];
                     v[r] = (h16)ov;
                   }
+                  if constexpr (XM == SRC_SEMO_IN) {   // columns [0, D) are relu(f): hand dL/df on (the x tile holds relu(f))
+                    if (f < xs.D) {
+                      const h16x4 xm = *(const LDS_VEC(h16x4)*)(tX0 + (srow0 + 32 * u) * PX0 + f);
+#pragma unroll
+                      for (int r = 0; r < 4; ++r) v[r] = (float)xm[r] > 0.f ? v[r] : (h16)0.f;
+                    }
+                  }
                   nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
                   *(h16x4*)(d_in + (size_t)row * IN + f) = v;
                 }
@@ -1510,7 +1513,7 @@ extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
   RowSrc go{}; go.mode = SRC_DLOGITS; go.w_row = w_row; go.g = g_sem; go.gw = C; go.N = N; go.S1 = S1; go.S2 = S2 > 0 ? S2 : 1;
   if (int rc = mlp_bwd_recomp_src(semo, xo, go, rows, nullptr, d_semo_in, dW_semo, found_inf, s)) return rc;
   RowSrc xf{}; xf.mode = SRC_SEMF_IN; xf.a = (const h16*)sigma_out; xf.lda = 16; xf.G = G; xf.D = D;
-  RowSrc gf{}; gf.mode = SRC_DSEMF_OUT; gf.a = (const h16*)feat; gf.lda = D; gf.b = (const h16*)d_semo_in; gf.ldb = semo->in_pad;
+  RowSrc gf{}; gf.mode = SRC_DSEMF_OUT; gf.b = (const h16*)d_semo_in; gf.ldb = semo->in_pad;
   gf.w_row = w_row; gf.g = g_feat; gf.gw = D; gf.N = N; gf.S1 = S1; gf.S2 = S2 > 0 ? S2 : 1; gf.D = D; gf.fold_geo = fold_geo;
   return mlp_bwd_recomp_src(semf, xf, gf, rows, nullptr, d_semf_in, dW_semf, found_inf, s);
 }

@@ -59,7 +59,7 @@ _SIGS = {
     'aln_encode_fwd_cells': (i32, [vp, vp, i32, u32, u32, vp, i32, i32, vp, vp, vp]),
     'aln_encode_bwd_binned_ws_bytes': (i64, [vp, i32]),
     'aln_encode_bwd_binned_tile_rows': (i32, []),
-    'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp]),
+    'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp]),
     'aln_wide_nt': (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp]),
     'aln_wide_tn': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp]),
     'aln_transpose_f16': (i32, [vp, i32, i32, vp, vp]),

@@ -600,8 +600,9 @@ class HipPipeline:
         bins = ws.scratch('enc_bwd_bins', H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M))
         F = int(e.grid.n_features)
         for lo, hi in (level_groups or [(0, nl)]):
-            self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1), H.ptr(d_enc),
-                    H.ptr(P.grad), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi, H.stream(),
+            # (two passes: the tiles walk every ray in depth order, so coarse and fine samples of one cell dedupe into one record)
+            self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
+                    H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(P.grad), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi, H.stream(),
                     tag=(M, hi - lo))
             if on_grad_ready is not None and level_groups is not None:
                 a = int(e.grid.offset[lo]) * F

@@ -153,7 +153,8 @@ int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, int32_t G, 
 int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows);
 int32_t aln_encode_bwd_binned_tile_rows(void);   /* sample rows per phase-1 tile (layout of ws: pool chunks of 8 x tile records, then descriptors) */
 int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
-                          int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2, const void* d_enc,
+                          int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2,
+                          const uint16_t* depth_order /* optional [rays, stride1 + stride2] */, const void* d_enc,
                           float* grad_table, void* ws, int32_t level_lo, int32_t level_hi, int32_t* found_inf, void* stream);
 
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
@@ -184,7 +185,9 @@ int32_t aln_mlp_bwd_blocks(const AlnMlpDesc* m, int32_t rows);
 int aln_mlp_dw_reduce_all(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, void* stream);
 
 /* Both semantic heads (models.py:248-256) with their inputs / output gradients built on the fly from sigma_out, f, the
- * compositing weights and the per-ray output gradients (no [rows,80] / [rows,64] intermediates in HBM). */
+ * compositing weights and the per-ray output gradients (no [rows,80] / [rows,64] intermediates in HBM).
+ * d_semo_in [rows, D + 16]: columns [0, D) = dL/df of the semantic_out branch (the ReLU mask of cat[relu(f), geo_feat] applied),
+ * columns [D, D + 16) = its dL/d(geo_feat, 1). */
 int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, int32_t rows, int32_t D, int32_t G,
                       void* feat, void* logits, void* stream);
 int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat, const float* w_row,

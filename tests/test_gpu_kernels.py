@@ -211,10 +211,19 @@ def test_encode_fwd_bit_exact_grid(H, encoding, L):
         assert (got[:, :fd].float() - want[:, :fd].float()).abs().max() <= 1e-3
 
 
-def _binned_bwd(H, e, ro, rd, z, rows, rows1, s1, s2, d_enc, grad, lo=0, hi=None, flag=None):
-    ws = torch.empty(max(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), 16), dtype=torch.uint8, device='cuda')
-    H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows1, s1, s2, H.ptr(d_enc), H.ptr(grad),
-           H.ptr(ws), lo, int(e.grid.n_levels) if hi is None else hi, H.ptr(flag), H.stream())
+def _binned_bwd(H, e, ro, rd, z, rows, rows1, s1, s2, d_enc, grad, lo=0, hi=None, flag=None, perm=None, ws=None):
+    if ws is None:
+        ws = torch.empty(max(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), 16), dtype=torch.uint8, device='cuda')
+    H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows1, s1, s2, H.ptr(perm), H.ptr(d_enc),
+           H.ptr(grad), H.ptr(ws), lo, int(e.grid.n_levels) if hi is None else hi, H.ptr(flag), H.stream())
+
+
+def _record_count(H, e, ws, rows):
+    tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
+    nl, nt = int(e.grid.n_levels), (rows + tile - 1) // tile
+    pool = nl * nt * tile * 8 * 8
+    desc = ws[pool:pool + nl * 64 * nt * 4].view(torch.int32)
+    return int(((desc >> 13) & 0x3FFF).sum().item())
 
 
 def _grid_grad_reference(cfg, ro, rd, z_rows, ray_of_row, d_enc, bound):
@@ -296,6 +305,44 @@ def test_binned_encode_backward_matches_oracle(H, N, S):
     again = torch.zeros_like(grad)
     _binned_bwd(H, e, ro.cuda(), rd.cuda(), z.cuda().reshape(-1), rows, rows, S, S, d_enc.cuda(), again)
     assert torch.equal(again, grad), 'every level must be bit-reproducible'
+
+
+def test_binned_encode_backward_in_depth_order_same_gradient_fewer_records(H):
+    """With the rays' depth order (sampling.hip's perm) the phase-1 tiles walk coarse and fine samples interleaved, so the samples
+    of one cell form one run: the gradient is the one of the pass-major walk up to the fp16 rounding of the run sums (any walk
+    order is valid), with fewer records; bit-reproducible; and an arbitrary permutation is as good as the sorted one."""
+    bound = 2.0
+    e = H.make_enc_desc('hg+freq', bound)
+    N, S1, S2 = 300, 32, 32
+    S, M1, M = S1 + S2, N * S1, N * (S1 + S2)
+    g = torch.Generator().manual_seed(21)
+    ro = ((torch.rand(N, 3, generator=g) - 0.5) * bound).cuda()
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()
+    zc, zf = torch.rand(N, S1, generator=g).sort(dim=1)[0] * 4, torch.rand(N, S2, generator=g).sort(dim=1)[0] * 4
+    z = torch.cat([zc.reshape(-1), zf.reshape(-1)]).cuda().contiguous()
+    order = torch.cat([zc, zf], 1).argsort(dim=1, stable=True).to(torch.int16).cuda().contiguous()     # ids < S1: coarse sample, else fine
+    d_enc = torch.zeros(M, e.enc_pad, dtype=torch.float16, device='cuda')
+    d_enc[:, 12:44] = (torch.randn(M, 32, generator=g) * 0.05).half().cuda()
+    n = int(e.grid.n_entries) * 2
+    ray_of_row = torch.cat([torch.arange(N, device='cuda').repeat_interleave(S1), torch.arange(N, device='cuda').repeat_interleave(S2)])
+    ref = _grid_grad_reference(O.ModelConfig(bound=bound), ro, rd, z, ray_of_row, d_enc, bound)
+    ws = torch.empty(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M)), dtype=torch.uint8, device='cuda')
+    plain, walk, again, shuffled = (torch.zeros(n, device='cuda') for _ in range(4))
+    _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, plain, ws=ws)
+    n_plain = _record_count(H, e, ws, M)
+    _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, walk, perm=order, ws=ws)
+    n_walk = _record_count(H, e, ws, M)
+    _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, again, perm=order, ws=ws)
+    assert torch.equal(walk, again)
+    assert (walk - ref).norm().item() <= 1e-3 * ref.norm().item()
+    assert (walk - plain).norm().item() <= 1e-3 * ref.norm().item()
+    assert not ((walk != 0) & (ref == 0)).any()
+    assert n_walk < n_plain, (n_walk, n_plain)
+    rnd = torch.stack([torch.randperm(S, generator=g) for _ in range(N)]).to(torch.int16).cuda().contiguous()
+    _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, shuffled, perm=rnd, ws=ws)
+    assert (shuffled - ref).norm().item() <= 1e-3 * ref.norm().item()
+    with pytest.raises(RuntimeError):   # a depth order needs the two-pass layout
+        _binned_bwd(H, e, ro, rd, z, M, M, S, S, d_enc, shuffled, perm=rnd, ws=ws)
 
 
 def test_binned_encode_backward_two_passes_and_level_groups(H):
