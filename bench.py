@@ -217,8 +217,11 @@ def scatter_roofline(eng, events, rows_per_step, n_event_steps):
             'avg_launch_us': avg_s * 1e6, 'launches': len(durs), 'rows_per_launch': rows_per_step, 'algorithmic_bytes_per_launch': alg,
             'records_per_launch': records, 'record_bytes': 8, 'record_traffic_bytes_per_launch': rec_bytes,
             'records_per_s': records / avg_s if records else None,
-            'limiter': 'not HBM bandwidth: phase 1 is bound by LDS atomics / barriers per level (instruction issue), phase 2 by the latency of '
-                       '512-byte record runs (lines in flight per CU) and the fp16 -> 64-bit fixed-point decode (VALU); see DESIGN.md 4.1',
+            'limiter': 'not HBM bandwidth: phase 1 costs the same ~23 us per level whether the level leaves 0.6 M or 8.4 M records '
+                       '(per-level trace in DESIGN.md 4.1): fixed work per (tile, level) -- corner indices / weights / run merge (VALU) and '
+                       'the LDS sort (random LDS accesses run at ~6 lanes/clk/CU), about half each; phase 2 sustains 1.4 G records/s per CU '
+                       '= ~10 GB/s per CU of 512-byte record runs (2.5 TB/s over the chip) with the fp16 -> 64-bit fixed-point decode and two '
+                       'LDS atomics per record overlapped underneath',
             'note': 'HIP events around the launch pair over %d launch-by-launch steps right after the timed region (the timed region itself '
                     'replays a hipGraph, which cannot carry events); phase 1 sorts fp16x2 (index, value) records by table slice in LDS and '
                     'streams them out (8 B/record), phase 2 streams them back and accumulates in 64-bit fixed point in LDS: no global '

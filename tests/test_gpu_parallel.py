@@ -224,3 +224,29 @@ def test_two_ranks_on_half_batches_equal_one_process_on_the_full_batch():
             assert flag == 0 and rel <= 1e-3 and rel_mlp <= 1e-5, (rank, 'f16', overlap, rel, rel_mlp)
             assert nbytes16 < 0.51 * nbytes      # the hash-grid block crosses the wire as halves
         assert r['overflow_flag'] == 1
+
+
+def test_bench_contract_with_two_ranks_sharing_the_device():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with gloo carrying the
+    collectives so that both ranks can share this box's single GPU: the barrier / max-over-ranks timing, the frame shards, the
+    data-parallel step (launch by launch, overlapped buckets, fp16 payload) and the ONE JSON line of rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALN_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+           '--batch', '512', '--no-cpu-baseline', '--no-pmc', '--no-march', '--no-lseg', '--quality-steps', '0', '--render-frames', '0',
+           '--event-steps', '0']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 2 and d['scaling'] == 'weak'
+    assert d['n_ranks_seen'] == 2 and d['value'] > 0 and d['higher_is_better'] is True
+    assert abs(d['value'] - 2 * 512 * 4 / (d['ms_per_step'] * 4e-3)) <= 1e-6 * d['value'], 'value = rays of ALL ranks / max-over-ranks time'
+    assert d['config']['gradient_exchange_bytes_per_rank_and_step'] > 0 and d['config']['parallelism'] == 'dp2'
