@@ -18,7 +18,8 @@
 //                                     (0 = block inactive), c[5+2b] = 1/sqrt(bc2_b)
 #define ADAM_MAX_BLOCKS 8
 struct AdamHyper { float lr, beta1, beta2, eps, wd_net, growth, backoff; int growth_interval; double log_beta1, log_beta2; };
-struct AdamBlocks { int n; long long end[ADAM_MAX_BLOCKS]; int needs_sem[ADAM_MAX_BLOCKS]; int needs_sem_or_feat[ADAM_MAX_BLOCKS]; int feat_on; };
+struct AdamBlocks { int n; long long end[ADAM_MAX_BLOCKS]; int needs_sem[ADAM_MAX_BLOCKS]; int needs_sem_or_feat[ADAM_MAX_BLOCKS]; int feat_on;
+                    int skip_grid; };   // skip_grid: block 0 was updated by phase 2 of the hash-grid scatter (encode.hip, AccAdam)
 
 // The step constants (skip flag, 1 / loss scale, per-block step size and bias correction) are a pure function of the state words
 // as they stand BEFORE this step; every block derives them itself (one thread, a handful of pow() in double) instead of waiting
@@ -36,6 +37,7 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
                        AdamBlocks blk, const int* counts, uint32_t* step_dev) {
   __shared__ AdamConsts cs;
   const size_t vec_end = (blk.n > 0 && (size_t)blk.end[0] <= n_grid) ? ((size_t)blk.end[0] & ~(size_t)3) : 0;
+  const size_t vec_lo = blk.skip_grid ? vec_end / 4 : 0;     // (skip_grid: nothing of block 0 is touched, not even its zero gradient)
   {   // lane b derives the constants of parameter block b (the lanes work side by side); all state words in ONE round trip
     const int b = threadIdx.x & (ADAM_MAX_BLOCKS - 1);
     const int found = si[2], t0 = si[4 + b], lab = counts ? counts[1] : 1;
@@ -68,7 +70,7 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     const float step_size = r_step[0], inv_sqrt_bc2 = r_isb[0];
     const bool idle = skip || step_size == 0.f;
     const float b1 = h.beta1, b2 = h.beta2, c1 = 1.f - h.beta1, c2 = 1.f - h.beta2;
-    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < vec_end / 4; q += (size_t)gridDim.x * blockDim.x) {
+    for (size_t q = vec_lo + blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < vec_end / 4; q += (size_t)gridDim.x * blockDim.x) {
       const float4 g4 = ((const float4*)g)[q];
       float4 p4, m4, v4;
       if (!idle) { p4 = ((const float4*)p)[q]; m4 = ((const float4*)m)[q]; v4 = ((const float4*)v)[q]; }
@@ -93,7 +95,7 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     }
   }
   // the rest (MLP weights, a ragged grid tail): one parameter per lane, block looked up per element
-  for (size_t i = vec_end + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (blk.skip_grid ? (size_t)blk.end[0] : vec_end) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
     g[i] = 0.f;
     if (skip) continue;
@@ -144,7 +146,7 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
                              int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
                              float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
                              int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
-                             const int32_t* counts, uint32_t* step_dev, void* stream) {
+                             int32_t skip_grid, const int32_t* counts, uint32_t* step_dev, void* stream) {
   ALN_REQUIRE(params && grads && m && v && state_i && state_f, "adam: NULL pointer");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
   ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
@@ -158,7 +160,10 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
     for (int b = 0; b < n_blocks; ++b) { blk.end[b] = block_end[b]; blk.needs_sem[b] = block_kind[b] == 1; blk.needs_sem_or_feat[b] = block_kind[b] == 2; }
   }
   blk.feat_on = feature_loss;
-  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_total, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
+  ALN_REQUIRE(!skip_grid || (n_blocks > 0 && block_end[0] == n_grid), "adam: skip_grid needs the table as parameter block 0");
+  blk.skip_grid = skip_grid ? 1 : 0;
+  const int64_t n_work = skip_grid ? n_total - n_grid : n_total;
+  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_work > 0 ? n_work : 1, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
                      (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, counts, step_dev);
   ALN_CHECK_LAUNCH("adam");
   return 0;

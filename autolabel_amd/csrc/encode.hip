@@ -365,15 +365,17 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
 #define BIN_TILE 512            // sample rows per phase-1 block (= threads: lane = sample, so runs along a ray dedupe in-wave); -DBIN_TILE=1024
                                 // (1 KB runs for phase 2) measured: dense pair 771 -> 806 us, marching 265 -> 260 us: no gain
 #endif
-// descriptor word: start (13 bits) | count << 13 (14 bits) | shift << 27
+// descriptor word: start (13 bits) | count << 13 (14 bits) | (shift + BIN_SHIFT_BIAS) << 27
 #define DESC_START(q) ((q) & 0x1FFFu)
 #define DESC_COUNT(q) (((q) >> 13) & 0x3FFFu)
-#define DESC_SHIFT(q) ((q) >> 27)
+#define BIN_SHIFT_BIAS 8
+#define BIN_MIN_SHIFT (-8)      // a run sums <= 64 products of magnitude <= 65504: below 2^23, so scaling down by 2^8 always fits fp16
+#define DESC_SHIFT(q) ((int)((q) >> 27) - BIN_SHIFT_BIAS)
 #define BIN_SLICE_LOG2 13       // largest slice: 8192 table entries (x 2 features x 8 B = 128 KB of LDS accumulators in phase 2)
 #define BIN_SLICE (1 << BIN_SLICE_LOG2)
 #define BIN_MAX_SLICES 64       // slices per level (2^19 entries / 8192)
 #define BIN_CHUNK (BIN_TILE * 8)   // records per (tile, level) chunk of the pool
-#define BIN_MAX_SHIFT 11        // largest per-tile up-scaling of the fp16 record values
+#define BIN_MAX_SHIFT 11        // largest per-tile up-scaling of the fp16 record values (BIN_MIN_SHIFT: largest down-scaling)
 #ifndef BIN_DEDUPE_LEVELS
 #define BIN_DEDUPE_LEVELS 8
 #endif                          // levels below this run the in-wave run-dedupe (finer: consecutive samples practically never share a cell)
@@ -482,8 +484,10 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
       }
     }
     // records of this lane (run heads only).  Values travel as fp16x2 scaled by 2^e, e = per (tile, level) exponent chosen so
-    // that the largest |value| of the tile lands in [2^14, 2^15) (0 <= e <= BIN_MAX_SHIFT; never scaled down): tiny products
-    // w * g keep their bits instead of flushing at the fp16 denormal step.  An overflow shows up as inf -> found_inf.
+    // that the largest |value| of the tile lands in [2^14, 2^15) (BIN_MIN_SHIFT <= e <= BIN_MAX_SHIFT): tiny products w * g keep
+    // their bits instead of flushing at the fp16 denormal step, and a run sum beyond the fp16 range (64 samples of one cell at
+    // the largest loss scales) is scaled down instead of overflowing -- a record is non-finite only if d_enc was, and then
+    // the producer of d_enc has raised found_inf before this kernel started (what lets phase 2 apply the optimizer itself).
     float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
@@ -503,14 +507,14 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
       base[lane] = inc - np;
       cnt[par][lane] = 0;
       const int ex = (int)((vmax_s[par] >> 23) & 0xFFu) - 127;          // floor(log2(max)); inf / huge -> large -> shift 0
-      const int sh = min(max(14 - ex, 0), BIN_MAX_SHIFT);
-      if (lane == 63) { total_s = inc; shift_s = sh; }
-      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - np) | (n << 13) | ((uint32_t)sh << 27);
+      const int sh = min(max(14 - ex, BIN_MIN_SHIFT), BIN_MAX_SHIFT);
+      if (lane == 63) { total_s = inc; shift_s = (uint32_t)(sh + BIN_SHIFT_BIAS); }
+      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - np) | (n << 13) | ((uint32_t)(sh + BIN_SHIFT_BIAS) << 27);
     }
     __syncthreads();
     if (tid == 0) vmax_s[par] = 0u;    // next use: level l + 2, two barriers away from any reader
     if (emit) {
-      const float sc = __uint_as_float((uint32_t)(127 + shift_s) << 23);   // 2^shift
+      const float sc = __uint_as_float((uint32_t)(127 - BIN_SHIFT_BIAS + shift_s) << 23);   // 2^shift
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         h16x2 hv; hv[0] = (h16)(v[2 * c] * sc); hv[1] = (h16)(v[2 * c + 1] * sc);
@@ -527,8 +531,17 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   }
 }
 
+// Optimizer fused into phase 2 (single-GPU training): the block that owns a slice holds its exact gradient sums in LDS, so it
+// applies Adam to those entries itself -- the gradient never goes to HBM and comes back (16 of the 34 bytes per parameter the
+// separate kernel moves).  Same arithmetic, in the same order, as k_adam (adam.hip); the step constants are derived from the
+// optimizer state words as they stand before the step (k_adam, launched afterwards for the MLP blocks, advances them).
+struct AccAdam {
+  float* p; float* m; float* v; h16* t16;      // master parameters, moments, fp16 shadow of the table (NULL p = off)
+  const int* si; const float* sf;              // optimizer state (adam.hip): si[2] found_inf, si[4] steps of block 0, sf[0] scale, sf[1] lr
+  float lr, beta1, beta2, eps; double log_beta1, log_beta2;
+};
 struct AccParams {
-  const uint2* pool; const uint32_t* desc; float* grad; int32_t* found_inf;
+  const uint2* pool; const uint32_t* desc; float* grad; int32_t* found_inf; AccAdam ad;
   int ntiles, level_lo, n_levels_here;
   uint32_t blk_start[ALN_MAX_LEVELS + 1];   // first block of each launched level (levels enumerated from level_lo)
   uint32_t size[ALN_MAX_LEVELS], offset[ALN_MAX_LEVELS];
@@ -557,6 +570,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
                                            // an entry side by side, a wave's 64 slots fell onto 16 bank quads (PMC: 65 % of the
                                            // LDS cycles of this kernel were bank conflicts); a plane spreads them over 32 bank pairs
   __shared__ unsigned long long bound_s;
+  __shared__ int smin_s;
+  __shared__ float adam_c[4];   // skip, 1 / loss scale, lr / bc1, 1 / sqrt(bc2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = ACC_THREADS / 64;
   int li = 0;
   while (li + 1 < a.n_levels_here && blockIdx.x >= a.blk_start[li + 1]) ++li;
@@ -572,19 +587,30 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   // this never triggers for the hashed levels; it is what lets the two coarsest levels (thousands of records per entry at the
   // largest loss scales) share the exact path.
   const uint32_t plane = 1u << sl;   // entries per plane
-  if (tid == 0) bound_s = 0ull;
+  if (tid == 0) { bound_s = 0ull; smin_s = 0; }
+  if (a.ad.p && tid == 64) {   // (a lane of wave 1: off the critical path, needed at the flush only)
+    const int found = a.ad.si[2], t = a.ad.si[4] + 1;
+    const float lr = a.ad.sf[1] > 0.f ? a.ad.sf[1] : a.ad.lr;
+    const double bc1 = 1.0 - exp((double)t * a.ad.log_beta1), bc2 = 1.0 - exp((double)t * a.ad.log_beta2);
+    adam_c[0] = found ? 1.f : 0.f; adam_c[1] = 1.0f / a.ad.sf[0];
+    adam_c[2] = (float)((double)lr / bc1); adam_c[3] = (float)(1.0 / sqrt(bc2));
+  }
   for (uint32_t i = tid; i < ne; i += ACC_THREADS) { acc[i] = 0ll; acc[plane + i] = 0ll; }
   __syncthreads();
   {
-    unsigned long long bsum = 0ull;
-    for (int t = tid; t < a.ntiles; t += ACC_THREADS) { const uint32_t q = d[t]; const uint32_t sh = DESC_SHIFT(q); bsum += (unsigned long long)DESC_COUNT(q) << (sh ? 15u - sh : 16u); }
+    unsigned long long bsum = 0ull; int smin = 0;
+    for (int t = tid; t < a.ntiles; t += ACC_THREADS) {
+      const uint32_t q = d[t]; const int sh = DESC_SHIFT(q);
+      if (DESC_COUNT(q)) { bsum += (unsigned long long)DESC_COUNT(q) << (15 - sh); smin = min(smin, sh); }   // |record| < 2^(15 - shift)
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o);
-    if (lane == 0 && bsum) atomicAdd(&bound_s, bsum);
+    for (int o = 32; o > 0; o >>= 1) { bsum += __shfl_xor(bsum, o); smin = min(smin, __shfl_xor(smin, o)); }
+    if (lane == 0 && bsum) { atomicAdd(&bound_s, bsum); atomicMin(&smin_s, smin); }
   }
   __syncthreads();
   int U = FX_UNIT_LOG2;
-  { const unsigned long long bd = bound_s; const int lg = bd ? 64 - __clzll(bd) : 0; U = min(FX_UNIT_LOG2, 62 - lg); }   // bd < 2^lg
+  // (a tile that was scaled DOWN carries records up to 2^(16 - shift): the double-precision conversion needs them below 2^51 units)
+  { const unsigned long long bd = bound_s; const int lg = bd ? 64 - __clzll(bd) : 0; U = min(FX_UNIT_LOG2 + smin_s, 62 - lg); }   // bd < 2^lg
   const uint2* pool = a.pool + (size_t)l * a.ntiles * BIN_CHUNK;
   bool bad = false;   // a non-finite record (inf / nan upstream, or an fp16 overflow of a run sum)
   auto add = [&](uint2 r, int ex) {   // ex = U - shift of the run's tile
@@ -608,7 +634,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
 #pragma unroll
         for (int u = 0; u < ACC_RB; ++u) {
           const uint32_t q = __builtin_amdgcn_readlane(dd, (j0 + u) & 63);
-          st[buf][u] = DESC_START(q); n[buf][u] = (j0 + u < nt) ? DESC_COUNT(q) : 0u; ex[buf][u] = U - (int)DESC_SHIFT(q);
+          st[buf][u] = DESC_START(q); n[buf][u] = (j0 + u < nt) ? DESC_COUNT(q) : 0u; ex[buf][u] = U - DESC_SHIFT(q);
           const uint2* src = pool + (size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u];
 #pragma unroll
           for (int v = 0; v < ACC_LPR; ++v) {
@@ -637,8 +663,40 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     }
   }
   __syncthreads();
-  float* g = a.grad + 2 * ((size_t)a.offset[l] + e0);
+  const size_t g0 = 2 * ((size_t)a.offset[l] + e0);
   const double unit = ldexp(1.0, -U);
+  if (a.ad.p) {
+    // optimizer step for the entries of this slice: both features of an entry per lane (8-byte accesses), every entry -- torch's Adam
+    // also moves a parameter whose gradient is zero while its moments are not.  A non-finite record implies that d_enc was
+    // non-finite, i.e. si[2] was raised before this launch and every block skips alike.
+    const bool skip = adam_c[0] != 0.f;
+    const float inv_scale = adam_c[1], step_size = adam_c[2], inv_sqrt_bc2 = adam_c[3];
+    const float b1 = a.ad.beta1, b2 = a.ad.beta2, c1 = 1.f - a.ad.beta1, c2 = 1.f - a.ad.beta2, eps = a.ad.eps;
+    if (!skip) {
+      float2* const P2 = (float2*)(a.ad.p + g0); float2* const M2 = (float2*)(a.ad.m + g0); float2* const V2 = (float2*)(a.ad.v + g0);
+      h16x2* const T2 = (h16x2*)(a.ad.t16 + g0);
+      for (uint32_t e = tid; e < ne; e += ACC_THREADS) {
+        const float2 p2 = P2[e], m2 = M2[e], v2 = V2[e];
+        float gg[2] = {(float)((double)acc[e] * unit), (float)((double)acc[plane + e] * unit)};
+        float pp[2] = {p2.x, p2.y}, mm[2] = {m2.x, m2.y}, vv[2] = {v2.x, v2.y};
+        h16x2 t2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float gi = gg[k] * inv_scale;
+          const float mi = b1 * mm[k] + c1 * gi;
+          const float vi = b2 * vv[k] + c2 * gi * gi;
+          mm[k] = mi; vv[k] = vi;
+          const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+          pp[k] -= step_size * (mi / denom);
+          t2[k] = (h16)pp[k];
+        }
+        M2[e] = make_float2(mm[0], mm[1]); V2[e] = make_float2(vv[0], vv[1]); P2[e] = make_float2(pp[0], pp[1]); T2[e] = t2;
+      }
+    }
+    if (bad && a.found_inf) *a.found_inf = 1;   // (already set by the producer of d_enc; kept for a caller that feeds records of its own)
+    return;
+  }
+  float* g = a.grad + g0;
   for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) {   // g is [entry][feature]
     const long long q = acc[(i & 1u) * plane + (i >> 1)];
     if (q != 0ll) g[i] += (float)((double)q * unit);    // one rounding of the exact sum; no other block owns this entry
@@ -659,13 +717,17 @@ extern "C" int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t r
 extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
                                      const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
                                      const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
-                                     int32_t level_hi, int32_t* found_inf, void* stream) {
+                                     int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* stream) {
   BinParams b;
   if (int rc = fill_params(b.p, e, nullptr, rays_o, rays_d, z, xyz, rows, stride1)) return rc;
   if (rows == 0 || !e->use_grid) return 0;
   ALN_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= (int)e->grid.n_levels, "encode_bwd_binned: level range [%d, %d)",
               level_lo, level_hi);
-  ALN_REQUIRE(d_enc && grad_table && ws, "encode_bwd_binned: NULL pointer");
+  ALN_REQUIRE(d_enc && (grad_table || adam) && ws, "encode_bwd_binned: NULL pointer");
+  ALN_REQUIRE(!adam || (adam->params && adam->m && adam->v && adam->table_f16 && adam->state_i && adam->state_f && e->grid.n_features == 2),
+              "encode_bwd_binned: incomplete optimizer descriptor");
+  ALN_REQUIRE(!adam || ((((uintptr_t)adam->params | (uintptr_t)adam->m | (uintptr_t)adam->v) & 7) == 0 && ((uintptr_t)adam->table_f16 & 3) == 0),
+              "encode_bwd_binned: optimizer buffers must be 8-byte aligned (fp16 shadow: 4)");
   ALN_REQUIRE(0 <= rows_pass1 && rows_pass1 <= rows && (rows_pass1 == rows || stride2 > 0), "encode_bwd_binned: bad pass split");
   ALN_REQUIRE(!perm || (!xyz && stride1 > 0 && rows_pass1 % stride1 == 0 && rows_pass1 < rows &&
                         (int64_t)(rows_pass1 / stride1) * (stride1 + stride2) == rows),
@@ -682,6 +744,9 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
   hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
   ALN_CHECK_LAUNCH("encode_bwd_bin");
   a.pool = b.pool; a.desc = b.desc; a.grad = grad_table; a.found_inf = found_inf; a.ntiles = ntiles;
+  a.ad = AccAdam{};
+  if (adam) a.ad = AccAdam{adam->params, adam->m, adam->v, (h16*)adam->table_f16, adam->state_i, adam->state_f, adam->lr, adam->beta1,
+                           adam->beta2, adam->eps, log((double)adam->beta1), log((double)adam->beta2)};
   a.level_lo = level_lo; a.n_levels_here = level_hi - level_lo;
   uint32_t nblk = 0, max_entries = 1;
   for (int l = level_lo; l < level_hi; ++l) {

@@ -17,7 +17,7 @@ SCALER_DEFAULTS = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5
 class TrainEngine:
     def __init__(self, pipe, lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6, rgb_weight=1.0, depth_weight=0.1,
                  semantic_weight=1.0, feature_weight=0.5, feature_loss=False, num_steps=128, upsample_steps=128,
-                 scaler=None, process_group=None, overlap_comm=True, grad_payload='f16'):
+                 scaler=None, process_group=None, overlap_comm=True, grad_payload='f16', fuse_grid_adam=True):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
         dv = self.P.device
         # the step's intermediates live in a workspace of the engine's own: a render through the same pipeline (pipe.ws) between
@@ -56,6 +56,9 @@ class TrainEngine:
         # data parallel: the gradient all-reduce runs in buckets on a side stream while the hash-grid scatter is still
         # working on the remaining levels (the scatter is the last and longest kernel of the backward pass)
         self.overlap_comm = self.world > 1 and bool(overlap_comm)   # False: one collective after the backward pass
+        # single GPU: the scatter's second phase holds the table's exact gradient sums in LDS and takes the Adam step for the table
+        # itself (step()); with more ranks the gradient has to be averaged first, so it goes through P.grad and aln_adam_step
+        self.fuse_grid_adam = bool(fuse_grid_adam) and self.world == 1 and L.n_grid > 0 and int(L.enc.grid.n_features) == 2
         self.grad_payload = grad_payload     # 'f16': the hash-grid gradient crosses the wire as fp16 (parallel.allreduce_bucket)
         self._comm = torch.cuda.Stream(device=dv) if self.world > 1 else None
         self._g = {}
@@ -87,7 +90,9 @@ class TrainEngine:
             t = self._g[name] = torch.empty(shape, dtype=torch.float32, device=self.P.device)
         return t
 
-    def forward_backward(self, batch, seed, step, noise=None, u=None, step_dev=None):
+    def forward_backward(self, batch, seed, step, noise=None, u=None, step_dev=None, grid_adam=False):
+        """Forward, loss, backward: every gradient in P.grad afterwards -- except, with ``grid_adam`` (step() on one GPU), the hash
+        table's: its optimizer step has then been taken inside the scatter and optimizer_step(skip_grid=True) must follow."""
         L, pipe = self.L, self.pipe
         N = batch['rays_o'].shape[0]
         out, ctx = pipe.forward(batch['rays_o'], batch['rays_d'], batch['direction_norms'].reshape(-1), self.S1, self.S2, True,
@@ -110,8 +115,14 @@ class TrainEngine:
                           scatter_flag=self.state_i[3:4])
         else:
             self._reduced = False
-            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat)
+            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat, grid_adam=self._adam_fuse() if grid_adam else None)
         return out
+
+    def _adam_fuse(self):
+        P, L = self.P, self.L
+        assert self.world == 1 and self._blk_end[0] == L.n_grid and self._blk_kind[0] == 0
+        return H.AlnAdamFuse(P.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), P.table16.data_ptr(), self.state_i.data_ptr(),
+                             self.state_f.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps)
 
     def level_groups(self):
         """Hash-grid levels in scatter order: the fine (large, 4 MB each) levels first in groups of four -- one level per wave
@@ -166,12 +177,12 @@ class TrainEngine:
                 allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts, n_grid=self.L.n_grid,
                                     payload=self.grad_payload, scratch=self._wire(self.L.n_grid))
 
-    def optimizer_step(self, step_dev=None):
+    def optimizer_step(self, step_dev=None, skip_grid=False):
         P, L, sc = self.P, self.L, self.scaler_cfg
         H.call('aln_adam_step', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
                H.ptr(self.state_i), H.ptr(self.state_f), H.ptr(self.consts), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), len(self._blk_kind), self._blk_end,
-               self._blk_kind, int(bool(self.feature_loss)), H.ptr(self.counts), H.ptr(step_dev), H.stream())
+               self._blk_kind, int(bool(self.feature_loss)), int(bool(skip_grid)), H.ptr(self.counts), H.ptr(step_dev), H.stream())
         P.refresh_shadows(grid=False)
 
     def maybe_update_grid(self):
@@ -184,9 +195,10 @@ class TrainEngine:
     def step(self, batch, seed, step, noise=None, u=None, step_dev=None, grid_update=True):
         if grid_update:
             self.maybe_update_grid()
-        out = self.forward_backward(batch, seed, step, noise, u, step_dev)
+        fuse = self.fuse_grid_adam
+        out = self.forward_backward(batch, seed, step, noise, u, step_dev, grid_adam=fuse)
         self.all_reduce_grads()
-        self.optimizer_step(step_dev)    # (advances the device step counter of a captured step: no separate increment launch)
+        self.optimizer_step(step_dev, skip_grid=fuse)    # (advances the device step counter of a captured step: no separate increment launch)
         return out
 
     def graphed(self, frames, batch, data_seed, seed, frame_range=None, first_step=0, warmup=3):

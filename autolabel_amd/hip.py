@@ -31,6 +31,11 @@ class AlnMlpDesc(C.Structure):
                 ('dw_ws_bytes', i64), ('defer_dw_reduce', i32), ('reserved_', i32)]
 
 
+class AlnAdamFuse(C.Structure):
+    _fields_ = [('params', vp), ('m', vp), ('v', vp), ('table_f16', vp), ('state_i', vp), ('state_f', vp), ('lr', f32), ('beta1', f32),
+                ('beta2', f32), ('eps', f32)]
+
+
 class AlnFrames(C.Structure):
     _fields_ = [('images', vp), ('depths', vp), ('semantics', vp), ('features', vp), ('rotations', vp), ('origins', vp),
                 ('pixel_indices', vp), ('n_frames', i32), ('w', i32), ('h', i32), ('n_pix', i32), ('feat_w', i32),
@@ -59,7 +64,7 @@ _SIGS = {
     'aln_encode_fwd_cells': (i32, [vp, vp, i32, u32, u32, vp, i32, i32, vp, vp, vp]),
     'aln_encode_bwd_binned_ws_bytes': (i64, [vp, i32]),
     'aln_encode_bwd_binned_tile_rows': (i32, []),
-    'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'aln_wide_nt': (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp]),
     'aln_wide_tn': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp]),
     'aln_transpose_f16': (i32, [vp, i32, i32, vp, vp]),
@@ -94,7 +99,7 @@ _SIGS = {
     'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 4 + [i32] + [vp] * 2),
     'aln_loss_terms_floats': (i32, []),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),
-    'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, vp, vp, vp]),
+    'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
     'aln_similarity_argmax': (i32, [vp, i32, i32, vp, i32, vp, vp]),
     'aln_cast_f16': (i32, [vp, vp, i64, vp]),
     'aln_cast_f32': (i32, [vp, vp, i64, vp]),

@@ -482,14 +482,16 @@ class HipPipeline:
                H.ptr(out.get('semantic_features')), H.stream())
         return out, c
 
-    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None, scatter_flag=None):
+    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None, scatter_flag=None, grid_adam=None):
         """Accumulate d(loss)/d(params) into P.grad from per-ray output gradients (fp32, already loss-scaled).
 
         Data-parallel callers pass ``level_groups`` = [(lo, hi), ...] and ``on_grad_ready``: the hash-grid scatter then runs
         one group of levels at a time and the callback fires as soon as a part of P.grad is final -- ``('mlp', a, b)`` for
         the MLP block (+ overflow flag) before the scatter starts, ``('grid', a, b)`` after each group (flat offsets) -- so
         its all-reduce overlaps the remaining scatter.  ``scatter_flag`` (int32[1]): the hash-grid scatter raises this word instead
-        of ``found_inf`` (a data-parallel caller ships ``found_inf`` with the MLP bucket while the scatter is still running)."""
+        of ``found_inf`` (a data-parallel caller ships ``found_inf`` with the MLP bucket while the scatter is still running).
+        ``grid_adam`` (hip.AlnAdamFuse): the scatter's second phase takes the optimizer step for the table itself instead of adding
+        the table's gradient to P.grad (single-GPU training: TrainEngine.step)."""
         L, P, ws = self.L, self.P, c['ws']
         assert c['train'], 'backward needs a forward(train=True) context'
         if c.get('serial') != getattr(ws, 'serial', None):
@@ -602,8 +604,8 @@ class HipPipeline:
         for lo, hi in (level_groups or [(0, nl)]):
             # (two passes: the tiles walk every ray in depth order, so coarse and fine samples of one cell dedupe into one record)
             self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
-                    H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(P.grad), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi, H.stream(),
-                    tag=(M, hi - lo))
+                    H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(P.grad), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi,
+                    C.byref(grid_adam) if grid_adam is not None else None, H.stream(), tag=(M, hi - lo))
             if on_grad_ready is not None and level_groups is not None:
                 a = int(e.grid.offset[lo]) * F
                 b = int(e.grid.offset[hi]) * F if hi < nl else L.n_grid

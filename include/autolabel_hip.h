@@ -150,12 +150,22 @@ int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, int32_t G, 
  * groups and all-reduces the finished part of the table while the next group is still being scattered.  Rows [0, rows_pass1) are rays_stride1 samples per ray, the rest rays_stride2 (the coarse and
  * the importance pass of autolabel/trainer.py:64-70 in one launch).  ws = aln_encode_bwd_binned_ws_bytes(e, rows) bytes of
  * caller-owned scratch.  *found_inf is set when a gradient entry is not finite (record values travel as fp16). */
+/* Optional optimizer for the table, applied by phase 2 itself (single-GPU training: the exact gradient sums of a slice sit in LDS,
+ * so the block that owns the slice takes the Adam step for its entries and the gradient never travels through HBM).  Same
+ * arithmetic as aln_adam_step, whose state words it reads (state_i[2] found_inf, state_i[4] steps of block 0, state_f[0] loss
+ * scale, state_f[1] learning rate); aln_adam_step(..., skip_grid = 1) afterwards updates the MLP blocks and advances the state. */
+typedef struct {
+  float* params; float* m; float* v; void* table_f16;   /* the grid part of the flat buffers (element 0 = entry 0 of level 0) */
+  const int32_t* state_i; const float* state_f;
+  float lr, beta1, beta2, eps;
+} AlnAdamFuse;
 int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows);
 int32_t aln_encode_bwd_binned_tile_rows(void);   /* sample rows per phase-1 tile (layout of ws: pool chunks of 8 x tile records, then descriptors) */
 int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
                           int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2,
                           const uint16_t* depth_order /* optional [rays, stride1 + stride2] */, const void* d_enc,
-                          float* grad_table, void* ws, int32_t level_lo, int32_t level_hi, int32_t* found_inf, void* stream);
+                          float* grad_table, void* ws, int32_t level_lo, int32_t level_hi, int32_t* found_inf,
+                          const AlnAdamFuse* adam /* NULL: gradients are added to grad_table */, void* stream);
 
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,
@@ -303,7 +313,9 @@ int aln_loss_fwd_bwd(const float* image, const float* depth, const float* semant
 int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid, int64_t n_total,
                   int32_t* state_i, float* state_f, float* consts, float lr, float beta1, float beta2, float eps, float wd_net,
                   float growth, float backoff, int32_t growth_interval, int32_t n_blocks, const int64_t* block_end /*host*/,
-                  const int32_t* block_kind /*host*/, int32_t feature_loss, const int32_t* counts /*device, optional*/,
+                  const int32_t* block_kind /*host*/, int32_t feature_loss,
+                  int32_t skip_grid /* 1: block 0 (the table) was updated by aln_encode_bwd_binned(adam); only its step counter advances */,
+                  const int32_t* counts /*device, optional*/,
                   uint32_t* step_dev /*optional: += 1 once per call (the step counter of aln_raygen_train & co. under graph replay)*/, void* stream);
 int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
 int aln_cast_f32(const void* src_f16, float* dst, int64_t n, void* stream);

@@ -17,7 +17,7 @@ n = int(e.grid.n_entries) * 2
 ref = torch.zeros(n, device='cuda'); got = torch.zeros(n, device='cuda')
 H.call('aln_encode_bwd', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(d_enc), H.ptr(ref), H.stream())
 ws = torch.zeros(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), dtype=torch.uint8, device='cuda')
-H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows, S, S, None, H.ptr(d_enc), H.ptr(got), H.ptr(ws), 0, 16, None, H.stream())
+H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows, S, S, None, H.ptr(d_enc), H.ptr(got), H.ptr(ws), 0, 16, None, None, H.stream())
 torch.cuda.synchronize()
 d = (got - ref).abs()
 print('max err', d.max().item(), 'ref max', ref.abs().max().item(), 'rel norm', (got - ref).norm().item() / ref.norm().item())

@@ -23,7 +23,7 @@ def atomic(lo, hi):
     H.call('aln_encode_bwd_levels', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z[M1:]), None, M - M1, S2, H.ptr(d_enc[M1:]), H.ptr(grad), lo, hi, H.stream())
 def binned(lo, hi):
     H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, S2, None, H.ptr(d_enc), H.ptr(grad), H.ptr(ws),
-           lo, hi, None, H.stream())
+           lo, hi, None, None, H.stream())
 def timeit(fn, reps=5):
     for _ in range(2): fn()
     torch.cuda.synchronize()

@@ -21,7 +21,7 @@ grad = torch.zeros(L.n_grid + 8, device='cuda')
 ws = torch.empty(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M)), dtype=torch.uint8, device='cuda')
 def binned(lo, hi):
     H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, S2, H.ptr(perm), H.ptr(d_enc), H.ptr(grad), H.ptr(ws),
-           lo, hi, None, H.stream())
+           lo, hi, None, None, H.stream())
 def timeit(fn, reps=8):
     for _ in range(2): fn()
     torch.cuda.synchronize()

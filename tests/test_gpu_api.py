@@ -270,6 +270,45 @@ def test_training_is_bit_reproducible_run_to_run():
             assert torch.equal(x, y), f'march={march}: {(x != y).sum().item()} of {x.numel()} values differ between two identical runs'
 
 
+def test_grid_adam_inside_the_scatter_equals_the_separate_optimizer_bit_for_bit():
+    """On one GPU the scatter's second phase takes the Adam step for the hash table itself (TrainEngine.fuse_grid_adam); the
+    gradient-through-HBM route (what a data-parallel run uses: P.grad, then aln_adam_step over everything) must leave every
+    parameter, moment, fp16 shadow and optimizer / GradScaler state word identical after every step -- including steps the loss
+    scaler skips (started at 2^36 the first steps overflow) and a change of learning rate; dense path and marching."""
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    scene = synthetic.make_cube_scene(n_frames=8)
+    frames = DeviceFrames.from_scene(scene, 'cuda')
+    for march in (False, True):
+        engs = []
+        for fuse in (True, False):
+            layout = ModelLayout('hg+freq', 15, 128, 128, 64, scene['n_classes'], bound=6.0)
+            P = Params(layout, torch.device('cuda'))
+            P.init_(seed=0)
+            pipe = HipPipeline(layout, P)
+            if march:
+                pipe.enable_marching(G=64, max_steps=256, samples=48)
+                pipe.mark_untrained_grid(frames.world_to_camera(), (frames.desc.fx, frames.desc.fy, frames.desc.cx, frames.desc.cy),
+                                         size=(frames.w, frames.h))
+            eng = TrainEngine(pipe, num_steps=48, upsample_steps=48, fuse_grid_adam=fuse, scaler={'init_scale': 2.0 ** 36, 'growth_interval': 5})
+            assert eng.fuse_grid_adam == fuse
+            engs.append((eng, P, frames.alloc_batch(1024)))
+        for it in range(24):
+            for eng, P, batch in engs:
+                if it == 19:
+                    eng.lr = 2e-3
+                frames.next_train(batch, seed=5, step=it)
+                eng.step(batch, seed=9, step=it)
+            (ea, Pa, _), (eb, Pb, _) = engs
+            for name, x, y in [('params', Pa.flat, Pb.flat), ('m', ea.m, eb.m), ('v', ea.v, eb.v), ('table16', Pa.table16, Pb.table16),
+                               ('state_i', ea.state_i, eb.state_i), ('state_f', ea.state_f, eb.state_f)]:
+                assert torch.equal(x, y), f'march={march} step {it}: {name} differs in {(x != y).sum().item()} of {x.numel()} values'
+        assert 4 < int(ea.state_i[0].item()) < 24, f'the run must contain applied AND skipped steps ({int(ea.state_i[0].item())} applied)'
+        assert Pa.grad[:ea.L.n_grid].abs().max().item() == 0, 'the fused route never writes the table gradient'
+
+
 def test_training_reduces_loss_on_cube_scene():
     from autolabel_amd import synthetic
     from autolabel_amd.dataset import DeviceFrames

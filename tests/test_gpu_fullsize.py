@@ -88,7 +88,7 @@ def test_binned_scatter_is_the_adjoint_of_the_gather_at_full_size(H):
         de = torch.cat([d_enc[a * S1:b * S1], d_enc[M1 + a * S2:M1 + b * S2]]).contiguous()
         n = b - a
         H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro[a:b]), H.ptr(rd[a:b]), H.ptr(zz), None, n * (S1 + S2), n * S1, S1, S2,
-               None, H.ptr(de), H.ptr(grad), H.ptr(ws), lo, hi, H.ptr(flag), H.stream())
+               None, H.ptr(de), H.ptr(grad), H.ptr(ws), lo, hi, H.ptr(flag), None, H.stream())
 
     grad = torch.zeros(spec.n_entries * 2, device='cuda')
     binned(grad)

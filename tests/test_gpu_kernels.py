@@ -215,7 +215,7 @@ def _binned_bwd(H, e, ro, rd, z, rows, rows1, s1, s2, d_enc, grad, lo=0, hi=None
     if ws is None:
         ws = torch.empty(max(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), 16), dtype=torch.uint8, device='cuda')
     H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows1, s1, s2, H.ptr(perm), H.ptr(d_enc),
-           H.ptr(grad), H.ptr(ws), lo, int(e.grid.n_levels) if hi is None else hi, H.ptr(flag), H.stream())
+           H.ptr(grad), H.ptr(ws), lo, int(e.grid.n_levels) if hi is None else hi, H.ptr(flag), None, H.stream())
 
 
 def _record_count(H, e, ws, rows):
@@ -343,6 +343,33 @@ def test_binned_encode_backward_in_depth_order_same_gradient_fewer_records(H):
     assert (shuffled - ref).norm().item() <= 1e-3 * ref.norm().item()
     with pytest.raises(RuntimeError):   # a depth order needs the two-pass layout
         _binned_bwd(H, e, ro, rd, z, M, M, S, S, d_enc, shuffled, perm=rnd, ws=ws)
+
+
+def test_binned_encode_backward_scales_run_sums_beyond_fp16_down(H):
+    """64 samples of one cell with gradients near the fp16 maximum: the run sum (up to 64 x 65504) does not fit a half, so the
+    tile's records are scaled DOWN (negative shift) instead of overflowing -- no found_inf, the gradient still matches fp32 autograd.
+    Only a non-finite d_enc (which its producer flags) makes a record non-finite."""
+    bound = 1.0
+    e = H.make_enc_desc('hg+freq', bound)
+    N, S = 8, 64
+    rows = N * S
+    g = torch.Generator().manual_seed(4)
+    ro = ((torch.rand(N, 3, generator=g) - 0.5) * 0.5).cuda()
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()
+    z = (0.2 + torch.rand(N, S, generator=g).sort(dim=1)[0] * 1e-3).reshape(-1).cuda().contiguous()      # all samples of a ray in one coarse cell
+    d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+    d_enc[:, 12:44] = 60000.0
+    ray_of_row = torch.arange(N, device='cuda').repeat_interleave(S)
+    ref = _grid_grad_reference(O.ModelConfig(bound=bound), ro, rd, z, ray_of_row, d_enc, bound)
+    got = torch.zeros(int(e.grid.n_entries) * 2, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    _binned_bwd(H, e, ro, rd, z, rows, rows, S, S, d_enc, got, flag=flag)
+    assert flag.item() == 0 and torch.isfinite(got).all()
+    assert ref.abs().max().item() > 65504.0, 'the case must exceed the fp16 range'
+    assert (got - ref).norm().item() <= 1e-3 * ref.norm().item()
+    d_enc[5, 20] = float('inf')
+    _binned_bwd(H, e, ro, rd, z, rows, rows, S, S, d_enc, got, flag=flag)
+    assert flag.item() == 1
 
 
 def test_binned_encode_backward_two_passes_and_level_groups(H):

@@ -319,7 +319,7 @@ def test_adam_step_matches_torch_adam_and_skips_on_inf():
 
     def step():
         H.call('aln_adam_step', H.ptr(p), H.ptr(gr), H.ptr(m), H.ptr(v), H.ptr(t16), n_grid, n, H.ptr(si), H.ptr(sf), H.ptr(cst),
-               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, H.ptr(counts), None, H.stream())
+               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, 0, H.ptr(counts), None, H.stream())
     for it in range(4):
         gt = torch.randn(n, generator=g)
         pr = p_ref.detach().clone()
