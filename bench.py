@@ -209,12 +209,18 @@ def scatter_roofline(eng, events, rows_per_step, n_event_steps):
     durs = [e[0].elapsed_time(e[1]) * 1e-3 for e, _ in enc_ev]
     per_launch = [r * (lv * 8 * 2 * 4 + (L.enc.enc_pad * 2 + 4) * lv / nl) for _, (r, lv) in enc_ev]
     avg_s = sum(durs) / len(durs)
-    alg = sum(per_launch) / len(per_launch)
+    alg_scatter = sum(per_launch) / len(per_launch)
+    # one GPU: phase 2 also takes the Adam step for the table (12 B read + 14 B written per parameter: p, m, v; p, m, v, fp16 shadow)
+    fused = bool(eng.fuse_grid_adam)
+    alg_adam = 26.0 * L.n_grid if fused else 0.0
+    alg = alg_scatter + alg_adam
     records = eng.pipe.binned_record_count(rows_per_step, ws=eng.ws)   # records of the last launch (same state as the events)
     rec_bytes = 2 * 8 * records if records else None                  # written once by phase 1, read once by phase 2
-    return {'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair)', 'bound': 'hbm',
+    return {'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair' + ("; the table's Adam step inside phase 2)" if fused else ')'), 'bound': 'hbm',
             'achieved': alg / avg_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / avg_s / 1e9 / 8000.0, 'traffic': None,
             'avg_launch_us': avg_s * 1e6, 'launches': len(durs), 'rows_per_launch': rows_per_step, 'algorithmic_bytes_per_launch': alg,
+            'algorithmic_bytes_scatter': alg_scatter, 'algorithmic_bytes_optimizer': alg_adam, 'optimizer_fused_into_phase2': fused,
+            'pair_without_optimizer_us': getattr(eng, 'pair_without_optimizer_us', None),
             'records_per_launch': records, 'record_bytes': 8, 'record_traffic_bytes_per_launch': rec_bytes,
             'records_per_s': records / avg_s if records else None,
             'limiter': 'not HBM bandwidth: phase 1 costs the same ~23 us per level whether the level leaves 0.6 M or 8.4 M records '
@@ -225,7 +231,9 @@ def scatter_roofline(eng, events, rows_per_step, n_event_steps):
             'note': 'HIP events around the launch pair over %d launch-by-launch steps right after the timed region (the timed region itself '
                     'replays a hipGraph, which cannot carry events); phase 1 sorts fp16x2 (index, value) records by table slice in LDS and '
                     'streams them out (8 B/record), phase 2 streams them back and accumulates in 64-bit fixed point in LDS: no global '
-                    'atomics, bit-reproducible' % n_event_steps}
+                    'atomics, bit-reproducible; on one GPU phase 2 applies Adam to its slice of the table from those sums (no gradient round '
+                    'trip through HBM, no separate optimizer pass over the 14.2 M table parameters); pair_without_optimizer_us = the same pair '
+                    'with the optimizer left to aln_adam_step (4 extra launch-by-launch steps, bit-identical results)' % n_event_steps}
 
 
 def mlp_roofline(eng, events, n_event_steps, live_rows):
@@ -269,6 +277,18 @@ def event_steps(eng, eager_step, n, sync):
         eager_step()
     sync()
     eng.pipe.kernel_events = None
+    eng.pair_without_optimizer_us = None
+    if eng.fuse_grid_adam:
+        # for reference only: the same launch pair WITHOUT the optimizer inside its second phase (the gradient goes to P.grad and
+        # aln_adam_step covers the table too) -- the results are bit-identical, so the trained state does not notice
+        ref = []
+        eng.fuse_grid_adam, eng.pipe.kernel_events = False, ref
+        for _ in range(4):
+            eager_step()
+        sync()
+        eng.fuse_grid_adam, eng.pipe.kernel_events = True, None
+        d = [e[0].elapsed_time(e[1]) for e, n_, t in ref if n_.startswith('aln_encode_bwd')]
+        eng.pair_without_optimizer_us = 1e3 * sum(d) / len(d) if d else None
     return events
 
 

@@ -140,11 +140,11 @@ def test_hip_training_matches_the_quality_of_the_oracle_on_means_over_seeds():
     assert lo[-1] < 0.5 * lo[0] and lh[-1] < 0.5 * lh[0], 'both sides must have trained'
     assert rec['mean_oracle']['psnr_db'] >= MIN_ORACLE_PSNR_DB, 'the gate only discriminates on a trained field'
     # SURVEY 8(d), as written: means over the seeds, +-0.2 dB PSNR, +-0.5 pt mIoU.  The survey's bound is the acceptance bound on the
-    # side that matters -- the HIP path may not be WORSE than the oracle by more than the tolerance.  On the other side the measured
-    # deltas are small but systematically positive in PSNR (+0.10 ... +0.28 dB over five probes of this protocol, +0.17 dB in the
-    # committed record profiles/r03_quality_gate.json): the HIP scatter accumulates exactly, the oracle's torch index_put meets in
-    # fp32 atomics whose noise Adam (eps 1e-15) amplifies.  A HIP side that is better is not a parity failure of the hot path, so there
-    # the gate only guards against anomalies (0.5 dB / 1 pt); the numbers themselves are in the record.
+    # side that matters -- the HIP path may not be WORSE than the oracle by more than the tolerance.  Any kernel change that moves a
+    # rounding moves the HIP trajectory a little: over six runs of this protocol with different kernel versions the PSNR delta was
+    # -0.07 ... +0.28 dB, the mIoU delta -0.25 ... +0.1 pt (committed record: profiles/r03_quality_gate.json).  A HIP side that
+    # happens to be better is not a parity failure of the hot path, so there the gate only guards against anomalies (0.5 dB / 1 pt);
+    # the numbers themselves are in the record.
     assert rec['delta_psnr_db'] >= -TOL_PSNR_DB, rec
     assert rec['delta_miou_pt'] >= -TOL_MIOU_PT, rec
     assert rec['delta_psnr_db'] <= 0.5 and rec['delta_miou_pt'] <= 1.0, rec
