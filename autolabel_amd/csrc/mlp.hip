@@ -1308,7 +1308,8 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
 template <int IN, int HID, int OUT, int NHID>
 static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows, const int* rows_dev, void* d_in,
                              float* dW, int* found_inf, hipStream_t s) {
-  if constexpr (HID == 64 && IN <= 32) {   // (IN = 80, semantic_out, does not fit the 128-VGPR budget of two blocks per CU)
+  if constexpr (HID == 64 && IN <= 32) {   // (IN = 80, semantic_out, does not fit the 128-VGPR budget of two blocks per CU: 60-70 registers
+                                            //  spill and the kernel goes 165 -> 230 us, measured in round 3)
     constexpr int OB = (OUT + 31) / 32, PO = OB * 32 + (OB == 1 ? 0 : 8);
     const size_t halves = (size_t)aln_mlp_rowmajor_halves(IN, HID, OUT, NHID);
     const size_t lds2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(IN + 8 + 2 * hid_pitch(HID) + PO)) * 2;
