@@ -234,15 +234,51 @@ __device__ inline bool nan_bad(h16x2 acc) { return !((float)acc[0] == 0.f) || !(
 // instead of materialising them ([rows,80] + [rows,64] + [rows,16] fp16 round trips through HBM) the MLP kernels build
 // each 8-feature chunk on the fly.
 enum { SRC_PLAIN = 0, SRC_SEMF_IN = 1, SRC_SEMO_IN = 2, SRC_DLOGITS = 3, SRC_DSEMF_OUT = 4, SRC_COLOR_IN = 5 };
+// n / d for a divisor fixed at launch (Granlund-Montgomery, round-up method): one multiply-high and two shifts instead of the
+// ~35-instruction software division -- the row sources below turn a sample row into its ray for every 16-byte chunk they build
+struct FastDiv { uint32_t m, s1, s2; };
+static FastDiv fastdiv_make(uint32_t d) {
+  if (d == 0) d = 1;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  FastDiv f;
+  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1; f.s2 = l - f.s1;
+  return f;
+}
+__device__ inline uint32_t fastdiv(uint32_t n, FastDiv f) {
+  const uint32_t t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
 struct RowSrc {
   int mode;
   const h16* a; int lda;      // PLAIN: x ; SEMF_IN: sigma_out (ld 16) ; SEMO_IN: f (ld D)
   const h16* b; int ldb;      // SEMO_IN: sigma_out ; DSEMF_OUT: d_semo_in (its first D columns = dL/df, ReLU mask applied)
   const float* w_row; const float* g;   // DLOGITS / DSEMF_OUT: per-row weight, per-ray output gradient [N, gw]
   int N, S1, S2, D, G, gw;
+  FastDiv d1, d2;             // / S1, / S2 (set by row_src_rays)
   const int* idx;             // COLOR_IN: live_idx (compact row -> sample row) or NULL; b = sigma_out, g = directions
   int fold_geo;               // DSEMF_OUT (as dL/dout of semantic_features): the backward adds b[row][D .. D+16) -- the geo_feat
 };                            //           columns of d(semantic_out input) -- into its d_in rows (one d(geo_feat) tensor leaves)                            //           (gw = 0: one per ray [N,3], gw = 1: one per sample row [rows,3])
+static void row_src_rays(RowSrc& s, int N, int S1, int S2) {
+  s.N = N; s.S1 = S1; s.S2 = S2 > 0 ? S2 : 1; s.d1 = fastdiv_make((uint32_t)s.S1); s.d2 = fastdiv_make((uint32_t)s.S2);
+}
+__device__ inline int row_ray(const RowSrc& s, int row) {   // pass-major rows: N x S1, then N x S2
+  const int n1 = s.N * s.S1;
+  return row < n1 ? (int)fastdiv((uint32_t)row, s.d1) : (int)fastdiv((uint32_t)(row - n1), s.d2);
+}
+// per-ray gradient row g[ray][c0 .. c0 + 7] (fp32): two 16-byte loads when the row width keeps every chunk 32-byte aligned (the
+// 64-wide feature gradient: eight chunks per sample row), else element by element with the tail masked (7 class logits)
+__device__ inline void ray_grad8(const RowSrc& s, int ray, int c0, float* o) {
+  const float* g = s.g + (size_t)ray * s.gw + c0;
+  if ((s.gw & 7) == 0) {
+    const float4 a = *(const float4*)g, b = *(const float4*)(g + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (c0 + j < s.gw) ? g[j] : 0.f;
+  }
+}
 __device__ inline h16x8 geo_chunk(const h16* sigma_out, size_t row, int j0, int G) {
   // [geo_feat (G), 1, 1, ...] features j0..j0+7 ; geo_feat[g] = sigma_out[row][1 + g].  j0 is 0 or 8: both cases use
   // compile-time element indices (a runtime-indexed local array would live in scratch memory)
@@ -269,24 +305,24 @@ __device__ inline h16x8 load_chunk8(const RowSrc& s, int row, int c0) {
       return v;
     }
     case SRC_DLOGITS: case SRC_DSEMF_OUT: {
-      const int ray = row < s.N * s.S1 ? row / s.S1 : (row - s.N * s.S1) / s.S2;
       const float w = s.w_row[row];
-      const float* g = s.g + (size_t)ray * s.gw;
+      float g[8];
+      ray_grad8(s, row_ray(s, row), c0, g);
       h16x8 o;
       if (s.mode == SRC_DLOGITS) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (h16)((c0 + j < s.gw) ? w * g[c0 + j] : 0.f);
+        for (int j = 0; j < 8; ++j) o[j] = (h16)((c0 + j < s.gw) ? w * g[j] : 0.f);
       } else {
         h16x8 d = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);   // d(semantic_out) / d f, ReLU mask applied by its producer
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (h16)(w * g[c0 + j] + (float)d[j]);
+        for (int j = 0; j < 8; ++j) o[j] = (h16)(w * g[j] + (float)d[j]);
       }
       return o;
     }
     case SRC_COLOR_IN: {   // color_net input [SH16(dir), geo_feat, 1...] of models.py:205-212, built on the fly (inference)
       const int r = s.idx ? s.idx[row] : row;
       if (c0 >= 16) return geo_chunk(s.b, (size_t)r, c0 - 16, s.G);
-      const float* d = s.g + 3 * (size_t)(s.gw ? r : (r < s.N * s.S1 ? r / s.S1 : (r - s.N * s.S1) / s.S2));
+      const float* d = s.g + 3 * (size_t)(s.gw ? r : row_ray(s, r));
       float sh[16];
       sh4_of_dir(d, sh);
       h16x8 o;
@@ -331,14 +367,10 @@ __device__ inline void raw_load(RawChunk& r, const RowSrc& s, int row, int c0) {
     if (c0 >= s.D) { const h16* p = s.b + (size_t)row * 16; r.a = *(const h16x8*)p; r.b = *(const h16x8*)(p + 8); }
     else r.a = *(const h16x8*)(s.a + (size_t)row * s.lda + c0);
   } else {
-    const int ray = row < s.N * s.S1 ? row / s.S1 : (row - s.N * s.S1) / s.S2;
+    const int ray = row_ray(s, row);
     r.w = s.w_row[row];
     if constexpr (LATEG) r.ray = ray;
-    else {
-      const float* g = s.g + (size_t)ray * s.gw;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r.g[j] = (c0 + j < s.gw) ? g[c0 + j] : 0.f;
-    }
+    else ray_grad8(s, ray, c0, r.g);
     if constexpr (MODE == SRC_DSEMF_OUT) r.b = *(const h16x8*)(s.b + (size_t)row * s.ldb + c0);
   }
 }
@@ -366,11 +398,8 @@ __device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
   } else {
     h16x8 o;
     float gl[8];
-    if constexpr (LATEG) {
-      const float* g = s.g + (size_t)r.ray * s.gw;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gl[j] = (c0 + j < s.gw) ? g[c0 + j] : 0.f;
-    } else {
+    if constexpr (LATEG) ray_grad8(s, r.ray, c0, gl);
+    else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) gl[j] = r.g[j];
     }
@@ -904,13 +933,19 @@ __device__ inline void write_packed_tile(TV t, int srow, const h16x8 (&p)[2 * NB
 // clock spent between consecutive stamps, per role (0 = chain wave 0, 1 = dW wave 4).
 #ifdef ALN_PHASE_TIMING
 __device__ long long g_phase_cycles[2][32];
+__device__ int g_phase_in = 0;    // 0: every instantiation records; else only the one with this input width
 extern "C" int aln_debug_read_phases(long long* host_out, int reset) {
-  if (reset) { long long z[64] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)); }
+  if (reset) {
+    long long z[64] = {0};
+    const int sel = reset > 1 ? reset : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_in), &sel, sizeof(int));
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z));
+  }
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 64);
 }
 #define PT_DECL long long pt_acc[32] = {0}; long long pt_last = clock64();
 #define PT_STAMP(i) { long long pt_now = clock64(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; }
-#define PT_FLUSH(role) if (blockIdx.x == 0 && cw == 0 && lane == 0) { for (int i = 0; i < 32; ++i) g_phase_cycles[role][i] += pt_acc[i]; }
+#define PT_FLUSH(role) if (blockIdx.x == 0 && cw == 0 && lane == 0 && (g_phase_in == 0 || g_phase_in == IN)) { for (int i = 0; i < 32; ++i) g_phase_cycles[role][i] += pt_acc[i]; }
 #else
 #define PT_DECL
 #define PT_STAMP(i)
@@ -956,12 +991,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
   constexpr int XCH = IN / 8, OCH = OUT / 8;                       // 8-half chunks per row
   constexpr int NXS = (TR * XCH + 511) / 512, NOS = (TR * OCH + 511) / 512;
   constexpr bool LG = RPW > 1;   // 256-row tiles: twice the prefetch registers, so the cache-resident per-ray rows are read late
+  // item i of the x tile -> (row, 8-half chunk).  semantic_out's input is [relu(f) (IN - 16) | geo_feat, 1 (16)]: its two kinds of
+  // chunks come from different tensors through different code, so the f chunks of the whole tile are numbered first and the geo
+  // chunks after them -- every wave then builds one kind only (mixed, both branches ran in every wave: 22 us of a 165 us launch)
+  auto xmap = [](int i, int& r, int& k) {
+    if constexpr (XM == SRC_SEMO_IN) {
+      constexpr int FCH = XCH - 2;
+      if (i < TR * FCH) { r = i / FCH; k = i % FCH; }
+      else { const int j = i - TR * FCH; r = j >> 1; k = FCH + (j & 1); }
+    } else { r = i / XCH; k = i % XCH; }
+  };
   RawChunk px[OCC2 ? 1 : NXS], po[OCC2 ? 1 : NOS];
   auto prefetch = [&](int r0) {
     if constexpr (OCC2) return;
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
+      const int i = threadIdx.x + 512 * q; int r, k; xmap(i, r, k);
       if (i < TR * XCH && r0 + r < rows) raw_load<XM, LG>(px[q], xs, r0 + r, 8 * k);
     }
 #pragma unroll
@@ -975,7 +1020,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
     if constexpr (OCC2) {   // load and store in one go: nothing of the tile stays in registers
 #pragma unroll
       for (int q = 0; q < NXS; ++q) {
-        const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
+        const int i = threadIdx.x + 512 * q; int r, k; xmap(i, r, k);
         if (i < TR * XCH) {
           h16x8 v = z;
           if (r0 + r < rows) { RawChunk t; raw_load<XM>(t, xs, r0 + r, 8 * k); v = raw_finish<XM>(t, xs, 8 * k); }
@@ -995,7 +1040,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
     }
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
-      const int i = threadIdx.x + 512 * q, r = i / XCH, k = i % XCH;
+      const int i = threadIdx.x + 512 * q; int r, k; xmap(i, r, k);
       if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX0 + r * PX0 + 8 * k) = (r0 + r < rows) ? raw_finish<XM, LG>(px[q], xs, 8 * k) : z;
     }
 #pragma unroll
@@ -1471,7 +1516,7 @@ extern "C" int aln_color_fwd(const AlnMlpDesc* color, const int32_t* live_idx, c
   ALN_REQUIRE(color && (rays_d || dirs) && sigma_out && color_out && (!live_idx || n_live), "color_fwd: NULL pointer");
   ALN_REQUIRE(color->in_pad == 32 && G + 1 <= 16, "color_fwd: needs in_pad 32 (SH16 + geo_feat <= 15), got in_pad %d G %d", color->in_pad, G);
   RowSrc x{}; x.mode = SRC_COLOR_IN; x.b = (const h16*)sigma_out; x.ldb = 16; x.G = G; x.idx = live_idx;
-  x.g = dirs ? dirs : rays_d; x.gw = dirs ? 1 : 0; x.N = N; x.S1 = S1; x.S2 = S2 > 0 ? S2 : 1;
+  x.g = dirs ? dirs : rays_d; x.gw = dirs ? 1 : 0; row_src_rays(x, N, S1, S2);
   return mlp_fwd_src(color, x, max_rows, live_idx ? n_live : nullptr, nullptr, nullptr, color_out, stream);
 }
 
@@ -1511,10 +1556,10 @@ extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
               "sem_heads_bwd: fold_geo needs the 16-wide recompute backward of semantic_features");
   hipStream_t s = (hipStream_t)stream;
   RowSrc xo{}; xo.mode = SRC_SEMO_IN; xo.a = (const h16*)feat; xo.lda = D; xo.b = (const h16*)sigma_out; xo.ldb = 16; xo.G = G; xo.D = D;
-  RowSrc go{}; go.mode = SRC_DLOGITS; go.w_row = w_row; go.g = g_sem; go.gw = C; go.N = N; go.S1 = S1; go.S2 = S2 > 0 ? S2 : 1;
+  RowSrc go{}; go.mode = SRC_DLOGITS; go.w_row = w_row; go.g = g_sem; go.gw = C; row_src_rays(go, N, S1, S2);
   if (int rc = mlp_bwd_recomp_src(semo, xo, go, rows, nullptr, d_semo_in, dW_semo, found_inf, s)) return rc;
   RowSrc xf{}; xf.mode = SRC_SEMF_IN; xf.a = (const h16*)sigma_out; xf.lda = 16; xf.G = G; xf.D = D;
   RowSrc gf{}; gf.mode = SRC_DSEMF_OUT; gf.b = (const h16*)d_semo_in; gf.ldb = semo->in_pad;
-  gf.w_row = w_row; gf.g = g_feat; gf.gw = D; gf.N = N; gf.S1 = S1; gf.S2 = S2 > 0 ? S2 : 1; gf.D = D; gf.fold_geo = fold_geo;
+  gf.w_row = w_row; gf.g = g_feat; gf.gw = D; row_src_rays(gf, N, S1, S2); gf.D = D; gf.fold_geo = fold_geo;
   return mlp_bwd_recomp_src(semf, xf, gf, rows, nullptr, d_semf_in, dW_semf, found_inf, s);
 }

@@ -19,6 +19,9 @@ from autolabel_amd import hip as H
 H.LIB = OUT          # load the instrumented build instead of the product library
 from autolabel_amd.pipeline import ModelLayout, Params
 head = sys.argv[1] if len(sys.argv) > 1 else 'sigma'
+sem_step = head in ('semo_step', 'semf_step')      # the head inside aln_sem_heads_bwd, with its on-the-fly row sources
+if sem_step:
+    head = head[:4]
 rows = 1 << 20
 L = ModelLayout('hg+freq', 15, 128, 128, 64, 7, bound=6.0)
 P = Params(L, 'cuda'); P.init_(0)
@@ -29,14 +32,27 @@ d_in = torch.empty(rows, m.in_pad, device='cuda', dtype=torch.float16)
 flag = torch.zeros(1, dtype=torch.int32, device='cuda')
 grad = torch.zeros_like(P.grad)
 gp = C.c_void_p(grad.data_ptr() + 4 * L.offsets[head])
+if sem_step:
+    N, S1, S2, D, G, Ccls = 4096, 128, 128, 64, 15, 7
+    sigma_out = (torch.randn(rows, 16, device='cuda') * 0.5).half()
+    feat = (torch.randn(rows, D, device='cuda') * 0.5).half()
+    w_row = torch.rand(rows, device='cuda') * 0.05
+    g_sem, g_feat = torch.randn(N, Ccls, device='cuda') * 0.1, torch.randn(N, D, device='cuda') * 0.1
+    d_oin = torch.empty(rows, L.nets['semo'].in_pad, device='cuda', dtype=torch.float16)
+    d_fin = torch.empty(rows, L.nets['semf'].in_pad, device='cuda', dtype=torch.float16)
+    gpf, gpo = (C.c_void_p(grad.data_ptr() + 4 * L.offsets[k]) for k in ('semf', 'semo'))
 def run():
+    if sem_step:
+        H.call('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem),
+               H.ptr(g_feat), N, S1, S2, Ccls, rows, D, G, H.ptr(d_oin), H.ptr(d_fin), gpf, gpo, 1, H.ptr(flag), H.stream())
+        return
     H.call('aln_mlp_bwd', C.byref(P.descs[head]), H.ptr(x), None, None, H.ptr(d_out), rows, None, None, None, H.ptr(d_in), gp,
            H.ptr(flag), H.stream())
 lib = H.lib()
 lib.aln_debug_read_phases.argtypes = [C.c_void_p, C.c_int]
 for _ in range(3): run()
 torch.cuda.synchronize()
-lib.aln_debug_read_phases(None, 1)
+lib.aln_debug_read_phases(None, int(m.in_pad) if sem_step else 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 5
 e0.record()

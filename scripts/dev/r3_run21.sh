@@ -8,5 +8,5 @@ cd $R
 }
 cp autolabel_amd/csrc/libautolabel_hip.so /tmp/lib_product.so
 stats product
-for v in "$@"; do cp scripts/dev/_build/lib_$v.so autolabel_amd/csrc/libautolabel_hip.so; stats $v; python -m pytest tests/test_gpu_kernels.py -q -x -k "sem" 2>&1 | tail -1; done
+for v in "$@"; do cp scripts/dev/_build/lib_$v.so autolabel_amd/csrc/libautolabel_hip.so; stats $v; done; python -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py tests/test_gpu_configs.py -q -x 2>&1 | tail -3
 cp /tmp/lib_product.so autolabel_amd/csrc/libautolabel_hip.so
