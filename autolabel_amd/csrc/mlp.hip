@@ -385,8 +385,9 @@ __device__ inline h16x8 geo_from(const h16x8& lo, const h16x8& hi, int j0, int G
   }
   return o;
 }
+#define GT_RAYS 2   // per-ray gradient rows staged in LDS per tile (a 128-row tile spans <= 2 rays when a ray has >= 128 samples)
 template <int MODE, bool LATEG = false>
-__device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
+__device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0, const float* gt = nullptr, int gt_first = 0, int gt_w = 0) {
   if constexpr (MODE == SRC_PLAIN) return r.a;
   else if constexpr (MODE == SRC_SEMF_IN) return geo_from(r.a, r.b, c0, s.G);
   else if constexpr (MODE == SRC_SEMO_IN) {
@@ -398,8 +399,13 @@ __device__ inline h16x8 raw_finish(const RawChunk& r, const RowSrc& s, int c0) {
   } else {
     h16x8 o;
     float gl[8];
-    if constexpr (LATEG) ray_grad8(s, r.ray, c0, gl);
-    else {
+    if constexpr (LATEG) {
+      const unsigned dr = (unsigned)(r.ray - gt_first);
+      if (gt && dr < GT_RAYS) {   // the tile's rays: staged in LDS by the kernel (k_mlp_bwd_recomp8)
+        const float4 a = *(const float4*)(gt + dr * gt_w + c0), b = *(const float4*)(gt + dr * gt_w + c0 + 4);
+        gl[0] = a.x; gl[1] = a.y; gl[2] = a.z; gl[3] = a.w; gl[4] = b.x; gl[5] = b.y; gl[6] = b.z; gl[7] = b.w;
+      } else ray_grad8(s, r.ray, c0, gl);
+    } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) gl[j] = r.g[j];
     }
@@ -1001,6 +1007,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
       else { const int j = i - TR * FCH; r = j >> 1; k = FCH + (j & 1); }
     } else { r = i / XCH; k = i % XCH; }
   };
+  // Per-ray output gradients (DLOGITS / DSEMF_OUT sources): the rows of the <= GT_RAYS rays a tile spans are staged in LDS one
+  // tile ahead by an otherwise idle weight-gradient wave, so building a 16-byte chunk costs two LDS reads instead of a trip to
+  // L2 per chunk (eight chunks per sample row for the 64-wide feature gradient).  Tiles that span more rays fall back to global loads.
+  constexpr bool GT = DM == SRC_DLOGITS || DM == SRC_DSEMF_OUT;
+  constexpr int GTW = OB * 32;                 // floats per staged ray row (>= OUT, zero beyond gw)
+  float* const gt = (float*)(tO + TR * PO);    // [2 buffers][GT_RAYS][GTW]
+  auto gt_fill = [&](int r0n, int buf) {       // called by ONE wave
+    if constexpr (GT) {
+      const int first = row_ray(ds, r0n);
+      for (int e = 4 * lane; e < GT_RAYS * GTW; e += 256) {
+        const int ray = first + e / GTW, c = e % GTW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ray < ds.N) {
+          const float* g = ds.g + (size_t)ray * ds.gw + c;
+          if ((ds.gw & 3) == 0 && c + 3 < ds.gw) v = *(const float4*)g;
+          else { if (c < ds.gw) v.x = g[0]; if (c + 1 < ds.gw) v.y = g[1]; if (c + 2 < ds.gw) v.z = g[2]; if (c + 3 < ds.gw) v.w = g[3]; }
+        }
+        *(float4*)(gt + buf * (GT_RAYS * GTW) + e) = v;
+      }
+    }
+  };
   RawChunk px[OCC2 ? 1 : NXS], po[OCC2 ? 1 : NOS];
   auto prefetch = [&](int r0) {
     if constexpr (OCC2) return;
@@ -1012,11 +1039,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
 #pragma unroll
     for (int q = 0; q < NOS; ++q) {
       const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
-      if (i < TR * OCH && r0 + r < rows) raw_load<DM, LG>(po[q], ds, r0 + r, 8 * k);
+      if (i < TR * OCH && r0 + r < rows) raw_load<DM, LG || GT>(po[q], ds, r0 + r, 8 * k);
     }
   };
-  auto stash = [&](int r0) {
+  auto stash = [&](int r0, int gbuf) {
     const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* const gtb = GT ? gt + gbuf * (GT_RAYS * GTW) : nullptr;
+    const int gfirst = GT ? row_ray(ds, r0) : 0;
     if constexpr (OCC2) {   // load and store in one go: nothing of the tile stays in registers
 #pragma unroll
       for (int q = 0; q < NXS; ++q) {
@@ -1032,7 +1061,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
         const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
         if (i < TR * OCH) {
           h16x8 v = z;
-          if (r0 + r < rows) { RawChunk t; raw_load<DM>(t, ds, r0 + r, 8 * k); v = raw_finish<DM>(t, ds, 8 * k); }
+          if (r0 + r < rows) { RawChunk t; raw_load<DM, GT>(t, ds, r0 + r, 8 * k); v = raw_finish<DM, GT>(t, ds, 8 * k, gtb, gfirst, GTW); }
           *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = v;
         }
       }
@@ -1046,19 +1075,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
 #pragma unroll
     for (int q = 0; q < NOS; ++q) {
       const int i = threadIdx.x + 512 * q, r = i / OCH, k = i % OCH;
-      if (i < TR * OCH) *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = (r0 + r < rows) ? raw_finish<DM, LG>(po[q], ds, 8 * k) : z;
+      if (i < TR * OCH) *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = (r0 + r < rows) ? raw_finish<DM, LG || GT>(po[q], ds, 8 * k, gtb, gfirst, GTW) : z;
     }
   };
-  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x * TR);
+  if ((int)blockIdx.x < ntiles) { prefetch(blockIdx.x * TR); if (wave == 4) gt_fill(blockIdx.x * TR, 0); }
   // The two roles run SEPARATE tile loops with the same barrier sequence (s_barrier only counts arrivals, and the role is
   // wave-uniform), so the register allocator never sees the chain state and the dW accumulators live at the same time.
   if (chain) {
     h16x2 nanz = {0, 0};
     PT_DECL
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
       const int r0 = tile * TR;
       PT_STAMP(0) __syncthreads(); PT_STAMP(1)   // B0
-      stash(r0);
+      stash(r0, it & 1);
       PT_STAMP(2) __syncthreads(); PT_STAMP(3)   // B1
       { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
       f32x16 acc[RPW][NB];
@@ -1158,12 +1188,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC2 ? 4 : 
     f32x16 dw_last[NBLK_LAST], dw_mid[NHID == 2 ? NBLK_MID : 1], dw_first[NBLK_FIRST];
     zero_acc(dw_last); zero_acc(dw_mid); zero_acc(dw_first);
     PT_DECL
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
       const int r0 = tile * TR;
       PT_STAMP(0) __syncthreads(); PT_STAMP(1)   // B0
-      stash(r0);
+      stash(r0, it & 1);
       PT_STAMP(2) __syncthreads(); PT_STAMP(3)   // B1
-      { const int nt = tile + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
+      { const int nt = tile + gridDim.x; if (nt < ntiles) { prefetch(nt * TR); if (wave == 4) gt_fill(nt * TR, (it + 1) & 1); } }
       PT_STAMP(4) __syncthreads(); PT_STAMP(5)   // B2
       if constexpr (NHID == 2) dw_accumulate<NBLK_LAST, OB, NB, TR>(dw_last, vO, vb2, cw, lane); else dw_accumulate<NBLK_LAST, OB, NB, TR>(dw_last, vO, vb1, cw, lane);
       PT_STAMP(6) __syncthreads(); PT_STAMP(7)   // B3
@@ -1278,7 +1309,7 @@ static int bwd_recomp_blocks(const AlnMlpDesc* m, int rows) {
   if (m->hidden == 64 && m->in_pad <= 32) {
     const int OB = (m->out_pad + 31) / 32, PO = OB * 32 + (OB == 1 ? 0 : 8);
     const size_t halves = (size_t)aln_mlp_rowmajor_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden);
-    occ2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(m->in_pad + 8 + 2 * hid_pitch(m->hidden) + PO)) * 2 <= 80 * 1024;
+    occ2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(m->in_pad + 8 + 2 * hid_pitch(m->hidden) + PO)) * 2 + 2 * GT_RAYS * OB * 32 * sizeof(float) <= 80 * 1024;
   }
   const int gmax = occ2 ? 512 : 256;
   return tiles < gmax ? tiles : gmax;
@@ -1312,7 +1343,7 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
   constexpr int PH = hid_pitch(HID), PX0 = OCC2 ? IN + 8 : IB * 32 + 8, PO = OB * 32 + (OB == 1 ? 0 : 8);   // as in the kernel
   size_t halves = (size_t)aln_mlp_rowmajor_halves(IN, HID, OUT, NHID);
   constexpr int TR = 128 * RPW;
-  size_t lds = (((halves + 7) & ~(size_t)7) + TR * (size_t)(PX0 + 2 * PH + PO)) * 2;
+  size_t lds = (((halves + 7) & ~(size_t)7) + TR * (size_t)(PX0 + 2 * PH + PO)) * 2 + 2 * GT_RAYS * OB * 32 * sizeof(float);   // + the staged per-ray gradient rows
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_recomp: LDS %zu B exceeds 160 KiB", lds);
   int tiles = (rows + TR - 1) / TR;
   const int gmax = OCC2 ? 512 : 256;
@@ -1357,7 +1388,7 @@ static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows
                                             //  spill and the kernel goes 165 -> 230 us, measured in round 3)
     constexpr int OB = (OUT + 31) / 32, PO = OB * 32 + (OB == 1 ? 0 : 8);
     const size_t halves = (size_t)aln_mlp_rowmajor_halves(IN, HID, OUT, NHID);
-    const size_t lds2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(IN + 8 + 2 * hid_pitch(HID) + PO)) * 2;
+    const size_t lds2 = (((halves + 7) & ~(size_t)7) + 128 * (size_t)(IN + 8 + 2 * hid_pitch(HID) + PO)) * 2 + 2 * GT_RAYS * OB * 32 * sizeof(float);
     if (lds2 <= 80 * 1024) return launch_bwd_recomp_occ<IN, HID, OUT, NHID, true, 1>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
   }
   return launch_bwd_recomp_occ<IN, HID, OUT, NHID, false, 1>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
