@@ -1343,7 +1343,8 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
   constexpr int PH = hid_pitch(HID), PX0 = OCC2 ? IN + 8 : IB * 32 + 8, PO = OB * 32 + (OB == 1 ? 0 : 8);   // as in the kernel
   size_t halves = (size_t)aln_mlp_rowmajor_halves(IN, HID, OUT, NHID);
   constexpr int TR = 128 * RPW;
-  size_t lds = (((halves + 7) & ~(size_t)7) + TR * (size_t)(PX0 + 2 * PH + PO)) * 2 + 2 * GT_RAYS * OB * 32 * sizeof(float);   // + the staged per-ray gradient rows
+  const bool gt_src = ds.mode == SRC_DLOGITS || ds.mode == SRC_DSEMF_OUT;
+  size_t lds = (((halves + 7) & ~(size_t)7) + TR * (size_t)(PX0 + 2 * PH + PO)) * 2 + (gt_src ? 2 * GT_RAYS * OB * 32 * sizeof(float) : 0);   // + the staged per-ray gradient rows
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_recomp: LDS %zu B exceeds 160 KiB", lds);
   int tiles = (rows + TR - 1) / TR;
   const int gmax = OCC2 ? 512 : 256;
