@@ -117,20 +117,17 @@ __device__ inline h16 freq_feature(int n_freq, const float* xr, int j) {
   return (h16)sinf(arg);
 }
 
-// Features of level l for the 64 samples of a wave (lane = sample, base_row = row of lane 0), in two steps so that a caller can
-// put the gathers of several row groups in flight before it consumes any of them: level_issue requests the table entries,
-// level_finish routes them to the owning lanes and accumulates.
-struct LevelLoads { uint32_t r[2][4]; float w[8]; int hl; };
-__device__ inline void level_issue(const EncParams& p, int l, const float* xn, int lane, int base_row, LevelLoads& L) {
-  uint32_t cell[3];
-  grid_weights(p.e.grid, l, xn, L.w, cell);
+// Features of level l for the 64 samples of a wave (lane = sample, base_row = row of lane 0).
+__device__ inline h16x2 level_features(const EncParams& p, int l, const float* xn, int lane, int base_row) {
+  float w[8]; uint32_t cell[3];
+  grid_weights(p.e.grid, l, xn, w, cell);
   const uint32_t* tab = p.table + p.e.grid.offset[l];
   // run-dedupe of the gathers: consecutive samples in the same cell read the same 8 entries; only the first sample
   // of a run (its head) loads them
   uint32_t q0 = __shfl_up(cell[0], 1), q1 = __shfl_up(cell[1], 1), q2 = __shfl_up(cell[2], 1);
   const bool head = (lane == 0) | (cell[0] != q0) | (cell[1] != q1) | (cell[2] != q2);
   const unsigned long long hm = __ballot(head);
-  L.hl = 63 - __clzll(hm & ((2ull << lane) - 1ull));   // head lane of this lane's run
+  const int hl = 63 - __clzll(hm & ((2ull << lane) - 1ull));   // head lane of this lane's run
   // A gather costs one request per distinct 64-byte chunk per wave instruction (scripts/dev/probe_gather_pairs.hip),
   // and the two x-neighbour corners of a cell sit in one chunk 15 times out of 16 (x prime = 1, 16 fp16x2 entries per
   // chunk).  So the loads are issued in PAIR layout -- lanes 2j and 2j+1 fetch the x = 0 / x = 1 corner of sample
@@ -138,6 +135,7 @@ __device__ inline void level_issue(const EncParams& p, int l, const float* xn, i
   const uint32_t res = p.e.grid.res[l], size = p.e.grid.size[l];
   const bool dense = p.e.grid.dense[l] != 0;
   const uint32_t ty = dense ? res : PRIME_Y, tz = dense ? res * res : PRIME_Z;
+  uint32_t r[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int s = (lane >> 1) + 32 * h;
@@ -149,28 +147,21 @@ __device__ inline void level_issue(const EncParams& p, int l, const float* xn, i
       uint32_t ix;
       if (dense) { ix = cx + ay[i & 1] + az[i >> 1]; ix = ix >= size ? ix - size : ix; }
       else ix = (cx ^ ay[i & 1] ^ az[i >> 1]) & (size - 1u);
-      L.r[h][i] = act ? tab[ix] : 0u;
+      r[h][i] = act ? tab[ix] : 0u;
     }
   }
-}
-__device__ inline h16x2 level_finish(const LevelLoads& L) {
-  const int src = 2 * (L.hl & 31);
+  const int src = 2 * (hl & 31);
   float a0 = 0.f, a1 = 0.f;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {   // corner c = x | y << 1 | z << 2 ; accumulation order c = 0..7 as in the oracle
-    const uint32_t t0 = __shfl(L.r[0][c >> 1], src + (c & 1)), t1 = __shfl(L.r[1][c >> 1], src + (c & 1));
-    const uint32_t vv = (L.hl >> 5) ? t1 : t0;
+    const uint32_t t0 = __shfl(r[0][c >> 1], src + (c & 1)), t1 = __shfl(r[1][c >> 1], src + (c & 1));
+    const uint32_t vv = (hl >> 5) ? t1 : t0;
     h16x2 hv = *(const h16x2*)&vv;
-    a0 = __fadd_rn(a0, __fmul_rn(L.w[c], (float)hv[0]));
-    a1 = __fadd_rn(a1, __fmul_rn(L.w[c], (float)hv[1]));
+    a0 = __fadd_rn(a0, __fmul_rn(w[c], (float)hv[0]));
+    a1 = __fadd_rn(a1, __fmul_rn(w[c], (float)hv[1]));
   }
   h16x2 o; o[0] = (h16)a0; o[1] = (h16)a1;
   return o;
-}
-__device__ inline h16x2 level_features(const EncParams& p, int l, const float* xn, int lane, int base_row) {
-  LevelLoads L;
-  level_issue(p, l, xn, lane, base_row, L);
-  return level_finish(L);
 }
 
 __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict__ out) {
@@ -222,41 +213,20 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
 // coalesced 256-byte store into a per-level plane, and a second, streaming kernel assembles the row-major [rows, enc_pad]
 // operand (frequency features, planes, ones) the MLP reads.
 #define ENC_LG 1   // levels per phase (measured: 1 -> 135 us, 2 -> 140 us, 4 -> 202 us per 512 K samples)
-// One level (lg = 1) of PH_RG groups of 64 rows per wave.  A wave's life used to be one memory round trip for its rows' positions
-// and one for its gathers around ~280 instructions: the kernel ran at the rate waves could be started and retired (123 us per
-// 2^19-row launch, of which 60 us remained with the gathers stubbed out: scripts/dev, round 3).  With several row groups per wave
-// the positions of all groups are requested together and so are their gathers.
-#ifndef PH_RG
-#define PH_RG 2
-#endif
 __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.x / nblk, b = blockIdx.x % nblk;
-  const int wbase = (b * 4 + wave) * (64 * PH_RG);
-  if (wbase >= p.rows) return;
-  float xn[PH_RG][3];
-#pragma unroll
-  for (int r = 0; r < PH_RG; ++r) {
-    const int row = wbase + 64 * r + lane;
-    float x[3] = {0, 0, 0};
-    if (row < p.rows) row_position(p, row, x);
-    normalize_pos(x, p.e.bound, true, xn[r]);
-  }
+  const int base_row = (b * 4 + wave) * 64;
+  if (base_row >= p.rows) return;
+  const int row = base_row + lane;
+  float x[3] = {0, 0, 0}, xn[3];
+  if (row < p.rows) row_position(p, row, x);
+  normalize_pos(x, p.e.bound, true, xn);
   for (int i = 0; i < lg; ++i) {
     const int l = g * lg + i;
     if (l < p.e.grid.n_levels) {
-      LevelLoads L[PH_RG];
-#pragma unroll
-      for (int r = 0; r < PH_RG; ++r)
-        if (wbase + 64 * r < p.rows) level_issue(p, l, xn[r], lane, wbase + 64 * r, L[r]);
-#pragma unroll
-      for (int r = 0; r < PH_RG; ++r) {
-        if (wbase + 64 * r < p.rows) {
-          const h16x2 o = level_finish(L[r]);
-          const int row = wbase + 64 * r + lane;
-          if (row < p.rows) planes[(size_t)l * p.rows + row] = o;
-        }
-      }
+      const h16x2 o = level_features(p, l, xn, lane, base_row);
+      if (row < p.rows) planes[(size_t)l * p.rows + row] = o;
     }
   }
 }
@@ -309,8 +279,8 @@ extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16,
   ALN_REQUIRE(e->use_grid && table_f16 && planes_ws && enc_out, "encode_fwd_phased: needs a grid encoding, its table and the plane workspace");
   if (rows == 0) return 0;
   const int lg = ENC_LG;
-  const int nblk = (rows + 255) / 256, nblk_g = (rows + 256 * PH_RG - 1) / (256 * PH_RG), ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
-  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk_g * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk_g, lg);
+  const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
+  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
   ALN_CHECK_LAUNCH("encode_grid_phased");
   hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
                      (const h16x2*)planes_ws, (h16*)enc_out);
@@ -361,8 +331,8 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
   if (rows == 0) return 0;
   if (e->use_grid && planes_ws) {
     const int lg = ENC_LG;
-    const int nblk = (rows + 255) / 256, nblk_g = (rows + 256 * PH_RG - 1) / (256 * PH_RG), ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
-    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk_g * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk_g, lg);
+    const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
+    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
     ALN_CHECK_LAUNCH("encode_grid_phased");
     hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
                        (const h16x2*)planes_ws, (h16*)enc_out);
