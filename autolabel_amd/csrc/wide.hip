@@ -312,7 +312,7 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
 struct WideTN {
   WideSrc a; int M, N, K;
   const h16* g; int ldg;     // [M, ldg], N columns used
-  float* dw; int lddw;       // [N, lddw] fp32, accumulated with atomics
+  float* ws;                 // [slabs][N][K] fp32 partial sums, one slab per block row range; k_wide_dw_reduce adds them to dW in a fixed order
   int slab;                  // sample rows per block
   int tn, tk;                // output tiles in n and k
 };
@@ -411,32 +411,64 @@ __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
       const int k = k0 + wk + 32 * j + c;
       if (k >= p.K) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; ++r) {   // the block's part of its slab of partial sums [N][K]: plain stores, every element written once
         const int n = n0 + wn + 32 * i + 8 * (r >> 2) + 4 * hf + (r & 3);
-        if (n < p.N && acc[i][j][r] != 0.f) unsafeAtomicAdd(p.dw + (size_t)n * p.lddw + k, acc[i][j][r]);
+        if (n < p.N) p.ws[((size_t)slab_i * p.N + n) * p.K + k] = acc[i][j][r];
       }
     }
 }
 
+// dW[n][k] += sum over the slabs of partial sums, slab 0 first: fixed order, no atomics (the fp32 atomic flush of rounds 1-2 made the
+// weight gradients of the LSeg-width heads -- and with them every LSeg training run -- depend on the order blocks finished in)
+__global__ __launch_bounds__(256) void k_wide_dw_reduce(const float* __restrict__ ws, int slabs, int N, int K, float* __restrict__ dw, int lddw) {
+  const size_t nk = (size_t)N * K;
+  for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < nk; e += (size_t)gridDim.x * 256) {
+    float acc = 0.f;
+    int sI = 0;
+    for (; sI + 8 <= slabs; sI += 8) {   // eight loads in flight, added in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(sI + u) * nk + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sI < slabs; ++sI) acc += ws[(size_t)sI * nk + e];
+    dw[(e / K) * (size_t)lddw + e % K] += acc;
+  }
+}
+static void wide_tn_split(int M, int N, int K, int& tn, int& tk, int& slab, int& slabs) {
+  tn = (N + WTN_TN - 1) / WTN_TN; tk = (K + WTN_TK - 1) / WTN_TK;
+  // enough slabs to fill the chip (>= ~1024 blocks), each a multiple of the 64-row tile
+  slabs = (1024 + tn * tk - 1) / (tn * tk);
+  slab = ((M + slabs - 1) / slabs + WTN_BM - 1) / WTN_BM * WTN_BM;
+  if (slab < WTN_BM) slab = WTN_BM;
+  slabs = (M + slab - 1) / slab;
+}
+extern "C" int64_t aln_wide_tn_ws_bytes(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int tn, tk, slab, slabs;
+  wide_tn_split(M, N, K, tn, tk, slab, slabs);
+  return (int64_t)slabs * N * K * (int64_t)sizeof(float);
+}
 extern "C" int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo,
-                           int32_t G, int32_t M, int32_t N, float* dw, int32_t lddw, void* stream) {
-  ALN_REQUIRE(g && dw && (a1 || geo) && M >= 0 && N > 0, "wide_tn: bad arguments");
+                           int32_t G, int32_t M, int32_t N, float* dw, int32_t lddw, void* ws, void* stream) {
+  ALN_REQUIRE(g && dw && ws && (a1 || geo) && M >= 0 && N > 0, "wide_tn: bad arguments");
   ALN_REQUIRE(ldg % 8 == 0 && N % 8 == 0 && K1 % 8 == 0 && (!a1 || lda1 % 8 == 0), "wide_tn: N / K1 / leading dimensions must be multiples of 8");
   if (M == 0) return 0;
   WideTN p;
   p.a = WideSrc{(const h16*)a1, lda1, a1 ? K1 : 0, relu1, (const h16*)geo, G};
   p.M = M; p.N = N; p.K = p.a.K1 + (geo ? 16 : 0);
-  p.g = (const h16*)g; p.ldg = ldg; p.dw = dw; p.lddw = lddw;
+  p.g = (const h16*)g; p.ldg = ldg; p.ws = (float*)ws;
   ALN_REQUIRE(lddw >= p.K, "wide_tn: gradient rows shorter than K");
-  const int tn = (N + WTN_TN - 1) / WTN_TN, tk = (p.K + WTN_TK - 1) / WTN_TK;
-  // enough slabs to fill the chip (>= ~1024 blocks), each a multiple of the 64-row tile
-  int slabs = (1024 + tn * tk - 1) / (tn * tk);
-  int slab = ((M + slabs - 1) / slabs + WTN_BM - 1) / WTN_BM * WTN_BM;
-  if (slab < WTN_BM) slab = WTN_BM;
-  slabs = (M + slab - 1) / slab;
+  int tn, tk, slab, slabs;
+  wide_tn_split(M, N, p.K, tn, tk, slab, slabs);
   p.slab = slab; p.tn = tn; p.tk = tk;
   hipLaunchKernelGGL(k_wide_tn, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p);
   ALN_CHECK_LAUNCH("wide_tn");
+  const int64_t nk = (int64_t)N * p.K;
+  hipLaunchKernelGGL(k_wide_dw_reduce, dim3((unsigned)((nk + 255) / 256 < 2048 ? (nk + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)ws, slabs, N, p.K, dw, lddw);
+  ALN_CHECK_LAUNCH("wide_dw_reduce");
   return 0;
 }
 

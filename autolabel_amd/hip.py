@@ -66,7 +66,8 @@ _SIGS = {
     'aln_encode_bwd_binned_tile_rows': (i32, []),
     'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'aln_wide_nt': (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp]),
-    'aln_wide_tn': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp]),
+    'aln_wide_tn_ws_bytes': (i64, [i32, i32, i32]),
+    'aln_wide_tn': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]),
     'aln_transpose_f16': (i32, [vp, i32, i32, vp, vp]),
     'aln_mlp_repack': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),

@@ -287,8 +287,10 @@ class HipPipeline:
                 tag=('wide', M, N * (K1 + (16 if geo is not None else 0))))
 
     def _tn(self, M, N, g, dw_off, ldw, a1=None, K1=0, relu1=0, geo=None, tag=None):
+        K = K1 + (16 if geo is not None else 0)
+        scratch = self._tn_ws.scratch('wide_tn_slabs', int(H.lib().aln_wide_tn_ws_bytes(M, N, K)))   # per-block partial sums, reduced in a fixed order
         self._k('aln_wide_tn', H.ptr(g), g.shape[1], H.ptr(a1), a1.shape[1] if a1 is not None else 0, K1, relu1, H.ptr(geo), self.L.G, M, N,
-                C.c_void_p(self.P.grad.data_ptr() + 4 * dw_off), ldw, H.stream(), tag=('wide', M, N * (K1 + (16 if geo is not None else 0))))
+                C.c_void_p(self.P.grad.data_ptr() + 4 * dw_off), ldw, H.ptr(scratch), H.stream(), tag=('wide', M, N * K))
 
     def wide_sem_fwd(self, sout, M, bufs):
         """f = semantic_features([geo, 1]); logits = semantic_out([relu(f), geo, 1]) for M rows of the density head's output.
@@ -493,6 +495,7 @@ class HipPipeline:
         ``grid_adam`` (hip.AlnAdamFuse): the scatter's second phase takes the optimizer step for the table itself instead of adding
         the table's gradient to P.grad (single-GPU training: TrainEngine.step)."""
         L, P, ws = self.L, self.P, c['ws']
+        self._tn_ws = ws      # scratch of the wide heads' weight-gradient GEMMs (_tn)
         assert c['train'], 'backward needs a forward(train=True) context'
         if c.get('serial') != getattr(ws, 'serial', None):
             raise RuntimeError('HipPipeline.backward: another forward() ran through the same workspace since the context was created; '

@@ -245,9 +245,11 @@ int aln_similarity_argmax(const float* features /*[n,D]*/, int32_t n, int32_t D,
 int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo, int32_t G, int32_t M, int32_t N,
                 const void* w, int32_t ldw, void* y, int32_t ldy, int32_t relu, const void* mask, int32_t ldm, const void* add,
                 int32_t lda, int32_t* found_inf, void* stream);
-/* dW[N,K] (fp32, row-major, leading dimension lddw) += G[M,N]^T A[M,K] */
+/* dW[N,K] (fp32, row-major, leading dimension lddw) += G[M,N]^T A[M,K]: row ranges of M go to blocks that write partial sums into
+ * `ws` (aln_wide_tn_ws_bytes(M, N, K) bytes, K = K1 + 16 with geo), added to dW in a fixed order -- no atomics, bit-reproducible */
+int64_t aln_wide_tn_ws_bytes(int32_t M, int32_t N, int32_t K);
 int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo, int32_t G,
-                int32_t M, int32_t N, float* dw, int32_t lddw, void* stream);
+                int32_t M, int32_t N, float* dw, int32_t lddw, void* ws, void* stream);
 int aln_transpose_f16(const void* src /*[R,C]*/, int32_t R, int32_t C, void* dst /*[C,R]*/, void* stream);
 
 /* ---- occupancy-grid marching (march.hip): the cuda_ray hooks of autolabel/trainer.py:21-23,34-36,176 and

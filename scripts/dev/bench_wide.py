@@ -33,5 +33,6 @@ dw = torch.zeros(512, 528, device=dev)
 for (N, K1, geo, name) in [(512, 512, False, 'dW 512x512'), (64, 512, True, 'dW 64x528'), (512, 0, True, 'dW 512x16')]:
     K = K1 + (16 if geo else 0)
     gg = g[:, :N].contiguous() if N != 512 else g
-    t = timeit(lambda: H.call('aln_wide_tn', H.ptr(gg), N, H.ptr(x) if K1 else None, 512, K1, 0, H.ptr(sout) if geo else None, 15, M, N, H.ptr(dw), K, H.stream()))
+    tn_ws = torch.empty(int(H.lib().aln_wide_tn_ws_bytes(M, N, K)), dtype=torch.uint8, device='cuda')
+    t = timeit(lambda: H.call('aln_wide_tn', H.ptr(gg), N, H.ptr(x) if K1 else None, 512, K1, 0, H.ptr(sout) if geo else None, 15, M, N, H.ptr(dw), K, H.ptr(tn_ws), H.stream()))
     print(f'tn {name:22s}: {t * 1e6:8.0f} us  {2.0 * M * N * K / t / 1e12:7.1f} TFLOP/s')

@@ -270,6 +270,35 @@ def test_training_is_bit_reproducible_run_to_run():
             assert torch.equal(x, y), f'march={march}: {(x != y).sum().item()} of {x.numel()} values differ between two identical runs'
 
 
+def test_lseg_training_is_bit_reproducible_run_to_run():
+    """The LSeg-width heads (512-d features, wide.hip): their weight-gradient GEMM adds per-row-range partial sums in a fixed order
+    (rounds 1-2 flushed them with fp32 atomics), so two identical runs agree bit for bit -- with the semantic loss (every GEMM per
+    sample) and with semantic_weight = 0 (the linear last layer per ray)."""
+    from autolabel_amd import synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    scene = synthetic.make_room_scene(n_frames=8, w=64, h=48, fx=32.0, fy=32.0, cx=31.5, cy=23.5, feat_dim=64, feat_hw=(6, 8), labelled_every=2)
+    frames = DeviceFrames.from_scene(scene, 'cuda')
+    for sem_w in (1.0, 0.0):
+        finals = []
+        for _ in range(2):
+            layout = ModelLayout('hg+freq', 15, 128, 128, 512, scene['n_classes'], bound=6.0)
+            P = Params(layout, torch.device('cuda'))
+            P.init_(seed=0)
+            eng = TrainEngine(HipPipeline(layout, P), num_steps=32, upsample_steps=32, feature_loss=True, semantic_weight=sem_w)
+            assert eng.sem_linear == (sem_w == 0.0)
+            batch = frames.alloc_batch(1024)
+            for it in range(6):
+                frames.next_train(batch, seed=5, step=it)
+                eng.step(batch, seed=9, step=it)
+            torch.cuda.synchronize()
+            assert int(eng.state_i[0].item()) > 0
+            finals.append((P.flat.clone(), eng.m.clone(), eng.v.clone()))
+        for x, y in zip(*finals):
+            assert torch.equal(x, y), f'semantic_weight={sem_w}: {(x != y).sum().item()} of {x.numel()} values differ between two identical runs'
+
+
 def test_grid_adam_inside_the_scatter_equals_the_separate_optimizer_bit_for_bit():
     """On one GPU the scatter's second phase takes the Adam step for the hash table itself (TrainEngine.fuse_grid_adam); the
     gradient-through-HBM route (what a data-parallel run uses: P.grad, then aln_adam_step over everything) must leave every

@@ -136,7 +136,8 @@ def test_wide_tn_full_size_weight_gradient_is_the_adjoint(H, M, N, K1, geo, relu
     so = rn(M, 16, sc=0.5) if geo else None
     G = rn(M, N, sc=0.05)
     dw = torch.zeros(N, K, device='cuda')
-    H.call('aln_wide_tn', H.ptr(G), N, H.ptr(a1), K1, K1, int(relu1), H.ptr(so), 15, M, N, H.ptr(dw), K, H.stream())
+    ws = torch.empty(int(H.lib().aln_wide_tn_ws_bytes(M, N, K)), dtype=torch.uint8, device='cuda')
+    H.call('aln_wide_tn', H.ptr(G), N, H.ptr(a1), K1, K1, int(relu1), H.ptr(so), 15, M, N, H.ptr(dw), K, H.ptr(ws), H.stream())
     torch.cuda.synchronize()
     A = []
     if K1:

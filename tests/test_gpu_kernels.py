@@ -826,10 +826,15 @@ def test_wide_tn_weight_gradient_matches_fp32(H, M, N, K1, geo, relu1):
     want = gr.float().t() @ A
     dw = torch.ones(N, K, device='cuda')
     a1d, sd, gd = a1.cuda(), sout.cuda(), gr.cuda()
+    ws = torch.empty(int(H.lib().aln_wide_tn_ws_bytes(M, N, K)), dtype=torch.uint8, device='cuda')
     H.call('aln_wide_tn', H.ptr(gd), N, H.ptr(a1d) if K1 else None, a1d.shape[1], K1, relu1, H.ptr(sd) if geo else None, G, M, N, H.ptr(dw), K,
-           H.stream())
+           H.ptr(ws), H.stream())
     got = dw.cpu() - 1.0
     assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+    again = torch.ones(N, K, device='cuda')     # partial sums per row range, added in a fixed order: bit-reproducible
+    H.call('aln_wide_tn', H.ptr(gd), N, H.ptr(a1d) if K1 else None, a1d.shape[1], K1, relu1, H.ptr(sd) if geo else None, G, M, N, H.ptr(again), K,
+           H.ptr(ws), H.stream())
+    assert torch.equal(again, dw)
 
 
 def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
