@@ -628,10 +628,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   // (a tile that was scaled DOWN carries records up to 2^(16 - shift): the double-precision conversion needs them below 2^51 units)
   { const unsigned long long bd = bound_s; const int lg = bd ? 64 - __clzll(bd) : 0; U = min(FX_UNIT_LOG2 + smin_s, 62 - lg); }   // bd < 2^lg
   const uint2* pool = a.pool + (size_t)l * a.ntiles * BIN_CHUNK;
-  bool bad = false;   // a non-finite record (inf / nan upstream, or an fp16 overflow of a run sum)
+  uint32_t badbits = 0u;   // bit 15 / 31 set by a record whose low / high half is inf or nan (exponent all ones: + 0x0400 carries out of the field)
   auto add = [&](uint2 r, int ex) {   // ex = U - shift of the run's tile
     const h16x2 hv = *(const h16x2*)&r.y;
-    bad |= (r.y & 0x7C00u) == 0x7C00u || (r.y & 0x7C000000u) == 0x7C000000u;
+    badbits |= (r.y & 0x7C007C00u) + 0x04000400u;
     atomicAdd((unsigned long long*)&acc[r.x], (unsigned long long)fx_from_half_d(hv[0], ex));
     atomicAdd((unsigned long long*)&acc[plane + r.x], (unsigned long long)fx_from_half_d(hv[1], ex));
   };
@@ -678,6 +678,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
       }
     }
   }
+  const bool bad = (badbits & 0x80008000u) != 0u;
   __syncthreads();
   const size_t g0 = 2 * ((size_t)a.offset[l] + e0);
   const double unit = ldexp(1.0, -U);
