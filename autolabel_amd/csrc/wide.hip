@@ -353,6 +353,9 @@ __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
   const int n0 = (tile_i % p.tn) * WTN_TN, k0 = (tile_i / p.tn) * WTN_TK;
   const int mlo = slab_i * p.slab, mhi = min(p.M, mlo + p.slab);
   const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;   // wave tile 64 (n) x 128 (k): 6 fragment reads per 8 MFMAs
+  // 32-column blocks of this wave's k range that exist at all (the 16-wide geo_feat operand of the first layer fills ONE block of one
+  // wave column: multiplying the 15 empty ones made that 512 x 16 GEMM cost as much as a 512 x 256 one)
+  const int nbj = __builtin_amdgcn_readfirstlane(max(0, min(4, (p.K - k0 - wk + 31) / 32)));
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -396,11 +399,11 @@ __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) ga[i] = wtr_frag(tG, wn + 32 * i, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ab[j] = wtr_frag(tA, wk + 32 * j, ks, lane);
+      for (int j = 0; j < 4; ++j) if (j < nbj) ab[j] = wtr_frag(tA, wk + 32 * j, ks, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = wmfma(ga[i], ab[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) if (j < nbj) acc[i][j] = wmfma(ga[i], ab[j], acc[i][j]);
     }
   }
   // lane holds column k = k0 + wk + 32 j + c; register r of block (i, j) is row n = n0 + wn + 32 i + 8 (r / 4) + 4 hf + r % 4
