@@ -299,6 +299,29 @@ def test_lseg_training_is_bit_reproducible_run_to_run():
             assert torch.equal(x, y), f'semantic_weight={sem_w}: {(x != y).sum().item()} of {x.numel()} values differ between two identical runs'
 
 
+def _fused_vs_separate(frames, scene, march, batch, samples, steps, scale):
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    engs = []
+    for fuse in (True, False):
+        layout = ModelLayout('hg+freq', 15, 128, 128, 64, scene['n_classes'], bound=6.0)
+        P = Params(layout, torch.device('cuda'))
+        P.init_(seed=0)
+        eng = TrainEngine(HipPipeline(layout, P), num_steps=samples, upsample_steps=samples, fuse_grid_adam=fuse, scaler={'init_scale': scale})
+        engs.append((eng, P, frames.alloc_batch(batch)))
+    for it in range(steps):
+        for eng, P, b in engs:
+            frames.next_train(b, seed=5, step=it)
+            eng.step(b, seed=9, step=it)
+        (ea, Pa, _), (eb, Pb, _) = engs
+        for name, x, y in [('params', Pa.flat, Pb.flat), ('m', ea.m, eb.m), ('v', ea.v, eb.v), ('table16', Pa.table16, Pb.table16),
+                           ('state_i', ea.state_i, eb.state_i)]:
+            assert torch.equal(x, y), f'batch {batch} step {it}: {name} differs in {(x != y).sum().item()} of {x.numel()} values'
+    assert int(engs[0][0].state_i[0].item()) == steps
+    del engs
+    torch.cuda.empty_cache()
+
+
 def test_grid_adam_inside_the_scatter_equals_the_separate_optimizer_bit_for_bit():
     """On one GPU the scatter's second phase takes the Adam step for the hash table itself (TrainEngine.fuse_grid_adam); the
     gradient-through-HBM route (what a data-parallel run uses: P.grad, then aln_adam_step over everything) must leave every
@@ -310,6 +333,7 @@ def test_grid_adam_inside_the_scatter_equals_the_separate_optimizer_bit_for_bit(
     from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
     scene = synthetic.make_cube_scene(n_frames=8)
     frames = DeviceFrames.from_scene(scene, 'cuda')
+    _fused_vs_separate(frames, scene, march=False, batch=4096, samples=128, steps=3, scale=2.0 ** 10)   # the bench's launch sizes (2^20 rows)
     for march in (False, True):
         engs = []
         for fuse in (True, False):

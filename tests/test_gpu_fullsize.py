@@ -110,6 +110,25 @@ def test_binned_scatter_is_the_adjoint_of_the_gather_at_full_size(H):
     for lo, hi in ((12, 16), (8, 12), (4, 8), (0, 4)):
         binned(g3, lo=lo, hi=hi)
     assert torch.equal(g3, grad)
+    # the depth-order walk of the training step (coarse and fine samples of a ray interleaved by depth): the adjoint identity and
+    # the reproducibility hold for it too, with fewer records than the pass-major walk
+    order = torch.cat([z[:M1].view(N, S1), z[M1:].view(N, S2)], 1).argsort(dim=1, stable=True).to(torch.int16).contiguous()
+
+    def records():
+        tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
+        nt, nl = (M + tile - 1) // tile, 16
+        pool = nl * nt * tile * 8 * 8
+        return int(((ws[pool:pool + nl * 64 * nt * 4].view(torch.int32) >> 13) & 0x3FFF).sum().item())
+    n_plain = records()     # (of the last pass-major launch over all levels... the level groups wrote the same descriptors)
+    walk, walk2 = torch.zeros_like(grad), torch.zeros_like(grad)
+    for dst in (walk, walk2):
+        H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, S2, H.ptr(order), H.ptr(d_enc), H.ptr(dst),
+               H.ptr(ws), 0, 16, H.ptr(flag), None, H.stream())
+    assert torch.equal(walk, walk2) and flag.item() == 0
+    rhs_w = (table.double().reshape(-1) * walk.double()).sum().item()
+    assert abs(lhs - rhs_w) <= 2.0 ** -10 * scale * 0.05 + 1e-6 * scale, (lhs, rhs_w, scale)
+    assert (walk - grad).norm().item() <= 1e-3 * grad.norm().item()
+    assert records() < n_plain
 
 
 def test_render_is_ray_independent_and_bounded_at_full_batch():
