@@ -597,8 +597,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   const uint32_t e0 = (uint32_t)s << sl;
   const uint32_t ne = min(1u << sl, a.size[l] - e0);   // entries of this slice (the LDS accumulators beyond them are never touched)
   const uint32_t* d = a.desc + ((size_t)l * BIN_MAX_SLICES + s) * a.ntiles;
-  // Range guard.  A record is below 2^(15 - shift) in magnitude (2^16 for shift 0: the tile was not scaled), so the sum over the
-  // runs of count * that bounds any accumulator of the slice; if that bound times 2^35 could pass 2^62, the block accumulates in a coarser unit 2^-U
+  // Range guard.  A record is below 2^(15 - shift) in magnitude (phase 1 scales every tile's largest value into [2^14, 2^15), up or
+  // down), so the sum over the runs of count * that bounds any accumulator of the slice; if that bound times 2^35 could pass 2^62, the block accumulates in a coarser unit 2^-U
   // (records are then ROUNDED to it -- still one fixed integer per record, so the sums stay order-independent).  In training
   // this never triggers for the hashed levels; it is what lets the two coarsest levels (thousands of records per entry at the
   // largest loss scales) share the exact path.
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     const bool skip = adam_c[0] != 0.f;
     const float inv_scale = adam_c[1], step_size = adam_c[2], inv_sqrt_bc2 = adam_c[3];
     const float b1 = a.ad.beta1, b2 = a.ad.beta2, c1 = 1.f - a.ad.beta1, c2 = 1.f - a.ad.beta2, eps = a.ad.eps;
-    if (!skip) {
+    if (!skip && !bad) {   // (bad without skip: a caller fed non-finite records without raising the flag -- never write them into the parameters)
       float2* const P2 = (float2*)(a.ad.p + g0); float2* const M2 = (float2*)(a.ad.m + g0); float2* const V2 = (float2*)(a.ad.v + g0);
       h16x2* const T2 = (h16x2*)(a.ad.t16 + g0);
       for (uint32_t e = tid; e < ne; e += ACC_THREADS) {
