@@ -11,4 +11,4 @@ cp autolabel_amd/csrc/libautolabel_hip.so /tmp/lib_product.so
 stats product "$PAT"
 for v in "$@"; do cp scripts/dev/_build/lib_$v.so autolabel_amd/csrc/libautolabel_hip.so; stats $v "$PAT"; done
 cp /tmp/lib_product.so autolabel_amd/csrc/libautolabel_hip.so
-python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize.py tests/test_gpu_pipeline.py tests/test_gpu_march.py -q -x 2>&1 | tail -2
+
