@@ -89,8 +89,9 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   lds_h16* const t1 = (lds_h16*)smem;           // [128 features][PH]  h1   ([feature][sample])
   lds_h16* const t2 = t1 + HID * PH;            //                     dA2  (phase D: the d_in rows of the tile, staged for whole-row stores)
   lds_h16* const t3 = t2 + HID * PH;            //                     dA1
-  lds_h16* const tXb = t3 + HID * PH;           // 2 x [128][PX]  x, row-major, double-buffered
-  lds_h16* const tOb = tXb + 2 * TR * PX;       // 2 x [128][PO]  dL/dout, row-major
+  lds_h16* const w0t = t3 + HID * PH;           // IB * 8 fragments of W0^T (wb image, layer 0): d_in's A operand, every wave reads all of it
+  lds_h16* const tXb = w0t + IB * KS * 512;     // 2 x [128][PX]  x, row-major, double-buffered
+  lds_h16* const tO = tXb + 2 * TR * PX;        // [128][PO]      dL/dout, row-major (dead after phase B: refilled in phase C)
   const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (rows_dev) rows = min(rows, *rows_dev);
@@ -99,7 +100,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   // ---- resident weight slices (fragment images of aln_mlp_repack: one 16-byte load per fragment and lane)
   const h16x8* const wf8 = (const h16x8*)wf_g;
   const h16x8* const wb8 = (const h16x8*)wb_g;
-  h16x8 B0[KS0], B1[KS], B1T[KS], BL, W0T[IB][KS];
+  h16x8 B0[KS0], B1[KS], B1T[KS], BL;
 #pragma unroll
   for (int ks = 0; ks < KS0; ++ks) B0[ks] = wf8[(size_t)(wave * KS0 + ks) * 64 + lane];            // W0[32w + n][natural k]
 #pragma unroll
@@ -107,30 +108,35 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   BL = wb8[(size_t)wave * 64 + lane];                                                              // WL[o][32w + n]
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) B1T[ks] = wb8[(size_t)(4 + wave * KS + ks) * 64 + lane];         // W1[chained o][32w + i]
-#pragma unroll
-  for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) W0T[ib][ks] = wb8[(size_t)(36 + ib * KS + ks) * 64 + lane];    // W0[chained o][32 ib + i]  (d_in: every wave, all of it)
-  for (int i = threadIdx.x; i < (2 * TR * (PX + PO) + 64) / 8; i += 256) ((uint4*)tXb)[i] = make_uint4(0, 0, 0, 0);
+  {
+    const uint4* src = (const uint4*)(wb8 + (size_t)36 * 64);                                      // W0[chained o][32 ib + i]
+    for (int i = threadIdx.x; i < IB * KS * 64; i += 256) ((uint4*)w0t)[i] = src[i];
+    for (int i = threadIdx.x; i < (2 * TR * PX + TR * PO + 64) / 8; i += 256) ((uint4*)tXb)[i] = make_uint4(0, 0, 0, 0);
+  }
 
   // ---- tile load: 16-byte chunks requested one tile ahead, parked in registers, stashed into the buffer of the NEXT tile
   h16x8 px[NXS], po;
-  auto prefetch = [&](int r0) __attribute__((always_inline)) {
+  auto prefetch_x = [&](int r0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
       const int i = threadIdx.x + 256 * q, r = i / XCH, k = i % XCH;
       if (i < TR * XCH && r0 + r < rows) px[q] = *(const h16x8*)(x_g + (size_t)(r0 + r) * IN + 8 * k);
     }
+  };
+  auto prefetch_o = [&](int r0) __attribute__((always_inline)) {
     const int r = threadIdx.x >> 1, k = threadIdx.x & 1;
     if (r0 + r < rows) po = *(const h16x8*)(do_g + (size_t)(r0 + r) * OUT + 8 * k);
   };
-  auto stash = [&](int r0, lds_h16* tX, lds_h16* tO) __attribute__((always_inline)) {
+  auto stash_x = [&](int r0, lds_h16* tX) __attribute__((always_inline)) {
     const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
       const int i = threadIdx.x + 256 * q, r = i / XCH, k = i % XCH;
       if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX + r * PX + 8 * k) = (r0 + r < rows) ? px[q] : z;
     }
+  };
+  auto stash_o = [&](int r0) __attribute__((always_inline)) {
+    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     const int r = threadIdx.x >> 1, k = threadIdx.x & 1;
     *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = (r0 + r < rows) ? po : z;
   };
@@ -145,223 +151,253 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   h16x2 nanz = {0, 0};
 #define SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
 
-  // h1 = relu(x W0^T), own slice -> t1 (first layer of a tile; runs one tile ahead, inside phase D of the tile before)
-  auto layer0 = [&](const lds_h16* tX) __attribute__((always_inline)) {
-    f32x16 acc[4];
-    h16x8 a[2][4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) a[0][rb] = *(const LDS_VEC(h16x8)*)(tX + (32 * rb + c) * PX + 8 * hf);
-#pragma unroll
-    for (int ks = 0; ks < KS0; ++ks) {
-      if (ks + 1 < KS0) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) a[(ks + 1) & 1][rb] = *(const LDS_VEC(h16x8)*)(tX + (32 * rb + c) * PX + 16 * (ks + 1) + 8 * hf);
-      }
-      SCHED_FENCE;
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb] = mfma16(a[ks & 1][rb], B0[ks], ks == 0 ? zero16 : acc[rb]);
-    }
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) { Pk hp; relu_pack(acc[rb], hp); write_slice(t1, wave, rb, hp, lane); }
-  };
+  // A fragments of the register chain come from an LDS tile through a ring of RING slots, requested DEPTH steps ahead: one wave
+  // per SIMD has nothing but its own instruction stream to hide the ~300-tick LDS latency behind, and a step (two MFMAs of the
+  // chain, two of the weight gradients) is 64-128 ticks long.
+  constexpr int DEPTH = 4, RING = 5;
+  constexpr int PIECES = 32 * IN / 8, NPC = (PIECES + 63) / 64;   // 16-byte pieces of a wave's 32 d_in rows (contiguous in d_in)
+  u32x4 dst[NPC];                           // d_in rows of the PREVIOUS tile as whole pieces, stored early in the next phase B
+  int dprev_row0 = -1;
+  h16x8 l0a[4];                             // first-k-step x fragments of the next tile's first layer, requested before the barrier
 
-  // The weight loads must have LANDED before the loop is entered: otherwise hipcc's wait-count pass, merging the loop's two
-  // entries, guards the first use of every weight register inside the loop with a counted vmcnt wait -- which, from the second
-  // pass on, waits for the tile prefetch issued a moment earlier instead (measured: 2 000 ticks of exposed memory latency per tile).
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-#pragma unroll
-  for (int ks = 0; ks < KS0; ++ks) asm volatile("" : "+v"(B0[ks]));
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) { asm volatile("" : "+v"(B1[ks])); asm volatile("" : "+v"(B1T[ks])); }
-  asm volatile("" : "+v"(BL));
-#pragma unroll
-  for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(W0T[ib][ks]));
   PT_DECL
   if ((int)blockIdx.x < ntiles) {
-    prefetch(blockIdx.x * TR);
+    prefetch_x(blockIdx.x * TR); prefetch_o(blockIdx.x * TR);
     __syncthreads();                       // zero fill done
-    stash(blockIdx.x * TR, tXb, tOb);
-    { const int nt = blockIdx.x + gridDim.x; if (nt < ntiles) prefetch(nt * TR); }
+    stash_x(blockIdx.x * TR, tXb); stash_o(blockIdx.x * TR);
+    { const int nt = blockIdx.x + gridDim.x; if (nt < ntiles) { prefetch_x(nt * TR); prefetch_o(nt * TR); } }
     __syncthreads();
-    layer0(tXb);
+    {   // first layer of the first tile (every later one runs inside phase D of the tile before)
+      f32x16 acc[4];
+#pragma unroll
+      for (int ks = 0; ks < KS0; ++ks)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+          acc[rb] = mfma16(*(const LDS_VEC(h16x8)*)(tXb + (32 * rb + c) * PX + 16 * ks + 8 * hf), B0[ks], ks == 0 ? zero16 : acc[rb]);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) { Pk hp; relu_pack(acc[rb], hp); write_slice(t1, wave, rb, hp, lane); }
+    }
     __syncthreads();
   }
   int cur = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, cur ^= 1) {
     const int r0 = tile * TR;
     const lds_h16* const tX = tXb + cur * (TR * PX);
-    const lds_h16* const tO = tOb + cur * (TR * PO);
     lds_h16* const tXn = tXb + (cur ^ 1) * (TR * PX);
-    lds_h16* const tOn = tOb + (cur ^ 1) * (TR * PO);
     const bool more = tile + (int)gridDim.x < ntiles;
+    const int nt2 = tile + 2 * gridDim.x;
     f32x16 acc[4];
     PT_STAMP(0)
-    // ---- phase B: dH2 = dOut WL (while the first h1 fragments are on their way), h2 = relu(h1 W1^T) (registers only),
-    //      dA2 = dH2 * relu'(h2) -> t2, dW_last
+    // =====================================================================================================================
+    // phase B: h2 = relu(h1 W1^T) (registers only), dH2 = dOut WL, dA2 = dH2 * relu'(h2) -> t2, dW_last.  Beside it: the previous
+    //          tile's d_in rows leave, the next tile's x rows go into the other buffer.
+    // The chain runs row-block PAIR by pair (two independent accumulators per step), so the epilogue of the first pair (last
+    // layer's backward, ReLU, mask, pack, dW_last) sits between the MFMAs of the second.
     Pk da2[4];
     {
-      h16x8 a[2][4], ao[4];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) ao[rb] = *(const LDS_VEC(h16x8)*)(tO + (32 * rb + c) * PO + 8 * hf);
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) a[0][rb] = act_frag(t1, rb, 0, lane);
-      SCHED_FENCE;
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb] = mfma16(ao[rb], BL, zero16);
-      Pk dh2[4];   // dH2 as packed halves (the conversion mask2 would do; the ReLU mask follows once h2 exists)
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int v = 0; v < 8; ++v) dh2[rb].q[v >> 2][v & 3] = cvt_pk(acc[rb][2 * v], acc[rb][2 * v + 1]);
-      h16x8 fo[8];   // dOut^T fragments of dW_last (A operand), requested during the layer
-      PT_STAMP(20)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) a[(ks + 1) & 1][rb] = act_frag(t1, rb, ks + 1, lane);
-        }
-        if (ks >= 4) {
-          fo[2 * (ks - 4)] = tr_frag_chained(PlainV<const lds_h16*>{tO, PO}, 0, 2 * (ks - 4), lane);
-          fo[2 * (ks - 4) + 1] = tr_frag_chained(PlainV<const lds_h16*>{tO, PO}, 0, 2 * (ks - 4) + 1, lane);
-        }
-        SCHED_FENCE;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = mfma16(a[ks & 1][rb], B1[ks], ks == 0 ? zero16 : acc[rb]);
-      }
-      PT_STAMP(21)
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
+      h16x8 a[RING][2], ao[2], fo[2][2];
+      f32x16 lacc[2];
+      auto req = [&](int s) __attribute__((always_inline)) {   // step s = (pair s >> 3, k step s & 7)
+        a[s % RING][0] = act_frag(t1, 2 * (s >> 3), s & 7, lane);
+        a[s % RING][1] = act_frag(t1, 2 * (s >> 3) + 1, s & 7, lane);
+      };
+      auto prep = [&](int rb) __attribute__((always_inline)) {   // dL/dout rows of the block (A operand of the last layer's backward) and their transposes (dW_last)
+        ao[rb & 1] = *(const LDS_VEC(h16x8)*)(tO + (32 * rb + c) * PO + 8 * hf);
+        fo[rb & 1][0] = tr_frag_chained(PlainV<const lds_h16*>{tO, PO}, 0, 2 * rb, lane);
+        fo[rb & 1][1] = tr_frag_chained(PlainV<const lds_h16*>{tO, PO}, 0, 2 * rb + 1, lane);
+      };
+      auto last = [&](int rb) __attribute__((always_inline)) { lacc[rb & 1] = mfma16(ao[rb & 1], BL, zero16); };
+      auto epilogue = [&](int rb) __attribute__((always_inline)) {
         Pk h2p;
         relu_pack(acc[rb], h2p);
         // dW_last[o][32w + n] += sum_s dOut[s][o] h2[s][n]
-        mfma_acc(dwl, fo[2 * rb], as_frag(h2p.q[0]));
-        mfma_acc(dwl, fo[2 * rb + 1], as_frag(h2p.q[1]));
+        mfma_acc(dwl, fo[rb & 1][0], as_frag(h2p.q[0]));
+        mfma_acc(dwl, fo[rb & 1][1], as_frag(h2p.q[1]));
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-          uint32_t m;
-          asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(m) : "v"(h2p.q[v >> 2][v & 3]));
-          asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(da2[rb].q[v >> 2][v & 3]) : "v"(dh2[rb].q[v >> 2][v & 3]), "v"(m));
-        }
+        for (int v = 0; v < 8; ++v) da2[rb].q[v >> 2][v & 3] = mask2(lacc[rb & 1][2 * v], lacc[rb & 1][2 * v + 1], h2p.q[v >> 2][v & 3]);
         write_slice(t2, wave, rb, da2[rb], lane);
+      };
+#pragma unroll
+      for (int s = 0; s < DEPTH; ++s) req(s);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (s + DEPTH < 16) req(s + DEPTH);
+        if (s == 2 && dprev_row0 >= 0 && d_in) {
+#pragma unroll
+          for (int i = 0; i < NPC; ++i) {
+            const int pc = lane + 64 * i;
+            if (pc < PIECES && dprev_row0 + pc / (IN / 8) < rows) *(u32x4*)(d_in + (size_t)dprev_row0 * IN + 8 * pc) = dst[i];
+          }
+        }
+        if (s == 5 && more) stash_x((tile + gridDim.x) * TR, tXn);
+        if (s == 6 && more && nt2 < ntiles) prefetch_x(nt2 * TR);
+        if (s == 8) prep(0);
+        if (s == 10) prep(1);
+        if (s == 13) prep(2);
+        SCHED_FENCE;
+        const int p = s >> 3, ks = s & 7;
+        acc[2 * p] = mfma16(a[s % RING][0], B1[ks], ks == 0 ? zero16 : acc[2 * p]);
+        acc[2 * p + 1] = mfma16(a[s % RING][1], B1[ks], ks == 0 ? zero16 : acc[2 * p + 1]);
+        if (s == 9) last(0);
+        if (s == 10) epilogue(0);
+        if (s == 11) last(1);
+        if (s == 12) epilogue(1);
+        if (s == 14) last(2);
       }
+      prep(3);
+      epilogue(2);
+      last(3);
+      epilogue(3);
     }
-    PT_STAMP(22)
-    // first two k steps of dW_mid's LDS operand (h1, complete since the barrier at the top): in flight across the barrier
+    // first two k steps of dW_mid's LDS operand (h1, complete since the barrier at the top): requested before the barrier
     h16x8 bm[3][4];
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib) { bm[0][ib] = samp_frag(t1, ib, 0, 0, lane); bm[1][ib] = samp_frag(t1, ib, 0, 1, lane); }
-    PT_STAMP(1) __syncthreads(); PT_STAMP(2)   // B_b: t2 complete
+    PT_STAMP(1) __syncthreads(); PT_STAMP(2)   // B_b: t2 complete, the next tile's x in place, dOut dead
 
-    // ---- phase C: dH1 = dA2 W1 (own input slice), dA1 = dH1 * relu'(h1) -> t3 ; dW_mid beside it.
-    // The weight-gradient MFMAs of the first two k steps run while the first dA2 fragments arrive, those of the last two
-    // beside the mask / pack epilogue of the chain.
+    // =====================================================================================================================
+    // phase C: dH1 = dA2 W1 (own input slice), dA1 = dH1 * relu'(h1) -> t3 ; dW_mid beside it: its first two k steps while the first
+    //          dA2 fragments arrive, its last beside the mask / pack epilogue of the second pair.  The next tile's dOut rows go in.
     Pk da1[4];
     {
-      h16x8 a[2][4];
-      u32x2 m[4][4];
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) a[0][rb] = act_frag(t2, rb, 0, lane);
-      auto dw = [&](int ks) __attribute__((always_inline)) {   // dW_mid[32w + n][i] += sum_s dA2[s][n] h1[s][i], k step = (row block ks >> 1, half ks & 1)
-        if (ks + 2 < KS) {
-#pragma unroll
-          for (int ib = 0; ib < 4; ++ib) bm[(ks + 2) % 3][ib] = samp_frag(t1, ib, (ks + 2) >> 1, (ks + 2) & 1, lane);
-        }
-        SCHED_FENCE;
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) mfma_acc(dwm[ib], as_frag(da2[ks >> 1].q[ks & 1]), bm[ks % 3][ib]);
+      h16x8 a[RING][2];
+      u32x2 m[2][4];
+      auto req = [&](int s) __attribute__((always_inline)) {
+        a[s % RING][0] = act_frag(t2, 2 * (s >> 3), s & 7, lane);
+        a[s % RING][1] = act_frag(t2, 2 * (s >> 3) + 1, s & 7, lane);
       };
-      auto chain = [&](int ks) __attribute__((always_inline)) {
-        if (ks + 1 < KS) {
+      auto dw = [&](int kd, int ib0, int n) __attribute__((always_inline)) {   // dW_mid[32w + n][i] += sum_s dA2[s][n] h1[s][i], k step kd = (row block, half)
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) a[(ks + 1) & 1][rb] = act_frag(t2, rb, ks + 1, lane);
-        }
-        if (ks == KS - 2) {   // h1 of the own slice, for the mask
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) m[rb][q] = *(const LDS_VEC(u32x2)*)(t1 + (32 * wave + c) * PH + 32 * rb + 4 * hf + 8 * q);
-        }
-        SCHED_FENCE;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = mfma16(a[ks & 1][rb], B1T[ks], ks == 0 ? zero16 : acc[rb]);
+        for (int ib = ib0; ib < ib0 + n; ++ib) mfma_acc(dwm[ib], as_frag(da2[kd >> 1].q[kd & 1]), bm[kd % 3][ib]);
       };
-      PT_STAMP(10)
-      dw(0); dw(1);
-      PT_STAMP(11)
-      chain(0); chain(1);
-      PT_STAMP(12)
+      auto req_bm = [&](int kd) __attribute__((always_inline)) {
 #pragma unroll
-      for (int ks = 2; ks < KS - 2; ++ks) { dw(ks); chain(ks); }
-      PT_STAMP(13)
-      chain(KS - 2); chain(KS - 1);
-      PT_STAMP(14)
-      dw(KS - 2);
+        for (int ib = 0; ib < 4; ++ib) bm[kd % 3][ib] = samp_frag(t1, ib, kd >> 1, kd & 1, lane);
+      };
+      auto req_m = [&](int rb, int j) __attribute__((always_inline)) {   // h1 of the own slice, for the mask
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        if (rb == 2) dw(KS - 1);
+        for (int q = 0; q < 4; ++q) m[j][q] = *(const LDS_VEC(u32x2)*)(t1 + (32 * wave + c) * PH + 32 * rb + 4 * hf + 8 * q);
+      };
+      auto epilogue = [&](int rb, int j) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          da1[rb].q[q >> 1][2 * (q & 1)] = mask2(acc[rb][4 * q], acc[rb][4 * q + 1], m[rb][q].x);
-          da1[rb].q[q >> 1][2 * (q & 1) + 1] = mask2(acc[rb][4 * q + 2], acc[rb][4 * q + 3], m[rb][q].y);
+          da1[rb].q[q >> 1][2 * (q & 1)] = mask2(acc[rb][4 * q], acc[rb][4 * q + 1], m[j][q].x);
+          da1[rb].q[q >> 1][2 * (q & 1) + 1] = mask2(acc[rb][4 * q + 2], acc[rb][4 * q + 3], m[j][q].y);
         }
         write_slice(t3, wave, rb, da1[rb], lane);
+      };
+#pragma unroll
+      for (int s = 0; s < DEPTH; ++s) req(s);
+      req_bm(2);
+      SCHED_FENCE;
+      dw(0, 0, 4);
+      req_bm(3);
+      SCHED_FENCE;
+      dw(1, 0, 4);
+      // k steps 2..6 of dW_mid: two MFMAs beside every step of the chain's first ten.  LDS requests are issued one or two at a time
+      // between the MFMAs (a burst of eight against a full queue stalls the wave -- and every MFMA behind it -- until slots free up)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int p = s >> 3, ks = s & 7;
+        if (s + DEPTH < 16) a[(s + DEPTH) % RING][0] = act_frag(t2, 2 * ((s + DEPTH) >> 3), (s + DEPTH) & 7, lane);
+        if (s == 3 && more) stash_o((tile + gridDim.x) * TR);
+        if (s == 4) { req_m(0, 0); if (more && nt2 < ntiles) prefetch_o(nt2 * TR); }
+        if (s == 5) req_m(1, 1);
+        SCHED_FENCE;
+        acc[2 * p] = mfma16(a[s % RING][0], B1T[ks], ks == 0 ? zero16 : acc[2 * p]);
+        SCHED_FENCE;
+        if (s + DEPTH < 16) a[(s + DEPTH) % RING][1] = act_frag(t2, 2 * ((s + DEPTH) >> 3) + 1, (s + DEPTH) & 7, lane);
+        SCHED_FENCE;
+        acc[2 * p + 1] = mfma16(a[s % RING][1], B1T[ks], ks == 0 ? zero16 : acc[2 * p + 1]);
+        SCHED_FENCE;
+        if (s < 10) {
+          const int kd = 2 + s / 2, ib0 = 2 * (s & 1), kn = kd + 2;   // operands of k step kd + 2 are requested beside k step kd
+          if (kn < KS) bm[kn % 3][ib0] = samp_frag(t1, ib0, kn >> 1, kn & 1, lane);
+          SCHED_FENCE;
+          dw(kd, ib0, 1);
+          SCHED_FENCE;
+          if (kn < KS) bm[kn % 3][ib0 + 1] = samp_frag(t1, ib0 + 1, kn >> 1, kn & 1, lane);
+          SCHED_FENCE;
+          dw(kd, ib0 + 1, 1);
+        }
+        if (s == 10) { epilogue(0, 0); req_m(2, 0); }
+        if (s == 12) { epilogue(1, 1); req_m(3, 1); }
       }
+      dw(7, 0, 2);
+      epilogue(2, 0);
+      dw(7, 2, 2);
+      epilogue(3, 1);
     }
-    PT_STAMP(15)
-    // the next tile's x / dOut rows (requested a tile ago) go into the other buffer; then the tile after that is requested
-#ifndef ALN_ABL_NOSTASH
-    if (more) {
-#ifdef ALN_PHASE_TIMING
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      PT_STAMP(17)
-#endif
-      stash((tile + gridDim.x) * TR, tXn, tOn);
-      PT_STAMP(18)
-      const int nt = tile + 2 * gridDim.x;
-      if (nt < ntiles) prefetch(nt * TR);
-    }
-#endif
-    PT_STAMP(16)
-    // phase D's LDS operands that do not depend on t3: x^T fragments of the first two k steps
+    // phase D's LDS operands that do not depend on t3: x^T fragments of the first two k steps, the next tile's first x fragments
     h16x8 bx[3][IB];
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) { bx[0][ib] = tr_frag_chained(PlainV<const lds_h16*>{tX, PX}, 32 * ib, 0, lane); bx[1][ib] = tr_frag_chained(PlainV<const lds_h16*>{tX, PX}, 32 * ib, 1, lane); }
-    PT_STAMP(3) __syncthreads(); PT_STAMP(4)   // B_c: t3 complete, the next tile's x / dOut in place, t1 / t2 free
+    if (more) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) l0a[rb] = *(const LDS_VEC(h16x8)*)(tXn + (32 * rb + c) * PX + 8 * hf);
+    }
+    PT_STAMP(3) __syncthreads(); PT_STAMP(4)   // B_c: t3 complete, t1 / t2 free
 
-    // ---- phase D: d_in^T[i][s] = sum_k W0[k][i] dA1[s][k] for the wave's 32 samples ; dW_first beside it ; then the first layer
-    //      of the NEXT tile (h1 -> t1) and this tile's d_in rows through t2 as whole rows
+    // =====================================================================================================================
+    // phase D: d_in^T[i][s] = sum_k W0[k][i] dA1[s][k] for the wave's 32 samples ; dW_first beside it ; and the first layer of the
+    //          NEXT tile (h1 -> t1), whose MFMAs open the phase while the dA1 fragments arrive.
     {
       f32x16 o[IB];
-      h16x8 b[2];
-      b[0] = act_frag(t3, wave, 0, lane);
-      auto dwf_ = [&](int ks) __attribute__((always_inline)) {   // dW_first[32w + n][i] += sum_s dA1[s][n] x[s][i]
-        if (ks + 2 < KS) {
+      h16x8 b[RING], la[2][4], wa[2][IB];
+      auto req = [&](int ks) __attribute__((always_inline)) { b[ks % RING] = act_frag(t3, wave, ks, lane); };
+      auto req_w = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-          for (int ib = 0; ib < IB; ++ib) bx[(ks + 2) % 3][ib] = tr_frag_chained(PlainV<const lds_h16*>{tX, PX}, 32 * ib, ks + 2, lane);
-        }
-        SCHED_FENCE;
+        for (int ib = 0; ib < IB; ++ib) wa[ks & 1][ib] = *(const LDS_VEC(h16x8)*)(w0t + ((ib * KS + ks) * 64 + lane) * 8);
+      };
+      auto dwf_ = [&](int ks) __attribute__((always_inline)) {   // dW_first[32w + n][i] += sum_s dA1[s][n] x[s][i]
 #pragma unroll
         for (int ib = 0; ib < IB; ++ib) mfma_acc(dwf[ib], as_frag(da1[ks >> 1].q[ks & 1]), bx[ks % 3][ib]);
       };
-      auto din = [&](int ks) __attribute__((always_inline)) {
-        if (ks + 1 < KS) b[(ks + 1) & 1] = act_frag(t3, wave, ks + 1, lane);
+      auto req_bx = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) bx[ks % 3][ib] = tr_frag_chained(PlainV<const lds_h16*>{tX, PX}, 32 * ib, ks, lane);
+      };
+#pragma unroll
+      for (int ks = 0; ks < DEPTH; ++ks) req(ks);
+      req_w(0);
+      if (more) {
+        if (KS0 > 1) {
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) la[1][rb] = *(const LDS_VEC(h16x8)*)(tXn + (32 * rb + c) * PX + 16 + 8 * hf);
+        }
         SCHED_FENCE;
 #pragma unroll
-        for (int ib = 0; ib < IB; ++ib) o[ib] = mfma16(W0T[ib][ks], b[ks & 1], ks == 0 ? zero16 : o[ib]);
-      };
-      PT_STAMP(25)
-      dwf_(0); dwf_(1);
-      din(0); din(1);
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = mfma16(l0a[rb], B0[0], zero16);
+      }
+      req_bx(2);
+      SCHED_FENCE;
+      dwf_(0);
+      if (more) {
 #pragma unroll
-      for (int ks = 2; ks < KS - 2; ++ks) { dwf_(ks); din(ks); }
-      din(KS - 2); din(KS - 1);
-      dwf_(KS - 2); dwf_(KS - 1);
-      PT_STAMP(26)
-      // lane (sample c, half) holds features 32 ib + 8 q + 4 half + 0..3 of its row: through the wave's [32][IN] corner of t2, so the
-      // rows leave as contiguous 16-byte pieces (one row per lane and store touched 64 lines per instruction: 800 ticks per tile)
+        for (int ks = 1; ks < KS0; ++ks) {
+          if (ks + 1 < KS0) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) la[(ks + 1) & 1][rb] = *(const LDS_VEC(h16x8)*)(tXn + (32 * rb + c) * PX + 16 * (ks + 1) + 8 * hf);
+          }
+          SCHED_FENCE;
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) acc[rb] = mfma16(la[ks & 1][rb], B0[ks], acc[rb]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + DEPTH < KS) req(ks + DEPTH);
+        if (ks + 1 < KS) req_w(ks + 1);
+        if (ks + 3 < KS) req_bx(ks + 3);
+        SCHED_FENCE;
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) o[ib] = mfma16(wa[ks & 1][ib], b[ks % RING], ks == 0 ? zero16 : o[ib]);
+        if (ks + 1 < KS) dwf_(ks + 1);
+        if (more && ks >= 1 && ks <= 4) { Pk hp; relu_pack(acc[ks - 1], hp); write_slice(t1, wave, ks - 1, hp, lane); }
+      }
+      // lane (sample c, half) holds features 32 ib + 8 q + 4 half + 0..3 of its row: through the wave's [32][IN] corner of t2 (free
+      // since B_c), so the rows leave as contiguous 16-byte pieces (one row per lane and store touched 64 lines per instruction:
+      // 800 ticks per tile); the pieces are read back here and stored early in the next tile's phase B
       lds_h16* const stage = t2 + wave * (32 * IN);
 #pragma unroll
       for (int ib = 0; ib < IB; ++ib)
@@ -369,32 +405,24 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
         for (int q = 0; q < 4; ++q) {
           const int f = 32 * ib + 8 * q + 4 * hf;
           if (f < IN) {
-            h16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (h16)o[ib][4 * q + r];
-            nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
-            *(LDS_VEC(h16x4)*)(stage + c * IN + f) = v;
+            const u32x2 v = {cvt_pk(o[ib][4 * q], o[ib][4 * q + 1]), cvt_pk(o[ib][4 * q + 2], o[ib][4 * q + 3])};
+            nanz = nan_fold(__builtin_bit_cast(h16x2, v.x), nan_fold(__builtin_bit_cast(h16x2, v.y), nanz));
+            *(LDS_VEC(u32x2)*)(stage + c * IN + f) = v;
           }
         }
-    }
-    PT_STAMP(27)
-#ifndef ALN_ABL_NOL0
-    if (more) layer0(tXn);
-#endif
-    PT_STAMP(28)
-#ifndef ALN_ABL_NOSTORE
-    if (d_in) {
-      constexpr int PIECES = 32 * IN / 8;   // 16-byte pieces of the wave's 32 rows (contiguous in d_in)
-      const lds_h16* const stage = t2 + wave * (32 * IN);
-      const int row0 = r0 + 32 * wave;
+      SCHED_FENCE;
 #pragma unroll
-      for (int i = 0; i < (PIECES + 63) / 64; ++i) {
-        const int pc = lane + 64 * i;
-        if (pc < PIECES && row0 + pc / (IN / 8) < rows) *(u32x4*)(d_in + (size_t)row0 * IN + 8 * pc) = *(const LDS_VEC(u32x4)*)(stage + 8 * pc);
-      }
+      for (int i = 0; i < NPC; ++i) if (lane + 64 * i < PIECES) dst[i] = *(const LDS_VEC(u32x4)*)(stage + 8 * (lane + 64 * i));
+      dprev_row0 = r0 + 32 * wave;
     }
-#endif
     PT_STAMP(5) __syncthreads(); PT_STAMP(6)   // end of tile: t1 holds the next tile's h1; t2 / t3 / this tile's x buffer are free again
+  }
+  if (dprev_row0 >= 0 && d_in) {   // the last tile's d_in rows
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int pc = lane + 64 * i;
+      if (pc < PIECES && dprev_row0 + pc / (IN / 8) < rows) *(u32x4*)(d_in + (size_t)dprev_row0 * IN + 8 * pc) = dst[i];
+    }
   }
   PT_STAMP(0)
   PT_FLUSH
@@ -421,7 +449,8 @@ template <int IN>
 static int launch(const AlnMlpDesc* m, const h16* x, const h16* d_out, int rows, const int* rows_dev, void* d_in, float* ws, int g,
            int* found_inf, hipStream_t s) {
   constexpr int PX = px_pitch(IN);
-  constexpr size_t lds = (2 * (size_t)TR * (PX + PO) + 64 + 3 * (size_t)HID * PH) * 2;   // + 64 halves: the transposed reads of the last row run past it
+  constexpr int IB = (IN + 31) / 32;
+  constexpr size_t lds = (2 * (size_t)TR * PX + (size_t)TR * PO + 64 + 3 * (size_t)HID * PH + (size_t)IB * KS * 512) * 2;   // + 64 halves: the transposed reads of the last row run past it
   static_assert(lds <= 160 * 1024, "LDS");
   hipFuncSetAttribute((const void*)k_mlp_bwd128<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((k_mlp_bwd128<IN>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,
@@ -437,14 +466,14 @@ extern "C" int aln_debug_read_phases128(long long* host_out, int reset) {
 #endif
 
 // backward of a 128-wide two-hidden-layer head with a 16-wide output from plain x / dL/dout rows; `ws` = the block slabs
-// (NULL: no weight gradients), g = aln_mlp_bwd_blocks.  Returns -3 when the shape has no instantiation.
+// (NULL: no weight gradients), g = aln_mlp_bwd_blocks.  Returns -3 when the shape has no instantiation (a 64-wide input --
+// the 'freq' encoding -- does not fit the LDS budget with a double-buffered x tile: it stays on k_mlp_bwd_recomp8).
 int aln_launch_bwd128(const AlnMlpDesc* m, const void* x, const void* d_out, int rows, const int* rows_dev, void* d_in, float* ws,
                       int g, int* found_inf, hipStream_t s) {
   if (m->hidden != 128 || m->n_hidden != 2 || m->out_pad != 16) return -3;
   switch (m->in_pad) {
     case 32: return launch<32>(m, (const h16*)x, (const h16*)d_out, rows, rows_dev, d_in, ws, g, found_inf, s);
     case 48: return launch<48>(m, (const h16*)x, (const h16*)d_out, rows, rows_dev, d_in, ws, g, found_inf, s);
-    case 64: return launch<64>(m, (const h16*)x, (const h16*)d_out, rows, rows_dev, d_in, ws, g, found_inf, s);
     default: return -3;
   }
 }

@@ -128,12 +128,7 @@ if a.phases:
     buf = (C.c_longlong * 32)()
     lib.aln_debug_read_phases128(buf, 0)
     tiles = (rows // 128 + 255) // 256 * n
-    names = ['loop edge', 'B: last, L1, mask, write t2, dW_last', 'wait B_b', 'C: mid + dW_mid + mask + write t3 + stash', 'wait B_c',
-             'D: tail (d_in row stores)', 'wait end'] + ['sub %d' % i for i in range(7, 32)]
-    names[10:17] = ['C: first A reads', 'C: dw0 dw1', 'C: chain0 chain1', 'C: ks 2..5', 'C: chain6 chain7', 'C: dw6, mask, dw7, write', 'C: stash + prefetch']
-    names[17:19] = ['C: vmcnt(0) before stash', 'C: stash']
-    names[20:23] = ['B: ao/a0 reads, last, cvt', 'B: L1 loop', 'B: relu, dW_last, mask, write']
-    names[25:29] = ['D: first reads', 'D: d_in + dW_first mfma', 'D: cvt + stage', 'D: next L0']
+    names = ['D: whole phase + loop edge', 'B: whole phase', 'wait B_b', 'C: whole phase', 'wait B_c', 'D', 'wait end'] + ['sub %d' % i for i in range(7, 32)]
     tot = sum(buf[i] for i in range(32)) / tiles
     print(f'-- block 0 wave 0: {tot:.0f} ticks per tile')
     for i, nm in enumerate(names):
