@@ -17,12 +17,16 @@ import os as _os
 _PACKET_VAR = 'DEBUG_CLR_GRAPH_PACKET_CAPTURE'
 _preset = _os.environ.get(_PACKET_VAR)
 _hip_was_up = False
+# a profiler's preloaded tool library (rocprofv3 --pmc ...) brings the HIP runtime up before this process runs a line of Python:
+# torch.cuda.is_initialized() cannot see that, so an unset variable under a profiler counts as "too late"
+_profiler_preloaded = any('rocprof' in _os.environ.get(v, '').lower() for v in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB'))
 if _preset is None:
     try:
         import torch as _torch
         _hip_was_up = bool(_torch.cuda.is_initialized())
     except Exception:   # pragma: no cover
         _hip_was_up = False
+    _hip_was_up = _hip_was_up or _profiler_preloaded
     _os.environ[_PACKET_VAR] = '0'
 
 

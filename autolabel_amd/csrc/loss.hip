@@ -102,10 +102,12 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ticket = __hip_atomic_fetch_add(a.counts + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_s = ticket == (int)gridDim.x - 1;
-    if (last_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  if (last_s) {   // the whole block folds the rows: thread t takes row t, then a fixed tree (lanes, then waves): same sum every run
+  if (last_s) {   // the whole block folds the rows
+    // every reading thread takes the agent-scope acquire itself (a workgroup barrier does not extend one thread's acquire to the
+    // others under the HIP memory model, even though one buffer_inv happens to cover the CU's L1 on gfx950); last block only
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");: thread t takes row t, then a fixed tree (lanes, then waves): same sum every run
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (threadIdx.x < gridDim.x) v = *(const float4*)(a.terms + 8 + 4 * threadIdx.x);
     v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);

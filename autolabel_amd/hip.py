@@ -11,6 +11,7 @@ import torch
 from .build import LIB
 
 ALN_MAX_LEVELS = 16
+ABI_VERSION = 4   # include/autolabel_hip.h: ALN_ABI_VERSION
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
 
@@ -120,6 +121,14 @@ def lib():
             raise RuntimeError(f'{LIB} not found: build it with `python -m autolabel_amd.build` '
                                '(hipcc --offload-arch=gfx950). autolabel_amd has no CPU fallback.')
         L = C.CDLL(LIB)
+        L.aln_abi_version.restype = C.c_int
+        if L.aln_abi_version() != ABI_VERSION:   # a signature-only change would otherwise pass garbage arguments silently
+            raise RuntimeError(f'{LIB} implements ABI {L.aln_abi_version()}, these bindings were written for ABI {ABI_VERSION}: '
+                               'rebuild it with `python -m autolabel_amd.build`')
+        from . import build as _build
+        if LIB == _build.LIB and _build.needs_build():
+            import warnings
+            warnings.warn(f'{LIB} is older than its sources: rebuild it with `python -m autolabel_amd.build`')
         L.aln_last_error.restype = C.c_char_p
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)

@@ -15,6 +15,7 @@ import math
 import os
 import time
 
+import numpy as np
 import torch
 from torch import optim
 from torch.nn import functional as F
@@ -72,7 +73,7 @@ class Trainer:
                  local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
                  workspace='workspace', best_mode='min', use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint='latest', use_tensorboardX=False, scheduler_update_every_step=False, fused=None,
-                 process_group=None, use_graph=True):
+                 process_group=None, use_graph=True, device_data='auto'):
         self.name, self.opt, self.mute, self.metrics = name, opt, mute, metrics
         self.local_rank, self.world_size, self.workspace = local_rank, world_size, workspace
         self.ema_decay, self.fp16, self.best_mode = ema_decay, fp16, best_mode
@@ -84,6 +85,11 @@ class Trainer:
         self.time_stamp = time.strftime('%Y-%m-%d_%H-%M-%S')
         self.process_group = process_group
         self.use_graph = bool(use_graph)   # device-resident loaders: replay the whole step from a hipGraph (engine.GraphedStep)
+        # 'auto': a reference-style host loader (scripts/train.py:65-68: DataLoader over the dataset, one worker) is replaced by
+        # device-resident frames + HIP batch assembly whenever the frames fit in HBM -- the reference's CLI has no switch for it, so the
+        # drop-in route must not depend on one.  False keeps the host loader; True insists (raises when the frames do not fit).
+        self.device_data = device_data
+        self._resident = None
         model.to(self.device)
         self.model = model
         self.criterion = criterion if criterion is not None else torch.nn.MSELoss(reduction='none')
@@ -148,6 +154,46 @@ class Trainer:
             self._engine_state = None
         self.engine.lr = self.optimizer.param_groups[0]['lr']  # follows the torch scheduler (a device word: captured steps see it)
         return self.engine
+
+    def resident_loader(self, dataloader):
+        """The loader `train_iterations` actually draws from: `dataloader` itself, or -- for a host loader over a BaseDataset whose
+        frames fit in HBM -- a DeviceLoader over the same frames (same batch size, same epoch length; rank-specific seed and frame
+        shard under data parallelism).  Built once per dataset object; `dataset_updated` / `SceneDataset.update_sampler` callers get
+        the labels re-uploaded through `refresh_resident_labels`."""
+        from .dataset import BaseDataset, DeviceLoader, DynamicDataset
+        from . import parallel
+        if isinstance(dataloader, DeviceLoader) or not self.fused or self.device_data is False:
+            return dataloader
+        ds = getattr(dataloader, '_data', None)
+        if self._resident is not None and self._resident[0] is ds:
+            return self._resident[1]
+        ok = isinstance(ds, BaseDataset) and not isinstance(ds, DynamicDataset) and isinstance(getattr(ds, 'images', None), np.ndarray)
+        if ok:
+            need = ds.images.nbytes + ds.depths.nbytes + ds.semantics.nbytes + (ds.features.nbytes if ds.features is not None else 0)
+            free, _ = torch.cuda.mem_get_info(self.device)
+            ok = need <= 0.5 * free
+        if not ok:
+            if self.device_data is True:
+                raise RuntimeError('device_data=True: the dataset cannot be made device-resident (lazy / online frames, or larger than half of the free HBM)')
+            return dataloader
+        try:
+            length = len(dataloader)
+        except TypeError:
+            length = 1000
+        loader = DeviceLoader(ds.device_frames(self.device), ds.batch_size, length, seed=parallel.rank_seed(0, self.local_rank),
+                              frame_range=parallel.frame_shard(ds.n_examples, self.local_rank, self.world_size))
+        loader._data = ds
+        self._resident = (ds, loader)
+        self.log(f'[INFO] {ds.n_examples} frames resident in HBM ({need / 2 ** 20:.0f} MB): batches are assembled on the device')
+        return loader
+
+    def refresh_resident_labels(self):
+        """Re-upload the semantic maps and the class index after the labels changed on the host (semantic_map_updated)."""
+        if self._resident is not None:
+            ds, loader = self._resident
+            fr = loader.frames
+            fr.semantics.copy_(torch.as_tensor(ds.semantics).reshape(fr.semantics.shape))
+            fr.set_class_index(ds.semantics)
 
     def _to_device_batch(self, data):
         as_t = lambda v, dt: torch.as_tensor(v).to(self.device, dtype=dt, non_blocking=True).contiguous()
@@ -237,6 +283,7 @@ class SimpleTrainer(Trainer):
         if self.model.cuda_ray and getattr(dataloader, '_data', None) is not None:   # autolabel/trainer.py:34-36
             self.model.mark_untrained_grid(dataloader._data.poses, dataloader._data.intrinsics)
         from .dataset import DeviceLoader
+        dataloader = self.resident_loader(dataloader)
         if self.fused and isinstance(dataloader, DeviceLoader) and self.world_size == 1 and self.use_graph:
             loss = self._graphed_iterations(dataloader, iterations)
             if loss is not None:
@@ -416,3 +463,4 @@ class InteractiveTrainer(SimpleTrainer):
 
     def dataset_updated(self, loader):
         self.loader = loader
+        self.refresh_resident_labels()

@@ -55,6 +55,7 @@ def parse():
     p.add_argument('--march-samples', type=int, default=64)
     p.add_argument('--march-thresh', type=float, default=10.0)
     p.add_argument('--no-lseg', action='store_true', help='skip the LSeg-width (512-d feature head) leg')
+    p.add_argument('--no-dropin', action='store_true', help="skip the leg that times the reference's own route (scene directory -> SimpleTrainer)")
     p.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 PMC passes behind roofline.traffic')
     p.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)   # the run rocprofv3 wraps: a few eager steps, no JSON
     return p.parse_args()
@@ -393,6 +394,72 @@ def lseg_leg(wl, args, B):
                     'DINO-like targets supervise the first 64 of the 512 feature channels'}
 
 
+def dropin_leg(wl, args, B):
+    """The reference's own route, timed: the training frames written as a scene DIRECTORY (README.md:107-135 layout), read back by
+    `SceneDataset` at factor 2 with DINO-like feature maps, wrapped in `DataLoader(num_workers=1)` and trained by
+    `SimpleTrainer.train_iterations` with the optimizer / schedule / EMA objects of scripts/train.py:50-93 -- what
+    `python scripts/train.py <scene> --features dino` executes.  SimpleTrainer moves the frames into HBM when they fit (they do) and
+    replays the step from the hipGraph; `host_loader` times the same trainer with device_data=False (the reference's data path:
+    numpy batch assembly in a worker process + H2D copy per step)."""
+    import math
+    import shutil
+    import tempfile
+    from argparse import Namespace
+    import torch
+    from torch import optim
+    from autolabel_amd import model_utils, utils
+    from autolabel_amd.dataset import LenDataset, SceneDataset
+    from autolabel_amd.trainer import SimpleTrainer
+    tmp = tempfile.mkdtemp(prefix='aln_scene_')
+    try:
+        t0 = time.time()
+        sc, ids = wl.scene, wl.train_ids
+        cpu = lambda v: v.cpu() if torch.is_tensor(v) else v
+        utils.write_scene(dict(sc, images=cpu(sc['images'][ids]), depths=cpu(sc['depths'][ids]), semantics=cpu(sc['semantics'][ids]),
+                               features=cpu(sc['features'][ids]), T_CW=sc['T_CW'][ids]), tmp)
+        t_write = time.time() - t0
+        flags = model_utils.model_flag_parser().parse_args(['--features', 'dino', '--feature-dim', str(args.feature_dim)])
+        t0 = time.time()
+        dataset = SceneDataset('train', tmp, factor=2.0, batch_size=B, features='dino')
+        t_load = time.time() - t0
+        opt = Namespace(rand_pose=-1, color_space='srgb', feature_loss=True, rgb_weight=flags.rgb_weight, depth_weight=flags.depth_weight,
+                        semantic_weight=flags.semantic_weight, feature_weight=flags.feature_weight)
+        optimizer = lambda model: torch.optim.Adam([{'name': 'encoding', 'params': list(model.encoder.parameters())},
+                                                    {'name': 'net', 'params': model.network_parameters(), 'weight_decay': 1e-6}],
+                                                   lr=flags.lr, betas=(0.9, 0.99), eps=1e-15)
+        scheduler = lambda o: optim.lr_scheduler.StepLR(o, gamma=0.5, step_size=max(10000 // math.log(1e-4 / flags.lr, 0.5) // 1000, 1))
+
+        def run(device_data, warm, steps):
+            torch.manual_seed(SEEDS[0][0])
+            model = model_utils.create_model(dataset.min_bounds, dataset.max_bounds, dataset.n_classes, flags)
+            tr = SimpleTrainer('ngp', opt, model, device=wl.device, workspace=None, optimizer=optimizer, criterion=torch.nn.MSELoss(reduction='none'),
+                               fp16=True, ema_decay=0.95, lr_scheduler=scheduler, scheduler_update_every_step=False, metrics=[],
+                               use_checkpoint='scratch', mute=True, device_data=device_data)
+            loader = torch.utils.data.DataLoader(LenDataset(dataset, 1000), batch_size=None, num_workers=1)
+            loader._data = dataset
+            tr.train_iterations(loader, warm)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            tr.train_iterations(loader, steps)
+            torch.cuda.synchronize()
+            dt = time.time() - t1
+            return B * steps / dt, 1000 * dt / steps, float(tr.engine.terms[4]), isinstance(tr.resident_loader(loader), type(loader))
+        v, ms, loss, stayed_host = run('auto', max(args.warmup, 20), args.steps)
+        res = {'value': v, 'unit': 'rays/s', 'ms_per_step': ms, 'steps': args.steps, 'frames_resident_in_hbm': not stayed_host,
+               'loss_total_last_step': loss, 'scene_write_s': t_write, 'scene_load_s': t_load,
+               'route': 'utils.write_scene -> SceneDataset(factor 2, features dino) -> DataLoader(num_workers=1) -> SimpleTrainer.train_iterations '
+                        '(ema update + scheduler step per call included)'}
+        try:
+            hv, hms, _, _ = run(False, 10, min(args.steps, 40))
+            res['host_loader'] = {'value': hv, 'unit': 'rays/s', 'ms_per_step': hms, 'steps': min(args.steps, 40),
+                                  'note': "device_data=False: the reference's data path (numpy _next_train in a DataLoader worker, H2D per step)"}
+        except Exception as e:   # a worker process that cannot be forked on this box must not cost the line
+            res['host_loader'] = {'error': repr(e)[:200]}
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel pair from the PMC counters: rocprofv3 --pmc around a child run of this script
     (`--pmc-child`: a few launch-by-launch steps of the same step on a smaller frame set), FETCH_SIZE and WRITE_SIZE in separate
@@ -405,7 +472,7 @@ def pmc_traffic(args):
     res = {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         out = tempfile.mkdtemp(prefix='aln_pmc_', dir='/tmp')
-        env = dict(os.environ, TMPDIR='/tmp')
+        env = dict(os.environ, TMPDIR='/tmp', DEBUG_CLR_GRAPH_PACKET_CAPTURE='0')   # (the child steps launch by launch; exported anyway: the profiler's tool library initialises HIP before Python runs)
         cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__), '--pmc-child',
                '--batch', str(args.batch), '--frames', '40', '--feature-dim', str(args.feature_dim)]
         try:
@@ -624,6 +691,11 @@ def main():
             res['render_dense_Mrays_per_s'] = render_dense
             if not args.no_lseg and args.feature_dim != 512:
                 res['lseg'] = lseg_leg(wl, args, B)
+            if not args.no_dropin:
+                try:
+                    res['dropin'] = dropin_leg(wl, args, B)
+                except Exception as e:
+                    res['dropin'] = {'error': repr(e)[:300]}
             if roof:
                 if pmc:
                     roof['traffic'] = pmc.pop('traffic')

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0   # graph mode under rocprofv3: the tool library brings HIP up before Python can set it
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; cd $R
 (time python -m pytest tests -m gpu -q --durations=6) > $O/r3_pytest14.log 2>&1; tail -14 $O/r3_pytest14.log | cut -c1-200
 python bench.py > $O/r3_bench_k.json 2> $O/r3_bench_k.err; tail -3 $O/r3_bench_k.err

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0   # graph mode under rocprofv3: the tool library brings HIP up before Python can set it
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; cd $R
 (time python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_quality.py) > $O/r3_pytest16.log 2>&1; tail -12 $O/r3_pytest16.log | cut -c1-300
 python bench.py --no-cpu-baseline --no-pmc --no-lseg --quality-steps 0 --render-frames 0 > $O/r3_bench_l.json 2> $O/r3_bench_l.err; tail -3 $O/r3_bench_l.err

@@ -1,5 +1,7 @@
 """Fit a scene (CLI of the reference's scripts/train.py).  `--synthetic room|cube` trains on a generated scene instead
-of a directory; `--device-data` keeps the frames in HBM and assembles batches with the HIP ray-generation kernels.
+of a directory.  The frames are kept in HBM and the batches assembled by the HIP ray-generation kernels whenever they fit (they
+do for every scene of the reference's size: 200 frames at 320x240 are 230 MB); `--host-data` keeps the reference's host loader
+(DataLoader + worker process + H2D copy, scripts/train.py:65-68).
 
 Data parallel: start it under `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1
 scripts/train.py ...` -- one process per GPU, frames sharded over the ranks, model replicated (rank 0's initialisation is
@@ -18,7 +20,7 @@ from torch import optim
 
 from autolabel_amd import model_utils
 from autolabel_amd import parallel
-from autolabel_amd.dataset import ArrayDataset, DeviceLoader, LenDataset, SceneDataset
+from autolabel_amd.dataset import ArrayDataset, LenDataset, SceneDataset
 from autolabel_amd.trainer import SimpleTrainer
 
 
@@ -33,7 +35,8 @@ def read_args():
     parser.add_argument('--eval', action='store_true')
     parser.add_argument('--workspace', type=str, default=None, help='Save results here instead of the scene directory.')
     parser.add_argument('--synthetic', choices=['room', 'cube'], default=None)
-    parser.add_argument('--device-data', action='store_true', help='device-resident frames + HIP batch assembly')
+    parser.add_argument('--device-data', action='store_true', help='(default whenever the frames fit in HBM; kept for older command lines)')
+    parser.add_argument('--host-data', action='store_true', help="the reference's host DataLoader instead of device-resident frames")
     parser.add_argument('--global-batch', type=int, default=0, help='data parallel: fixed global batch (overrides --batch-size)')
     parser.add_argument('--cuda-ray', action='store_true', help='occupancy-grid marching (the reference hard-codes cuda_ray=False)')
     parser.add_argument('--march-samples', type=int, default=96, help='sample rows per ray with --cuda-ray')
@@ -66,11 +69,8 @@ def main():
         {'name': 'encoding', 'params': list(model.encoder.parameters())},
         {'name': 'net', 'params': model.network_parameters(), 'weight_decay': 1e-6},
     ], lr=flags.lr, betas=(0.9, 0.99), eps=1e-15)
-    if flags.device_data:
-        train_dataloader = DeviceLoader(dataset.device_frames(device), flags.batch_size, 1000, seed=parallel.rank_seed(0, rank),
-                                        frame_range=parallel.frame_shard(dataset.n_examples, rank, world))
-    else:
-        train_dataloader = torch.utils.data.DataLoader(LenDataset(dataset, 1000), batch_size=None, num_workers=flags.workers)
+    # the reference's loader; SimpleTrainer replaces it by device-resident frames when they fit (device_data='auto')
+    train_dataloader = torch.utils.data.DataLoader(LenDataset(dataset, 1000), batch_size=None, num_workers=flags.workers)
     train_dataloader._data = dataset
     criterion = torch.nn.MSELoss(reduction='none')
     gamma = 0.5
@@ -84,7 +84,8 @@ def main():
     pg = torch.distributed.group.WORLD if world > 1 else None
     trainer = SimpleTrainer('ngp', opt, model, device=device, workspace=model_dir, optimizer=optimizer, criterion=criterion,
                             fp16=True, ema_decay=0.95, lr_scheduler=scheduler, scheduler_update_every_step=False, metrics=[],
-                            use_checkpoint='latest', local_rank=rank, world_size=world, process_group=pg)
+                            use_checkpoint='latest', local_rank=rank, world_size=world, process_group=pg,
+                            device_data=False if flags.host_data else ('auto' if not flags.device_data else True))
     if world > 1:   # replicas start identical (a resumed checkpoint is read by every rank; the broadcast also covers a fresh init)
         parallel.broadcast_parameters(model._ensure_device().P.flat, pg)
         model._shadow_version = None

@@ -461,6 +461,38 @@ def test_other_encodings_train_one_step_like_the_oracle(encoding):
     assert eng.state_i[0].item() == 1 and not torch.equal(before, pipe.P.flat) and torch.isfinite(pipe.P.flat).all()
 
 
+def test_host_loader_over_a_dataset_is_replaced_by_device_resident_frames():
+    """The reference's route (scripts/train.py:65-93: DataLoader over the dataset -> SimpleTrainer.train): the trainer moves the
+    frames into HBM by itself and replays the step from the hipGraph; device_data=False keeps the host loader; label edits made
+    on the host dataset reach the device copy through refresh_resident_labels (InteractiveTrainer.dataset_updated)."""
+    from autolabel_amd.dataset import DeviceLoader, LenDataset
+    ds, _ = _host_batches(1, B=512)
+    bound = float(((ds.max_bounds - ds.min_bounds) - (ds.min_bounds + ds.max_bounds) * 0.5).max())
+    losses = {}
+    for mode in ('auto', False):
+        torch.manual_seed(0)
+        model = make_model(D=64, C_=7, bound=bound, grid_scale=1.0)
+        tr = _trainer(model, True)
+        tr.device_data = mode
+        loader = torch.utils.data.DataLoader(LenDataset(ds, 1000), batch_size=None, num_workers=0)
+        loader._data = ds
+        tr.train_iterations(loader, 6)
+        used = tr.resident_loader(loader)
+        assert isinstance(used, DeviceLoader) == (mode == 'auto')
+        assert tr.global_step == 6 and int(tr.engine.state_i[0]) == 6
+        losses[mode] = float(tr.engine.terms[4])
+        assert np.isfinite(losses[mode])
+        if mode == 'auto':
+            assert used.frames.n_frames == ds.n_examples and used.batch['rays_o'].shape == (512, 3) and used._data is ds
+            ds.semantics[1, :100] = 3     # a label edit on the host (SceneDataset.semantic_map_updated)
+            ds.index_sampler.update(ds.semantics)
+            tr.refresh_resident_labels()         # what InteractiveTrainer.dataset_updated calls
+            assert int(used.frames.semantics.reshape(ds.n_examples, -1)[1, :100].min()) == 3
+            ds.semantics[1, :100] = 0
+            ds.index_sampler.update(ds.semantics)
+    assert abs(losses['auto'] - losses[False]) < 0.5 * max(losses.values())    # same scene, same model, different random batches
+
+
 def test_interactive_trainer_and_eval_steps():
     """InteractiveTrainer.init/take_step (GUI / ROS loop) and SimpleTrainer.test_step / eval_step / evaluate shapes."""
     from autolabel_amd.trainer import InteractiveTrainer

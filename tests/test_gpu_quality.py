@@ -127,6 +127,8 @@ def run_gate(steps, batch, s1, s2, n_frames, w, h, levels, log2_T, hip_seeds, or
     rec['delta_psnr_db'] = rec['mean_hip']['psnr_db'] - rec['mean_oracle']['psnr_db']
     rec['delta_miou_pt'] = 100 * (rec['mean_hip']['miou'] - rec['mean_oracle']['miou'])
     rec['delta_depth_l1_m'] = rec['mean_hip']['depth_l1_m'] - rec['mean_oracle']['depth_l1_m']
+    # SURVEY 8(d) read two-sided (|delta| within the tolerance): recorded, not asserted -- see the test below
+    rec['two_sided_ok'] = bool(abs(rec['delta_psnr_db']) <= TOL_PSNR_DB and abs(rec['delta_miou_pt']) <= TOL_MIOU_PT)
     return rec
 
 
@@ -136,6 +138,7 @@ def test_hip_training_matches_the_quality_of_the_oracle_on_means_over_seeds():
     with open(os.path.join(ROOT, 'gpurun_out', 'quality_gate.json'), 'w') as f:
         json.dump(rec, f, indent=1)
     print(json.dumps({k: v for k, v in rec.items() if not k.startswith('loss_')}))
+    print('two_sided_ok:', rec['two_sided_ok'], '(|delta PSNR| <= %.1f dB and |delta mIoU| <= %.1f pt)' % (TOL_PSNR_DB, TOL_MIOU_PT))
     lh, lo = rec['loss_hip_every_100'], rec['loss_oracle_every_100']
     assert lo[-1] < 0.5 * lo[0] and lh[-1] < 0.5 * lh[0], 'both sides must have trained'
     assert rec['mean_oracle']['psnr_db'] >= MIN_ORACLE_PSNR_DB, 'the gate only discriminates on a trained field'
