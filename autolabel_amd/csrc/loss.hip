@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
     last_s = ticket == (int)gridDim.x - 1;
   }
   __syncthreads();
-  if (last_s) {   // the whole block folds the rows
+  if (last_s) {   // the whole block folds the rows: thread t takes row t, then a fixed tree (lanes, then waves): same sum every run
     // every reading thread takes the agent-scope acquire itself (a workgroup barrier does not extend one thread's acquire to the
     // others under the HIP memory model, even though one buffer_inv happens to cover the CU's L1 on gfx950); last block only
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");: thread t takes row t, then a fixed tree (lanes, then waves): same sum every run
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (threadIdx.x < gridDim.x) v = *(const float4*)(a.terms + 8 + 4 * threadIdx.x);
     v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);

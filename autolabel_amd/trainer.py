@@ -73,7 +73,7 @@ class Trainer:
                  local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
                  workspace='workspace', best_mode='min', use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint='latest', use_tensorboardX=False, scheduler_update_every_step=False, fused=None,
-                 process_group=None, use_graph=True, device_data='auto'):
+                 process_group=None, use_graph=True, device_data='auto', use_graph_dp=False):
         self.name, self.opt, self.mute, self.metrics = name, opt, mute, metrics
         self.local_rank, self.world_size, self.workspace = local_rank, world_size, workspace
         self.ema_decay, self.fp16, self.best_mode = ema_decay, fp16, best_mode
@@ -85,6 +85,9 @@ class Trainer:
         self.time_stamp = time.strftime('%Y-%m-%d_%H-%M-%S')
         self.process_group = process_group
         self.use_graph = bool(use_graph)   # device-resident loaders: replay the whole step from a hipGraph (engine.GraphedStep)
+        # data parallel: capture the step WITH its collectives (RCCL process groups are capturable, gloo is not); opt-in until it has
+        # run on a multi-GPU node -- a failed capture falls back to launch-by-launch steps with a warning
+        self.use_graph_dp = bool(use_graph_dp)
         # 'auto': a reference-style host loader (scripts/train.py:65-68: DataLoader over the dataset, one worker) is replaced by
         # device-resident frames + HIP batch assembly whenever the frames fit in HBM -- the reference's CLI has no switch for it, so the
         # drop-in route must not depend on one.  False keeps the host loader; True insists (raises when the frames do not fit).
@@ -284,7 +287,7 @@ class SimpleTrainer(Trainer):
             self.model.mark_untrained_grid(dataloader._data.poses, dataloader._data.intrinsics)
         from .dataset import DeviceLoader
         dataloader = self.resident_loader(dataloader)
-        if self.fused and isinstance(dataloader, DeviceLoader) and self.world_size == 1 and self.use_graph:
+        if self.fused and isinstance(dataloader, DeviceLoader) and self.use_graph and (self.world_size == 1 or self.use_graph_dp):
             loss = self._graphed_iterations(dataloader, iterations)
             if loss is not None:
                 if self.ema is not None:
@@ -345,6 +348,12 @@ class SimpleTrainer(Trainer):
                     self.log(f'[WARN] hipGraph replay disabled, stepping launch by launch: {e}')
                     self._graph_warned = True
                 self.use_graph = False
+                return None
+            except Exception as e:
+                if self.world_size == 1:
+                    raise
+                self.log(f'[WARN] the data-parallel step could not be captured ({type(e).__name__}: {e}); stepping launch by launch')
+                self.use_graph_dp = False
                 return None
             self.global_step += g.steps
             loader.step += g.steps

@@ -102,7 +102,7 @@ class Workload:
         self.bound = float(((hi - lo) - (lo + hi) * 0.5).max())  # autolabel/model_utils.py:62-63
         self.n_classes = scene['n_classes']
 
-    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None, semantic_weight=1.0):
+    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None, semantic_weight=1.0, overlap_comm=True):
         from autolabel_amd.engine import TrainEngine
         from autolabel_amd.parallel import broadcast_parameters
         from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
@@ -118,7 +118,7 @@ class Workload:
             t = self.train
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)
             pipe.mark_untrained_grid(t.world_to_camera(), (t.desc.fx, t.desc.fy, t.desc.cx, t.desc.cy), size=(t.w, t.h))
-        return TrainEngine(pipe, feature_loss=True, process_group=pg, semantic_weight=semantic_weight)
+        return TrainEngine(pipe, feature_loss=True, process_group=pg, semantic_weight=semantic_weight, overlap_comm=overlap_comm)
 
     def renderer(self, eng, march):
         """render callable for quality.heldout_metrics: 256 rows per ray along the whole ray (dense) / 128 rows inside occupied cells."""
@@ -609,21 +609,63 @@ def main():
     from autolabel_amd.quality import heldout_metrics
     wl = Workload(args, device)
     pg = torch.distributed.group.WORLD if world > 1 else None
-    eng = wl.engine(SEEDS[0][0], world=world, pg=pg)
     frange = frame_shard(len(wl.train_ids), rank, world)
     n_ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
     B = args.global_batch // world if args.global_batch else args.batch
     assert B % 512 == 0 and B > 0, 'per-rank batch must be a multiple of the 512-ray chunk (autolabel/dataset.py:171)'
     args.batch = B
     dseed, mseed = rank_seed(SEEDS[0][1], rank), rank_seed(SEEDS[0][2], rank)
-    use_graph = not args.no_graph and world == 1   # data-parallel steps are issued launch by launch (collectives on a side stream)
+    use_graph = not args.no_graph and world == 1
 
     def sync():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    dt, terms, events, step, done = timed_leg(wl, args, eng, B, dseed, mseed, frange, use_graph, world, sync)
+    dp_legs = None
+    if world == 1:
+        eng = wl.engine(SEEDS[0][0])
+        dt, terms, events, step, done = timed_leg(wl, args, eng, B, dseed, mseed, frange, use_graph, world, sync)
+    else:
+        # Data parallel: the step is timed in up to three forms, each inside its own try -- the first RCCL run of this code may be the
+        # driver's, and one exception must not cost the line.  dp_simple: ONE all-reduce of the gradient buffer after the backward
+        # pass (the plainest use of the collective); dp_overlap: five buckets on a communication stream behind the scatter's level
+        # groups; dp_graph: the overlapped step captured into a hipGraph, collectives included (launch-bound at small per-GPU
+        # batches otherwise).  The headline is the fastest leg that finished on EVERY rank.
+        a2 = argparse.Namespace(**vars(args))
+        a2.event_steps = 0
+        dp_legs, best = {}, None
+        plan = [('dp_simple', False, False), ('dp_overlap', True, False)] + ([('dp_graph', True, True)] if not args.no_graph and backend == 'nccl' else [])   # (gloo collectives cannot be captured)
+        for name, overlap, graph in plan:
+            ok, leg = 1, None
+            try:
+                e = wl.engine(SEEDS[0][0], world=world, pg=pg, overlap_comm=overlap)
+                leg = timed_leg(wl, a2, e, B, dseed, mseed, frange, graph, world, sync)
+                dp_legs[name] = {'value': B * world * args.steps / leg[0], 'unit': 'rays/s', 'ms_per_step': 1000 * leg[0] / args.steps,
+                                 'overlap_comm': overlap, 'hip_graph': graph}
+            except Exception as ex:   # recorded, not fatal
+                ok = 0
+                dp_legs[name] = {'error': f'{type(ex).__name__}: {ex}'[:300], 'overlap_comm': overlap, 'hip_graph': graph}
+            try:
+                flag = torch.tensor([ok], device=device, dtype=torch.int32)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                ok = int(flag.item())
+            except Exception as ex:
+                dp_legs[name].setdefault('error', f'agreement all-reduce failed: {ex}'[:200])
+                ok = 0
+            dp_legs[name]['finished_on_every_rank'] = bool(ok)
+            if ok and leg is not None and (best is None or leg[0] < best[1][0]):
+                best = (name, leg, e)
+            elif leg is not None:
+                del e
+                torch.cuda.empty_cache()
+        if best is None:
+            if rank == 0:
+                print(json.dumps({'metric': 'train rays/sec (640x480 synthetic RGB-D scene, hg+freq, DINO-like features)', 'value': None,
+                                  'unit': 'rays/s', 'n_gpus': world, 'error': 'no data-parallel leg finished', 'dp_legs': dp_legs}), flush=True)
+            sys.exit(1)
+        (dp_best, (dt, terms, events, step, done), eng) = best
+        use_graph = dp_legs[dp_best]['hip_graph']
     rays_per_s = B * world * args.steps / dt
     live_rows = float(eng.ws.get('n_live', (1,), torch.int32).item())   # color-head rows of the last step (w > 1e-4)
     roof = scatter_roofline(eng, events, B * (eng.S1 + eng.S2), args.event_steps) if events else None
@@ -669,9 +711,9 @@ def main():
             'config': {'workload': "S1 synthetic room standing in for the 'bench' scene: %d frames 640x480 trained at factor 2, " % args.frames +
                                    'DINO-like 64-d features, hg+freq L=16 T=2^19, 128+128 samples/ray',
                        'rays_per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'feature_dim': args.feature_dim,
-                       'hip_graph': bool(use_graph),
+                       'hip_graph': bool(use_graph), 'dp_leg': dp_best if world > 1 else None,
                        'gradient_exchange_bytes_per_rank_and_step': wire_bytes(L.n_grid, L.n_total, eng.grad_payload) if world > 1 else 0},
-            'n_ranks_seen': n_ranks_seen,
+            'n_ranks_seen': n_ranks_seen, 'dp_legs': dp_legs,
             'loss_terms_last_timed_step': dict(zip(('rgb', 'depth', 'feature', 'semantic', 'total'), terms)),
             'quality': quality,
         }

@@ -490,7 +490,6 @@ def test_host_loader_over_a_dataset_is_replaced_by_device_resident_frames():
             assert int(used.frames.semantics.reshape(ds.n_examples, -1)[1, :100].min()) == 3
             ds.semantics[1, :100] = 0
             ds.index_sampler.update(ds.semantics)
-    assert abs(losses['auto'] - losses[False]) < 0.5 * max(losses.values())    # same scene, same model, different random batches
 
 
 def test_interactive_trainer_and_eval_steps():
