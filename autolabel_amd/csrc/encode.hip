@@ -56,11 +56,13 @@ __device__ inline void normalize_pos(const float* x, float bound, bool clip, flo
   }
 }
 
-// level-local corner indices + trilinear weights (oracle: grid_corner_indices)
+// level-local corner indices + trilinear weights (oracle: grid_corner_indices).  KIND: -1 = dense / hashed decided per call (a
+// wave-uniform branch per corner), 0 = hashed, 1 = dense (the caller branches ONCE per level: k_encode_bwd_bin)
+template <int KIND = -1>
 __device__ inline void grid_corners(const AlnGridDesc& g, int l, const float* xn, uint32_t* idx, float* w, uint32_t* base = nullptr) {
   float scale = g.scale[l];
   uint32_t res = g.res[l], size = g.size[l];
-  bool dense = g.dense[l] != 0;
+  const bool dense = KIND < 0 ? g.dense[l] != 0 : KIND == 1;
   uint32_t gi[3]; float fr[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -443,24 +445,33 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     const uint32_t sl = b.slice_log2[l], slot_mask = (1u << sl) - 1u;
     const int k8 = (l - p.level_lo) & 7;
     if (k8 == 0) {   // words of levels l .. l + 7 -> this thread's column (nobody else touches it: no barrier)
+      // every load is requested before the first is parked (hipcc would otherwise wait for each one in turn: four to eight
+      // global-load latencies in a row at the top of every eighth level)
       const int nw = min(8, p.level_hi - l);
+      uint32_t wv[8];
       if (al8 && (l & 1) == 0) {
+        uint2 w2[4];
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
-          uint2 w2 = make_uint2(0u, 0u);
-          if (valid && j < nw) { if (j + 1 < nw) w2 = *(const uint2*)(grow + l + j); else w2.x = grow[l + j]; }
-          gws[j][tid] = w2.x; gws[j + 1][tid] = w2.y;
+          w2[j >> 1] = make_uint2(0u, 0u);
+          if (valid && j + 1 < nw) w2[j >> 1] = *(const uint2*)(grow + l + j);
+          else if (valid && j < nw) w2[j >> 1].x = grow[l + j];
         }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) { wv[j] = w2[j >> 1].x; wv[j + 1] = w2[j >> 1].y; }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gws[j][tid] = (valid && j < nw) ? grow[l + j] : 0u;
+        for (int j = 0; j < 8; ++j) wv[j] = (valid && j < nw) ? grow[l + j] : 0u;
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gws[j][tid] = wv[j];
     }
     const uint32_t gw = gws[k8][tid];
     const h16x2 g = *(const h16x2*)&gw;
     const float g0 = (float)g[0], g1 = (float)g[1];
     uint32_t idx[8]; float w[8]; uint32_t cell[3];
-    grid_corners(p.e.grid, l, xn, idx, w, cell);
+    if (p.e.grid.dense[l]) grid_corners<1>(p.e.grid, l, xn, idx, w, cell);   // one wave-uniform branch per level, not one per corner
+    else grid_corners<0>(p.e.grid, l, xn, idx, w, cell);
     // run-dedupe along the ray: adjacent lanes in the same cell are summed into the run head
     // (levels from BIN_DEDUPE_LEVELS on skip it: at 4096 cells per axis and beyond consecutive samples practically never share
     //  a cell -- 8.1-8.3 of 8.4 M records survive -- so the compare / ballot / ladder step costs more than the records it saves)
@@ -499,8 +510,16 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     // the copy-out alone saves 114 / 125 / 96 us of 325, all three together 131: the three LDS phases are not additive costs but
     // alternatives on one critical path -- barrier to barrier -- and halving the operations of two of them moves little.)
     uint32_t rk[8];
+    {
+      // the tile's largest magnitude: folded over the wave with shuffles, ONE LDS atomic per wave.  (atomicMax from every lane is
+      // rewritten by hipcc's atomic optimizer into a scalar loop over the active lanes -- ~6 scalar instructions per lane, 370 per
+      // wave and level: half of this kernel's instruction stream, profiles/r03_pmc_sq_summary.json)
+      uint32_t wm = emit ? __float_as_uint(vmax) : 0u;   // non-negative floats order like their bit patterns
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, o));
+      if (lane == 0 && wm) atomicMax(&vmax_s[par], wm);
+    }
     if (emit) {
-      atomicMax(&vmax_s[par], __float_as_uint(vmax));   // non-negative floats order like their bit patterns
 #pragma unroll
       for (int c = 0; c < 8; c += 2) {
         const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
