@@ -392,7 +392,10 @@ __device__ inline void chain_layer_m(f32x16 (&acc)[RPW][NB], FragFn frag, BFn bo
 // ---------------------------------------------------------------- forward
 // (three 256-thread blocks per CU wherever the chain fits 168 VGPRs -- the 128-wide heads with up to 48 inputs: the register
 //  allocator is told so, one register over costs a third of the resident waves)
-template <int HID, int NHID, int KS0>
+// PLAIN: the input rows are a plain [rows, in_pad] fp16 matrix (every training-step launch): one 16-byte load per chunk instead of
+// the row-source switch (210 branches and 1 170 scalar instructions in the 48-wide instantiation: three blocks per CU share one
+// scalar unit)
+template <int HID, int NHID, int KS0, bool PLAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HID == 128 && NHID == 2 && KS0 > 3) ? 2 : 3))) void k_mlp_fwd(const h16* __restrict__ wf_g, size_t wf_halves, int in_pad, int out_pad,
                                                 RowSrc xs, int rows, const int* __restrict__ rows_dev,
                                                 h16* __restrict__ h1, h16* __restrict__ h2, h16* __restrict__ out,
@@ -417,7 +420,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HID == 128
 #pragma unroll
     for (int ks = 0; ks < KS0; ++ks) {
       const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      xb[ks] = (r < rows) ? load_chunk8(xs, r, 16 * ks + 8 * hf) : z;
+      if constexpr (PLAIN) xb[ks] = (r < rows) ? *(const h16x8*)(xs.a + (size_t)r * xs.lda + 16 * ks + 8 * hf) : z;
+      else xb[ks] = (r < rows) ? load_chunk8(xs, r, 16 * ks + 8 * hf) : z;
     }
   };
   const int tstride = gridDim.x * 4;
@@ -1220,7 +1224,16 @@ static int bwd_recomp_blocks(const AlnMlpDesc* m, int rows) {
   return tiles < gmax ? tiles : gmax;
 }
 extern "C" int32_t aln_mlp_bwd_blocks(const AlnMlpDesc* m, int32_t rows) { return (m && rows > 0) ? bwd_recomp_blocks(m, rows) : 0; }
+static int dw_reduce_all_impl(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, const int32_t* slabs, void* stream);
 extern "C" int aln_mlp_dw_reduce_all(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, void* stream) {
+  return dw_reduce_all_impl(n_heads, descs, dW, rows, nullptr, stream);
+}
+// the same with the slab count of each head given (slabs[k] > 0: aln_sem_heads_bwd_slabs; 0: aln_mlp_bwd_blocks(descs[k], rows[k]))
+extern "C" int aln_mlp_dw_reduce_slabs(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, const int32_t* slabs,
+                                       void* stream) {
+  return dw_reduce_all_impl(n_heads, descs, dW, rows, slabs, stream);
+}
+static int dw_reduce_all_impl(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, const int32_t* slabs, void* stream) {
   ALN_REQUIRE(n_heads >= 0 && n_heads <= ALN_MAX_HEADS && (n_heads == 0 || (descs && dW && rows)), "dw_reduce_all: bad arguments");
   DwReduceAll a; a.n = 0; a.blk0[0] = 0;
   for (int k = 0; k < n_heads; ++k) {
@@ -1229,7 +1242,7 @@ extern "C" int aln_mlp_dw_reduce_all(int32_t n_heads, const AlnMlpDesc* const* d
     if (rows[k] <= 0) continue;
     const MlpLayers L = mlp_layers(m->in_pad, m->hidden, m->out_pad, m->n_hidden);
     const int n_w = (int)(L.w_off[L.n - 1] + (size_t)L.in_[L.n - 1] * L.out_[L.n - 1]);
-    const int parts = bwd_recomp_blocks(m, rows[k]);
+    const int parts = (slabs && slabs[k] > 0) ? slabs[k] : bwd_recomp_blocks(m, rows[k]);
     ALN_REQUIRE((size_t)m->dw_ws_bytes >= (size_t)parts * n_w * sizeof(float), "dw_reduce_all: dw_ws of head %d too small", k);
     a.ws[a.n] = (const float*)m->dw_ws; a.dW[a.n] = dW[k]; a.nparts[a.n] = parts; a.nw[a.n] = n_w;
     a.blk0[a.n + 1] = a.blk0[a.n] + (n_w + DWR_E - 1) / DWR_E;
@@ -1300,6 +1313,390 @@ static int launch_bwd_recomp(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int rows
   return launch_bwd_recomp_occ<IN, HID, OUT, NHID, false, 1>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);
 }
 
+// ---------------------------------------------------------------- both semantic heads, backward, ONE kernel
+// semantic_features (G -> 64 -> 64 -> 64) and semantic_out (cat[relu(f), geo_feat] -> 64 -> C) of models.py:248-256, forward recompute
+// included, from sigma_out, the compositing weights and the per-ray output gradients alone: the two-launch path moves 550 B per
+// sample row through HBM (f, d(semantic_out input) written and read back, sigma_out twice) and is half bound by that traffic
+// (DESIGN.md 4.6); here 36 B are read and 32 B written per row, and nothing but the matrices' gradients leaves the CU.
+// One wave per SIMD, two roles with their own tile loops (the register allocator never sees both states at once):
+//   * waves 0-1, the CHAIN: 32 sample rows each through the whole chain of both heads (62 MFMAs) with every weight fragment of both
+//     heads resident in registers (62 fragments, 248 registers: what a 64-wide pair allows and the 128-wide heads do not) -- the
+//     chain reads nothing from LDS but its own rows (two natural-order read-backs, the ReLU masks);
+//   * waves 2-3, the WEIGHT GRADIENTS: whole matrices per wave (W2, W1, W0 | V0, V1), so every transposed fragment read feeds two or
+//     three MFMAs; accumulators in the AGPR half for the whole kernel.
+// Activations and gradients of a 64-row tile are parked in LDS as row-major [sample][feature] tiles, in two sets: the chain fills
+// one while the weight-gradient waves read the other (one barrier per tile).  dL/d(semantic_out input)[:, :64] and dL/df never exist
+// outside a CU; d(geo_feat) of both heads leaves as one 16-wide row.
+// (First version, measured: four symmetric waves with the backward fragments streamed from L2 every tile -- 11 800 ticks per tile in
+//  the chain, all of it exposed load latency: 240 us, no better than the two launches.)
+__device__ inline void mfma_acc_a(f32x16& acc, h16x8 a, h16x8 b) {   // accumulator in the AGPR half (see mlp_bwd128.hip: mfma_acc)
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// NOB x NIB weight-gradient blocks of one matrix over the tile's 64 rows: dW[o][i] += sum_s A[s][o] B[s][i]
+template <int NOB, int NIB, int OFF, int NDW, class TVA, class TVB>
+__device__ inline void dw_matrix(f32x16 (&dw)[NDW], TVA tA, int colA, TVB tB, int colB, int lane) {
+  constexpr int KSTEPS = 4;
+  h16x8 a[2][NOB], b[2][NIB];
+#pragma unroll
+  for (int o = 0; o < NOB; ++o) a[0][o] = tr_frag(tA, colA + 32 * o, 0, lane);
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) b[0][i] = tr_frag(tB, colB + 32 * i, 0, lane);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    if (ks + 1 < KSTEPS) {
+#pragma unroll
+      for (int o = 0; o < NOB; ++o) a[(ks + 1) & 1][o] = tr_frag(tA, colA + 32 * o, ks + 1, lane);
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) b[(ks + 1) & 1][i] = tr_frag(tB, colB + 32 * i, ks + 1, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int o = 0; o < NOB; ++o)
+#pragma unroll
+      for (int i = 0; i < NIB; ++i) mfma_acc_a(dw[OFF + o * NIB + i], a[ks & 1][o], b[ks & 1][i]);
+  }
+}
+#ifdef ALN_PHASE_TIMING
+__device__ long long g_sp_cycles[4][8];
+extern "C" int aln_debug_read_pair(long long* host_out, int reset) {
+  if (reset) { long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sp_cycles), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sp_cycles), sizeof(long long) * 32);
+}
+#define SP_DECL long long sp_acc[8] = {0}, sp_last = clock64();
+#define SP_STAMP(i) { long long sp_now = clock64(); sp_acc[i] += sp_now - sp_last; sp_last = sp_now; }
+#define SP_FLUSH if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < 8; ++i) g_sp_cycles[wave][i] += sp_acc[i];
+#else
+#define SP_DECL
+#define SP_STAMP(i)
+#define SP_FLUSH
+#endif
+template <int CP>   // padded class count: semantic_out's out_pad (16 or 32)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_sem_bwd_pair(const h16* __restrict__ wf_f, const h16* __restrict__ wb_f, const h16* __restrict__ wf_o, const h16* __restrict__ wb_o,
+                    const h16* __restrict__ sigma_out, const float* __restrict__ w_row, RowSrc rs, const float* __restrict__ g_sem, int C,
+                    const float* __restrict__ g_feat, int G, int rows, h16* __restrict__ d_geo, float* __restrict__ ws_f,
+                    float* __restrict__ ws_o, int* __restrict__ found_inf) {
+  constexpr int D = 64, KS = 4, KSO = CP / 16, PH = hid_pitch(64), PFG = 80 + 8, PDL = 32, TR = 64;
+  constexpr int SET = TR * (PFG + 7 * PH + PDL + 16);   // halves per tile set
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntiles = (rows + TR - 1) / TR;
+  const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // tiles blockIdx.x, + gridDim.x, ...
+  for (int i = threadIdx.x; i < 2 * SET / 8 + 1; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);   // (dL/dlogits columns >= CP stay zero; + the flag word)
+  struct Tiles { PlainV<lds_h16*> FG, H1, H2, G1, DG1, DF, DH2, DH1, DL, DGO; };
+  auto tiles_of = [&](int set) {
+    lds_h16* t = (lds_h16*)smem + set * SET;
+    Tiles T;
+    T.FG = {t, PFG}; t += TR * PFG;      // relu(f) | geo_feat, 1   (semantic_out's input)
+    T.H1 = {t, PH}; t += TR * PH;        // h1, h2 of semantic_features, g1 of semantic_out
+    T.H2 = {t, PH}; t += TR * PH;
+    T.G1 = {t, PH}; t += TR * PH;
+    T.DG1 = {t, PH}; t += TR * PH;       // dL/d(pre-activation) of g1, f, h2, h1
+    T.DF = {t, PH}; t += TR * PH;
+    T.DH2 = {t, PH}; t += TR * PH;
+    T.DH1 = {t, PH}; t += TR * PH;
+    T.DL = {t, PDL}; t += TR * PDL;      // dL/dlogits (columns >= CP zero)
+    T.DGO = {t, 16};                     // d(geo_feat, 1) of the semantic_out branch
+    return T;
+  };
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  __syncthreads();   // zero fill done
+  if (wave < 2) {
+    // =================================================================================================== the chain
+    const h16x8* const ff = (const h16x8*)wf_f;
+    const h16x8* const of = (const h16x8*)wf_o; const h16x8* const ob = (const h16x8*)wb_o;
+    h16x8 Wf0[2], Wf1[2][KS], Wf2[2][KS], Vf0[2][5], V1T[2][KSO], V0T[3][KS];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      Wf0[m] = ff[(size_t)m * 64 + lane];                                                    // semantic_features: layer 0 (natural k)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        Wf1[m][ks] = ff[(size_t)(2 + m * KS + ks) * 64 + lane];                              //   layer 1 (chained k)
+        Wf2[m][ks] = ff[(size_t)(2 + 2 * KS + m * KS + ks) * 64 + lane];                     //   last layer (chained k)
+      }
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) Vf0[m][ks] = of[(size_t)(m * 5 + ks) * 64 + lane];      // semantic_out: layer 0 (natural k over relu(f) | geo)
+#pragma unroll
+      for (int ks = 0; ks < KSO; ++ks) V1T[m][ks] = ob[(size_t)(m * KSO + ks) * 64 + lane];  //   backward: V1^T (natural o over the logits)
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) V0T[m][ks] = ob[(size_t)(2 * KSO + m * KS + ks) * 64 + lane];   // semantic_out: V0^T (80 inputs, chained o)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // the loads have landed before the loop is entered (mlp_bwd128.hip: hipcc's wait-count pass)
+    const h16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int srow = 32 * wave + c;
+    // One wave per SIMD hides no latency by itself: the row inputs of tile it + 1 (geo_feat chunk, ray, weight) are fetched while
+    // tile it is in the chain, and the per-ray output gradients of tile it are requested before its first MFMA (they are needed
+    // after 26 and 50 of them).  Without this the four dependent trips to L2/HBM were 60 % of the chain's time (measured).
+    // (all of these loads are unconditional, from clamped rows: a branch around a load makes hipcc's wait-count pass fall back to
+    //  vmcnt(0) at the join, which waits for the prefetch of the NEXT tile as well)
+    const int last_row = rows - 1;
+    auto geo_of = [&](h16x8 lo, h16x8 hi) __attribute__((always_inline)) {   // geo_chunk() of the raw sigma_out row, without a divergent branch
+      h16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const h16 v0 = (j < 7) ? lo[j + 1] : hi[0], v1 = (j < 7) ? hi[j + 1] : (h16)1.0f;
+        const h16 v = hf ? v1 : v0;
+        o[j] = (8 * hf + j < G) ? v : (h16)1.0f;
+      }
+      return o;
+    };
+    // hipcc sinks plain loads down to their first use (one exposed round trip each, measured: 8 x vmcnt(0) in a row), and a
+    // scheduling barrier does not hold them (instruction selection orders loads before the barrier exists).  So these loads are
+    // asm statements with the idle AGPR half as destination, and the waits are placed by hand: memory loads return in order, a wait
+    // names the number of YOUNGER loads that may still be in flight, and takes the registers as operands so that no use moves above it.
+    f32x4 lon, hin; float wrn;
+#define SP_LOAD32(dst, ptr) asm volatile("global_load_dword %0, %1, off" : "=a"(dst) : "v"(ptr))
+#define SP_LOAD128(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(dst) : "v"(ptr))
+    {
+      const int row = min((int)blockIdx.x * TR + srow, last_row);
+      SP_LOAD128(lon, sigma_out + (size_t)row * 16); SP_LOAD128(hin, sigma_out + (size_t)row * 16 + 8); SP_LOAD32(wrn, w_row + row);
+    }
+    SP_DECL
+    for (int it = 0; it <= my_tiles; ++it) {
+      if (it < my_tiles) {
+        const Tiles T = tiles_of(it & 1);
+        const int row = ((int)blockIdx.x + it * (int)gridDim.x) * TR + srow;
+        const bool valid = row < rows;
+        f32x16 acc[2];
+        h16x8 p1[4], p2[4], pd[4];
+        const int ray = row_ray(rs, min(row, last_row));
+        float gs[KSO][8];
+        f32x4 gf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < KSO; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) SP_LOAD32(gs[ks][j], g_sem + (size_t)ray * C + min(16 * ks + 8 * hf + j, C - 1));
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) SP_LOAD128(gf[m][q], g_feat + (size_t)ray * D + 32 * m + 8 * q + 4 * hf);
+        if constexpr (KSO == 1) asm volatile("s_waitcnt vmcnt(16)" : "+a"(lon), "+a"(hin), "+a"(wrn));
+        else asm volatile("s_waitcnt vmcnt(24)" : "+a"(lon), "+a"(hin), "+a"(wrn));
+        const h16x8 x0 = valid ? geo_of(__builtin_bit_cast(h16x8, lon), __builtin_bit_cast(h16x8, hin)) : z8;
+        const float wr = valid ? wrn : 0.f;   // (zero weight: the row contributes nothing to any gradient)
+        *(LDS_VEC(h16x8)*)T.FG.at(srow, D + 8 * hf) = x0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m] = mfma16(Wf0[m], x0, zero16);
+        relu_pack_store<2>(acc, p1, nullptr, hf);
+        write_packed_tile<2>(T.H1, srow, p1, hf);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(Wf1[m][ks], p1[ks], ks == 0 ? zero16 : acc[m]);
+        relu_pack_store<2>(acc, p2, nullptr, hf);
+        write_packed_tile<2>(T.H2, srow, p2, hf);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(Wf2[m][ks], p2[ks], ks == 0 ? zero16 : acc[m]);
+        // f is rounded to fp16 first (what the forward stored), then relu'd: relu(f) feeds semantic_out and masks dL/df of that branch
+        relu_pack_store<2>(acc, pd, nullptr, hf);
+        write_packed_tile<2>(T.FG, srow, pd, hf);
+        // dL/dlogits of the rows: w * g_sem[ray], natural order, also parked for dW(V1)
+        h16x8 dl[KSO];
+#pragma unroll
+        for (int ks = 0; ks < KSO; ++ks)   // the 8 loads of g_feat are younger
+          asm volatile("s_waitcnt vmcnt(8)" : "+a"(gs[ks][0]), "+a"(gs[ks][1]), "+a"(gs[ks][2]), "+a"(gs[ks][3]), "+a"(gs[ks][4]), "+a"(gs[ks][5]),
+                       "+a"(gs[ks][6]), "+a"(gs[ks][7]));
+#pragma unroll
+        for (int ks = 0; ks < KSO; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dl[ks][j] = (h16)((16 * ks + 8 * hf + j < C) ? wr * gs[ks][j] : 0.f);
+          *(LDS_VEC(h16x8)*)T.DL.at(srow, 16 * ks + 8 * hf) = dl[ks];
+        }
+        {   // the next tile's row inputs: requested here, after the wait for g_sem (memory loads return in order), used in ~5000 cycles
+          const int rown = min(it + 1 < my_tiles ? row + (int)gridDim.x * TR : row, last_row);
+          SP_LOAD128(lon, sigma_out + (size_t)rown * 16); SP_LOAD128(hin, sigma_out + (size_t)rown * 16 + 8); SP_LOAD32(wrn, w_row + rown);
+        }
+        // semantic_out layer 0 reads its input in natural k order: the wave's own rows back from the tile
+        h16x8 xb[5];
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) xb[ks] = *(const LDS_VEC(h16x8)*)T.FG.at(srow, 16 * ks + 8 * hf);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(Vf0[m][ks], xb[ks], ks == 0 ? zero16 : acc[m]);
+        relu_pack_store<2>(acc, pd, nullptr, hf);
+        write_packed_tile<2>(T.G1, srow, pd, hf);
+        // ---- backward: g1 (its ReLU mask from the packed g1 still in registers)
+#pragma unroll
+        for (int ks = 0; ks < KSO; ++ks)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(V1T[m][ks], dl[ks], ks == 0 ? zero16 : acc[m]);
+        mask_pack_lds<2>(acc, pd, T.G1, srow, hf);
+        write_packed_tile<2>(T.DG1, srow, pd, hf);
+        // ---- d(relu(f) | geo): 64 + 16 outputs (the geo block first: its 16 values leave the accumulator at once)
+        h16x4 dgo[2];   // d(geo_feat, 1) of the semantic_out branch: features 8 q + 4 half + 0..3, q < 2
+        {
+          f32x16 ag = zero16;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) ag = mfma16(V0T[2][ks], pd[ks], ag);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dgo[q][r] = (h16)ag[4 * q + r];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[m] = mfma16(V0T[m][ks], pd[ks], ks == 0 ? zero16 : acc[m]);
+        {   // dL/df = w * g_feat[ray] + relu'(f) * dL/df of the semantic_out branch (that part rounded to fp16 first, as the two-launch path did)
+          h16x8 dfo[4];
+          mask_pack_lds<2>(acc, dfo, T.FG, srow, hf);
+          asm volatile("s_waitcnt vmcnt(3)" : "+a"(gf[0][0]), "+a"(gf[0][1]), "+a"(gf[0][2]), "+a"(gf[0][3]), "+a"(gf[1][0]), "+a"(gf[1][1]),
+                       "+a"(gf[1][2]), "+a"(gf[1][3]));   // the next tile's three loads are younger
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 g4 = gf[m][q];
+              const h16x8 ov = dfo[2 * m + (q >> 1)];
+              const int e = 4 * (q & 1);
+              pd[2 * m + (q >> 1)][e] = (h16)(wr * g4.x + (float)ov[e]); pd[2 * m + (q >> 1)][e + 1] = (h16)(wr * g4.y + (float)ov[e + 1]);
+              pd[2 * m + (q >> 1)][e + 2] = (h16)(wr * g4.z + (float)ov[e + 2]); pd[2 * m + (q >> 1)][e + 3] = (h16)(wr * g4.w + (float)ov[e + 3]);
+            }
+        }
+        write_packed_tile<2>(T.DF, srow, pd, hf);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *(LDS_VEC(h16x4)*)T.DGO.at(srow, 8 * q + 4 * hf) = dgo[q];
+      }
+      SP_STAMP(0) __syncthreads(); SP_STAMP(1)   // set it & 1 is complete, set (it - 1) & 1 has been consumed
+    }
+    SP_FLUSH
+  } else {
+    // ============================================================== backward of semantic_features, then the weight gradients
+    // The chain ends at dL/df: its waves would otherwise run twice as long as these two (measured 6800 against 3400 cycles per tile).
+    // Waves 2 and 3 take 32 rows each of the previous tile through W2^T, W1^T, W0^T (20 MFMAs, fragments resident), write dL/dh2,
+    // dL/dh1 and the rows' d(geo_feat); wave 3 then raises a flag in LDS, and wave 2 waits for it between dW(W2), which needs
+    // nothing of this, and dW(W1), dW(W0), which read all 64 rows.
+    const h16x8* const fb = (const h16x8*)wb_f;
+    h16x8 W2T[2][KS], W1T[2][KS], W0T[KS];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        W2T[m][ks] = fb[(size_t)(m * KS + ks) * 64 + lane];              // W2^T (natural o), W1^T (chained o)
+        W1T[m][ks] = fb[(size_t)(2 * KS + m * KS + ks) * 64 + lane];
+      }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) W0T[ks] = fb[(size_t)(4 * KS + ks) * 64 + lane];   // W0^T (16 inputs, chained o)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    LDS_VEC(int)* const flag = (LDS_VEC(int)*)((lds_h16*)smem + 2 * SET);
+    const int srow = 32 * (wave - 2) + c;
+    h16x2 nanz = {0, 0};
+    constexpr int NDW = 10;
+    f32x16 dw[NDW];
+#pragma unroll
+    for (int b = 0; b < NDW; ++b) dw[b] = zero16;
+    SP_DECL
+    for (int it = 0; it <= my_tiles; ++it) {
+      if (it > 0) {
+        const Tiles T = tiles_of((it - 1) & 1);
+        {
+          const int row = ((int)blockIdx.x + (it - 1) * (int)gridDim.x) * TR + srow;
+          f32x16 acc[2];
+          h16x8 xb[KS], pd[4];
+          // W2^T takes dL/df in natural order: the rows as the chain stored them
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) xb[ks] = *(const LDS_VEC(h16x8)*)T.DF.at(srow, 16 * ks + 8 * hf);
+          h16x4 dgo[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) dgo[q] = *(const LDS_VEC(h16x4)*)T.DGO.at(srow, 8 * q + 4 * hf);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = mfma16(W2T[m][ks], xb[ks], ks == 0 ? zero16 : acc[m]);
+          mask_pack_lds<2>(acc, pd, T.H2, srow, hf);
+          write_packed_tile<2>(T.DH2, srow, pd, hf);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = mfma16(W1T[m][ks], pd[ks], ks == 0 ? zero16 : acc[m]);
+          mask_pack_lds<2>(acc, pd, T.H1, srow, hf);
+          write_packed_tile<2>(T.DH1, srow, pd, hf);
+          f32x16 o = zero16;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) o = mfma16(W0T[ks], pd[ks], o);
+          if (row < rows) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              h16x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = (h16)(o[4 * q + r] + (float)dgo[q][r]);
+              nanz = nan_fold((h16x2){v[0], v[1]}, nan_fold((h16x2){v[2], v[3]}, nanz));
+              *(h16x4*)(d_geo + (size_t)row * 16 + 8 * q + 4 * hf) = v;
+            }
+          }
+        }
+        SP_STAMP(2)
+        if (wave == 2) {
+          dw_matrix<2, 2, 0>(dw, T.DF, 0, T.H2, 0, lane);      // W2 [64][64]: dL/df^T h2 (needs nothing of the other wave)
+          SP_STAMP(3)
+          while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          SP_STAMP(4)
+          dw_matrix<2, 2, 4>(dw, T.DH2, 0, T.H1, 0, lane);     // W1 [64][64]
+          dw_matrix<2, 1, 8>(dw, T.DH1, 0, T.FG, D, lane);     // W0 [64][16]: dL/dh1^T geo
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // rows 32..63 of dL/dh2, dL/dh1 are in LDS
+          __hip_atomic_store(flag, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          dw_matrix<2, 3, 0>(dw, T.DG1, 0, T.FG, 0, lane);     // V0 [64][80]: dL/dg1^T [relu(f) | geo]  (columns 80..95: never flushed)
+          dw_matrix<1, 2, 6>(dw, T.DL, 0, T.G1, 0, lane);      // V1 [CP][64]
+        }
+      }
+      SP_STAMP(0) __syncthreads(); SP_STAMP(1)
+    }
+    SP_FLUSH
+    // hipcc does not know that the asm statements above are MFMAs: the flush must wait for the last matrix pass to land
+    asm volatile("s_nop 15" : "+a"(dw[0]), "+a"(dw[1]), "+a"(dw[2]), "+a"(dw[3]), "+a"(dw[4]));
+    asm volatile("s_nop 1" : "+a"(dw[5]), "+a"(dw[6]), "+a"(dw[7]), "+a"(dw[8]), "+a"(dw[9]));
+    // ---- slabs of partial sums (fixed-order reduction by k_dw_reduce_all), layout = each head's fp32 master block
+    bool bad = false;
+    auto flush = [&](f32x16& a, int ob_, int ib_, int OUTL, int INL, float* dst) {
+      const int i = 32 * ib_ + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * ob_ + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const bool in_w = o < OUTL && i < INL;
+        bad |= in_w && !(fabsf(a[r]) <= 3.0e38f);
+        if (in_w) dst[(size_t)o * INL + i] = a[r];
+      }
+    };
+    if (ws_f && ws_o) {
+      constexpr int NF = 16 * 64 + 2 * 64 * 64, NO = 80 * 64 + 64 * CP;
+      float* const sf = ws_f + (size_t)blockIdx.x * NF;
+      float* const so = ws_o + (size_t)blockIdx.x * NO;
+      if (wave == 2) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) flush(dw[b], b >> 1, b & 1, 64, 64, sf + 16 * 64 + 64 * 64);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) flush(dw[4 + b], b >> 1, b & 1, 64, 64, sf + 16 * 64);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) flush(dw[8 + b], b, 0, 64, 16, sf);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) flush(dw[b], b / 3, b % 3, 64, 80, so);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) flush(dw[6 + b], 0, b, CP, 64, so + 80 * 64);
+      }
+    }
+    if (found_inf && __any(bad || nan_bad(nanz)) && lane == 0) atomicOr(found_inf, 1);
+  }
+}
+static bool sem_pair_fused_ok(const AlnMlpDesc* semf, const AlnMlpDesc* semo, int D, int G) {
+  return semf->in_pad == 16 && semf->hidden == 64 && semf->n_hidden == 2 && semf->out_pad == 64 && D == 64 && semo->in_pad == 80 &&
+         semo->hidden == 64 && semo->n_hidden == 1 && semo->out_pad <= 32 /* OBO = 1: five weight-gradient blocks per wave */ && G <= 15 && semf->wf && semf->wb && semo->wf && semo->wb;
+}
+static int sem_pair_blocks(int rows) { const int t = (rows + 63) / 64; return t < 256 ? t : 256; }
+// slabs per head the fused pair backward leaves in semf->dw_ws / semo->dw_ws for `rows` rows, or 0 when the pair runs as two launches
+// (then aln_mlp_bwd_blocks of each head applies)
+extern "C" int32_t aln_sem_heads_bwd_slabs(const AlnMlpDesc* semf, const AlnMlpDesc* semo, int32_t rows, int32_t D, int32_t G) {
+  return (semf && semo && rows > 0 && sem_pair_fused_ok(semf, semo, D, G)) ? sem_pair_blocks(rows) : 0;
+}
+
 // ---------------------------------------------------------------- launchers
 static int mlp_grid(int rows) {
   // blocks per launch of the forward / data-gradient kernels (256 threads, weights in LDS): 3 per CU
@@ -1321,11 +1718,15 @@ static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_fwd: weights (%zu B) exceed LDS", lds);
   dim3 g(mlp_grid(rows)), b(256);
   hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_KP(H, N, K, P)                                                                                          \
+  do {                                                                                                                 \
+    hipFuncSetAttribute((const void*)k_mlp_fwd<H, N, K, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    hipLaunchKernelGGL((k_mlp_fwd<H, N, K, P>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, xs,    \
+                       rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out, sigma);                                          \
+  } while (0)
 #define LAUNCH_K(H, N, K)                                                                                              \
   do {                                                                                                                 \
-    hipFuncSetAttribute((const void*)k_mlp_fwd<H, N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-    hipLaunchKernelGGL((k_mlp_fwd<H, N, K>), g, b, lds, s, (const h16*)m->wf, halves, m->in_pad, m->out_pad, xs,       \
-                       rows, rows_dev, (h16*)h1, (h16*)h2, (h16*)out, sigma);                                          \
+    if (xs.mode == SRC_PLAIN) LAUNCH_KP(H, N, K, true); else LAUNCH_KP(H, N, K, false);                                \
   } while (0)
 #define LAUNCH(H, N)                                                                                                   \
   do {                                                                                                                 \
@@ -1344,6 +1745,7 @@ static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32
   else { aln_set_error("mlp_fwd: unsupported hidden=%d n_hidden=%d", m->hidden, m->n_hidden); return -1; }
 #undef LAUNCH
 #undef LAUNCH_K
+#undef LAUNCH_KP
   ALN_CHECK_LAUNCH("mlp_fwd");
   return 0;
 }
@@ -1512,6 +1914,32 @@ extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
   ALN_REQUIRE(!fold_geo || (semf->in_pad == 16 && aln_mlp_has_recompute(semf->in_pad, semf->hidden, semf->out_pad, semf->n_hidden)),
               "sem_heads_bwd: fold_geo needs the 16-wide recompute backward of semantic_features");
   hipStream_t s = (hipStream_t)stream;
+  if (fold_geo && dW_semf && dW_semo && sem_pair_fused_ok(semf, semo, D, G)) {   // the training step: one kernel for both heads
+    if (rows <= 0) return 0;
+    const int g = sem_pair_blocks(rows);
+    const size_t nf = 16 * 64 + 2 * 64 * 64, no = 80 * 64 + 64 * (size_t)semo->out_pad;
+    ALN_REQUIRE(semf->dw_ws && semo->dw_ws && (size_t)semf->dw_ws_bytes >= g * nf * sizeof(float) && (size_t)semo->dw_ws_bytes >= g * no * sizeof(float),
+                "sem_heads_bwd: dw_ws of both heads must hold %d slabs", g);
+    RowSrc rs{}; row_src_rays(rs, N, S1, S2);
+    constexpr int PH = hid_pitch(64);
+    const size_t lds = 2 * (size_t)64 * (88 + 7 * PH + 32 + 16) * 2 + 16;   // two sets of 64-row tiles, the flag word
+#define LAUNCH_PAIR(CP)                                                                                                              \
+    do {                                                                                                                             \
+      hipFuncSetAttribute((const void*)k_sem_bwd_pair<CP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+      hipLaunchKernelGGL((k_sem_bwd_pair<CP>), dim3(g), dim3(256), lds, s, (const h16*)semf->wf, (const h16*)semf->wb, (const h16*)semo->wf,  \
+                         (const h16*)semo->wb, (const h16*)sigma_out, w_row, rs, g_sem, C, g_feat, G, rows, (h16*)d_semf_in,          \
+                         (float*)semf->dw_ws, (float*)semo->dw_ws, found_inf);                                                       \
+    } while (0)
+    if (semo->out_pad == 16) LAUNCH_PAIR(16); else LAUNCH_PAIR(32);
+#undef LAUNCH_PAIR
+    ALN_CHECK_LAUNCH("sem_bwd_pair");
+    if (!semf->defer_dw_reduce || !semo->defer_dw_reduce) {
+      hipLaunchKernelGGL(k_dw_reduce, dim3(((int)nf + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, (const float*)semf->dw_ws, g, (int)nf, dW_semf);
+      hipLaunchKernelGGL(k_dw_reduce, dim3(((int)no + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, s, (const float*)semo->dw_ws, g, (int)no, dW_semo);
+      ALN_CHECK_LAUNCH("dw_reduce");
+    }
+    return 0;
+  }
   RowSrc xo{}; xo.mode = SRC_SEMO_IN; xo.a = (const h16*)feat; xo.lda = D; xo.b = (const h16*)sigma_out; xo.ldb = 16; xo.G = G; xo.D = D;
   RowSrc go{}; go.mode = SRC_DLOGITS; go.w_row = w_row; go.g = g_sem; go.gw = C; row_src_rays(go, N, S1, S2);
   if (int rc = mlp_bwd_recomp_src(semo, xo, go, rows, nullptr, d_semo_in, dW_semo, found_inf, s)) return rc;

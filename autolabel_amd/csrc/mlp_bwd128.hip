@@ -426,6 +426,8 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   }
   PT_STAMP(0)
   PT_FLUSH
+  // (hipcc does not know the asm statements are MFMAs: the flush below must not read an accumulator before its last pass has landed)
+  asm volatile("s_nop 15" : "+a"(dwl), "+a"(dwm[0]), "+a"(dwm[1]), "+a"(dwm[2]), "+a"(dwm[3]), "+a"(dwf[0]));
   bool bad = nan_bad(nanz);
   if (dw_ws) {
     // per-block slab of partial sums, folded in a fixed order by k_dw_reduce(_all) (mlp.hip): layout = the fp32 master block

@@ -11,7 +11,7 @@ import torch
 from .build import LIB
 
 ALN_MAX_LEVELS = 16
-ABI_VERSION = 4   # include/autolabel_hip.h: ALN_ABI_VERSION
+ABI_VERSION = 5   # include/autolabel_hip.h: ALN_ABI_VERSION
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
 
@@ -76,6 +76,8 @@ _SIGS = {
     'aln_mlp_has_recompute': (i32, [i32, i32, i32, i32]),
     'aln_mlp_bwd_blocks': (i32, [vp, i32]),
     'aln_mlp_dw_reduce_all': (i32, [i32, vp, vp, vp, vp]),
+    'aln_mlp_dw_reduce_slabs': (i32, [i32, vp, vp, vp, vp, vp]),
+    'aln_sem_heads_bwd_slabs': (i32, [vp, vp, i32, i32, i32]),
     'aln_mlp_dw_ws_bytes': (i64, [i32, i32, i32, i32]),
     'aln_mlp_frag_halves': (i64, [i32, i32, i32, i32, i32]),
     'aln_mlp_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),

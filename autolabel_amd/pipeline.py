@@ -595,7 +595,10 @@ class HipPipeline:
             ds = (C.c_void_p * n)(*[C.addressof(P.descs[k]) for k in heads])
             dws = (C.c_void_p * n)(*[P.grad.data_ptr() + 4 * L.offsets[k] for k in heads])
             rows = (C.c_int32 * n)(*([M] * n))
-            self._k('aln_mlp_dw_reduce_all', n, ds, dws, rows, H.stream(), tag=None)
+            # the fused semantic pair (one kernel for both heads) leaves its own number of slabs
+            pair = int(H.lib().aln_sem_heads_bwd_slabs(C.byref(P.descs['semf']), C.byref(P.descs['semo']), M, L.D, L.G)) if sem_fused else 0
+            slabs = (C.c_int32 * n)(*[pair if k in ('semf', 'semo') else 0 for k in heads])
+            self._k('aln_mlp_dw_reduce_slabs', n, ds, dws, rows, slabs, H.stream(), tag=None)
         if on_grad_ready is not None:
             on_grad_ready('mlp', L.n_grid, L.n_total)
         if not e.use_grid:

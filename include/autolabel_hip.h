@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 4
+#define ALN_ABI_VERSION 5
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -193,6 +193,10 @@ int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* 
  * over rows[k] rows left in its dw_ws, all heads in ONE launch; aln_mlp_bwd_blocks = the number of slabs (the backward's grid) */
 int32_t aln_mlp_bwd_blocks(const AlnMlpDesc* m, int32_t rows);
 int aln_mlp_dw_reduce_all(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, void* stream);
+/* the same with the slab count of each head given explicitly (slabs[k] > 0: what aln_sem_heads_bwd_slabs returned for the fused
+ * semantic pair; 0: aln_mlp_bwd_blocks(descs[k], rows[k])) */
+int aln_mlp_dw_reduce_slabs(int32_t n_heads, const AlnMlpDesc* const* descs, float* const* dW, const int32_t* rows, const int32_t* slabs,
+                            void* stream);
 
 /* Both semantic heads (models.py:248-256) with their inputs / output gradients built on the fly from sigma_out, f, the
  * compositing weights and the per-ray output gradients (no [rows,80] / [rows,64] intermediates in HBM).
@@ -206,6 +210,10 @@ int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void
                       int32_t fold_geo /* 1 = d_semf_in rows also take the geo_feat columns of d_semo_in, so that
                                           aln_assemble_grads needs d_semf_in only (d_semo_in = NULL there) */,
                       int32_t* found_inf, void* stream);
+/* slabs per head that aln_sem_heads_bwd(..., fold_geo = 1, both dW) leaves in semf->dw_ws / semo->dw_ws when the pair runs as ONE
+ * kernel (both heads 64 wide, D = 64, <= 32 padded classes: models.py:248-256 at the reference's sizes); 0 = two launches, the
+ * per-head aln_mlp_bwd_blocks apply.  In the fused form d_semo_in is not written (dL/df never leaves the CU) and `feat` is not read. */
+int32_t aln_sem_heads_bwd_slabs(const AlnMlpDesc* semf, const AlnMlpDesc* semo, int32_t rows, int32_t D, int32_t G);
 /* ---- head plumbing: autolabel/models.py:175-188 (sigma = trunc_exp(h0), geo_feat = h[1:]), :190-220 (boolean-mask
  * gather + SH(dir) ++ geo_feat), :248-256 (cat[relu(f), geo_feat]) and the matching gradient assembly */
 int aln_sigma_act(const void* sigma_out /*[rows,16] f16*/, int32_t rows, float* sigma, void* stream);

@@ -662,7 +662,16 @@ def test_semantic_heads_backward_matches_fp32(H, N, S1, S2, Ccls, out_pad, G):
            N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, H.ptr(flag), H.stream())
     assert flag.item() == 0
     assert (d_fin_f.float() - d_geo).abs().max().item() <= 2e-3 * d_geo.abs().max().item() + 1e-6
-    assert torch.equal(dWf3, dWf) and torch.equal(dWo3, dWo)
+    fused = H.lib().aln_sem_heads_bwd_slabs(C.byref(dF), C.byref(dO), rows, 64, G) > 0
+    if fused:   # fold_geo = 1 with both dW: ONE kernel for both heads (k_sem_bwd_pair) -- another summation order, same sums
+        assert (dWf3 - dWf).abs().max().item() <= 2e-3 * dWf.abs().max().item() and (dWo3 - dWo).abs().max().item() <= 2e-3 * dWo.abs().max().item()
+        dWf4, dWo4, d_fin_g = torch.zeros_like(dWf), torch.zeros_like(dWo), torch.zeros_like(d_fin)
+        H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
+               N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_g), H.ptr(dWf4), H.ptr(dWo4), 1, H.ptr(flag), H.stream())
+        assert torch.equal(dWf4, dWf3) and torch.equal(dWo4, dWo3) and torch.equal(d_fin_g, d_fin_f), 'the fused pair must be bit-reproducible'
+        dWf, dWo = dWf3, dWo3     # the fp32 comparison below then checks the fused kernel's gradients
+    else:
+        assert torch.equal(dWf3, dWf) and torch.equal(dWo3, dWo)
     # fp32 autograd through the half_sim oracle MLPs
     x = sigma_out.cpu().float()
     geo = torch.cat([x[:, 1:1 + G], torch.ones(rows, 16 - G)], 1).requires_grad_(True)
