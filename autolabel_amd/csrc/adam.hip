@@ -20,6 +20,12 @@
 struct AdamHyper { float lr, beta1, beta2, eps, wd_net, growth, backoff; int growth_interval; double log_beta1, log_beta2; };
 struct AdamBlocks { int n; long long end[ADAM_MAX_BLOCKS]; int needs_sem[ADAM_MAX_BLOCKS]; int needs_sem_or_feat[ADAM_MAX_BLOCKS]; int feat_on;
                     int skip_grid; };   // skip_grid: block 0 was updated by phase 2 of the hash-grid scatter (encode.hip, AccAdam)
+// The slices [lo, hi) of the hash table this launch owns (multiples of 4 parameters).  One slice [0, n_grid) on one GPU; under
+// data parallelism with a sharded optimizer (aln_adam_step_ranges) every rank owns 1 / world of every gradient bucket, and its
+// moment buffers m, v hold the owned slices back to back (slice k at mv[k]), then the MLP block at mlp_mv: the optimizer state
+// of the table is 1 / world of the replicated one.
+#define ADAM_MAX_RANGES 8
+struct AdamRanges { int n; long long lo[ADAM_MAX_RANGES], hi[ADAM_MAX_RANGES], mv[ADAM_MAX_RANGES]; long long mlp_mv; };
 
 // The step constants (skip flag, 1 / loss scale, per-block step size and bias correction) are a pure function of the state words
 // as they stand BEFORE this step; every block derives them itself (one thread, a handful of pow() in double) instead of waiting
@@ -34,10 +40,10 @@ __device__ inline bool adam_block_active(const AdamBlocks& blk, int b, bool has_
 
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        h16* __restrict__ table16, size_t n_grid, size_t n_total, int* si, float* sf, float* c_out, AdamHyper h,
-                       AdamBlocks blk, const int* counts, uint32_t* step_dev) {
+                       AdamBlocks blk, AdamRanges rg, const int* counts, uint32_t* step_dev) {
   __shared__ AdamConsts cs;
   const size_t vec_end = (blk.n > 0 && (size_t)blk.end[0] <= n_grid) ? ((size_t)blk.end[0] & ~(size_t)3) : 0;
-  const size_t vec_lo = blk.skip_grid ? vec_end / 4 : 0;     // (skip_grid: nothing of block 0 is touched, not even its zero gradient)
+  // (skip_grid: rg.n = 0 -- nothing of block 0 is touched, not even its zero gradient)
   {   // lane b derives the constants of parameter block b (the lanes work side by side); all state words in ONE round trip
     const int b = threadIdx.x & (ADAM_MAX_BLOCKS - 1);
     const int found = si[2], t0 = si[4 + b], lab = counts ? counts[1] : 1;
@@ -70,10 +76,14 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     const float step_size = r_step[0], inv_sqrt_bc2 = r_isb[0];
     const bool idle = skip || step_size == 0.f;
     const float b1 = h.beta1, b2 = h.beta2, c1 = 1.f - h.beta1, c2 = 1.f - h.beta2;
-    for (size_t q = vec_lo + blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < vec_end / 4; q += (size_t)gridDim.x * blockDim.x) {
+    for (int k = 0; k < rg.n; ++k) {
+    const size_t q_lo = (size_t)rg.lo[k] / 4, q_hi = min((size_t)rg.hi[k], vec_end) / 4;
+    const long long mq0 = rg.mv[k] / 4 - (long long)q_lo;   // moment index of parameter group q: q + mq0
+    for (size_t q = q_lo + blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < q_hi; q += (size_t)gridDim.x * blockDim.x) {
+      const size_t mq = (size_t)((long long)q + mq0);
       const float4 g4 = ((const float4*)g)[q];
       float4 p4, m4, v4;
-      if (!idle) { p4 = ((const float4*)p)[q]; m4 = ((const float4*)m)[q]; v4 = ((const float4*)v)[q]; }
+      if (!idle) { p4 = ((const float4*)p)[q]; m4 = ((const float4*)m)[mq]; v4 = ((const float4*)v)[mq]; }
       ((float4*)g)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idle) continue;
       float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -88,14 +98,16 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
         pp[k] -= step_size * (mi / denom);
         t4[k] = (h16)pp[k];
       }
-      ((float4*)m)[q] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-      ((float4*)v)[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      ((float4*)m)[mq] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      ((float4*)v)[mq] = make_float4(vv[0], vv[1], vv[2], vv[3]);
       ((float4*)p)[q] = make_float4(pp[0], pp[1], pp[2], pp[3]);
       *(h16x4*)(table16 + 4 * q) = t4;
     }
+    }
   }
-  // the rest (MLP weights, a ragged grid tail): one parameter per lane, block looked up per element
-  for (size_t i = (blk.skip_grid ? (size_t)blk.end[0] : vec_end) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
+  // the rest (MLP weights, a ragged grid tail -- single-range launches only): one parameter per lane, block looked up per element
+  const long long mi0 = rg.mlp_mv - (long long)n_grid;   // moment index of MLP parameter i: i + mi0 (0 for the replicated layout)
+  for (size_t i = (blk.skip_grid || rg.mlp_mv != (long long)n_grid ? (size_t)blk.end[0] : vec_end) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_total; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i];
     g[i] = 0.f;
     if (skip) continue;
@@ -107,9 +119,10 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     float pi = p[i];
     gi *= inv_scale;
     if (i >= n_grid) gi += h.wd_net * pi;
-    float mi = h.beta1 * m[i] + (1.f - h.beta1) * gi;
-    float vi = h.beta2 * v[i] + (1.f - h.beta2) * gi * gi;
-    m[i] = mi; v[i] = vi;
+    const size_t im = (size_t)((long long)i + mi0);
+    float mi = h.beta1 * m[im] + (1.f - h.beta1) * gi;
+    float vi = h.beta2 * v[im] + (1.f - h.beta2) * gi * gi;
+    m[im] = mi; v[im] = vi;
     float denom = sqrtf(vi) * inv_sqrt_bc2 + h.eps;
     pi -= step_size * (mi / denom);
     p[i] = pi;
@@ -142,11 +155,12 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
 // block_kind[b]: 0 = always has a gradient, 1 = only with labelled rays (semantic_out), 2 = labelled rays or feature loss
 // (semantic_features).  counts (device, from aln_loss_fwd_bwd) may be NULL: every block is then active.
 // state_i: 16 int32 (si[15] = arrival ticket of the kernel: zero before the first launch, reset by the kernel itself).
-extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid,
-                             int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
-                             float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
-                             int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
-                             int32_t skip_grid, const int32_t* counts, uint32_t* step_dev, void* stream) {
+static int adam_launch(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid,
+                       int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
+                       float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
+                       int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
+                       int32_t skip_grid, int32_t n_ranges, const int64_t* range_lo, const int64_t* range_hi,
+                       const int32_t* counts, uint32_t* step_dev, void* stream) {
   ALN_REQUIRE(params && grads && m && v && state_i && state_f, "adam: NULL pointer");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
   ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
@@ -162,11 +176,50 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
   blk.feat_on = feature_loss;
   ALN_REQUIRE(!skip_grid || (n_blocks > 0 && block_end[0] == n_grid), "adam: skip_grid needs the table as parameter block 0");
   blk.skip_grid = skip_grid ? 1 : 0;
-  const int64_t n_work = skip_grid ? n_total - n_grid : n_total;
+  AdamRanges rg{};
+  int64_t n_work = n_total - n_grid;
+  if (n_ranges < 0) {   // the whole table (replicated optimizer), moments indexed like the parameters
+    rg.mlp_mv = n_grid;
+    if (!skip_grid && n_grid > 0) { rg.n = 1; rg.lo[0] = 0; rg.hi[0] = n_grid; rg.mv[0] = 0; n_work = n_total; }
+  } else {
+    ALN_REQUIRE(!skip_grid && n_ranges <= ADAM_MAX_RANGES && (n_ranges == 0 || (range_lo && range_hi)), "adam: bad range list (%d)", n_ranges);
+    ALN_REQUIRE(n_grid % 4 == 0 && n_blocks > 0 && block_end[0] == n_grid, "adam: owned ranges need the table as parameter block 0, a multiple of 4 long");
+    int64_t at = 0;
+    for (int k = 0; k < n_ranges; ++k) {
+      ALN_REQUIRE(0 <= range_lo[k] && range_lo[k] <= range_hi[k] && range_hi[k] <= n_grid && range_lo[k] % 4 == 0 && range_hi[k] % 4 == 0 &&
+                  (k == 0 || range_lo[k] >= range_hi[k - 1]), "adam: owned range %d = [%lld, %lld)", k, (long long)range_lo[k], (long long)range_hi[k]);
+      rg.lo[k] = range_lo[k]; rg.hi[k] = range_hi[k]; rg.mv[k] = at;
+      at += range_hi[k] - range_lo[k];
+    }
+    rg.n = n_ranges; rg.mlp_mv = at; n_work += at;
+  }
   hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_work > 0 ? n_work : 1, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
-                     (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, counts, step_dev);
+                     (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, rg, counts, step_dev);
   ALN_CHECK_LAUNCH("adam");
   return 0;
+}
+extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid,
+                             int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
+                             float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
+                             int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
+                             int32_t skip_grid, const int32_t* counts, uint32_t* step_dev, void* stream) {
+  return adam_launch(params, grads, m, v, table_f16, n_grid, n_total, state_i, state_f, consts, lr, beta1, beta2, eps, wd_net, growth, backoff,
+                     growth_interval, n_blocks, block_end, block_kind, feature_loss, skip_grid, -1, nullptr, nullptr, counts, step_dev, stream);
+}
+// Sharded optimizer of the data-parallel engine (autolabel_amd/engine.py: shard_optimizer): the step touches only the slices
+// [range_lo[k], range_hi[k]) of the hash table (ascending, disjoint, multiples of 4) and the whole MLP block.  `m`, `v` are
+// COMPACT: the owned slices back to back, then the n_total - n_grid MLP moments.  Gradients outside the owned slices are neither
+// read nor cleared (aln_grad_pack_f16 with clear_src does that when the gradient leaves for the reduce-scatter); the fp32 master
+// and the fp16 table are updated inside the owned slices only (the table is then all-gathered).
+extern "C" int aln_adam_step_ranges(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid,
+                                    int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
+                                    float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
+                                    int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
+                                    int32_t n_ranges, const int64_t* range_lo, const int64_t* range_hi, const int32_t* counts,
+                                    uint32_t* step_dev, void* stream) {
+  ALN_REQUIRE(n_ranges >= 0, "adam: negative range count");
+  return adam_launch(params, grads, m, v, table_f16, n_grid, n_total, state_i, state_f, consts, lr, beta1, beta2, eps, wd_net, growth, backoff,
+                     growth_interval, n_blocks, block_end, block_kind, feature_loss, 0, n_ranges, range_lo, range_hi, counts, step_dev, stream);
 }
 
 // fp16 shadow of the grid table from the fp32 master (initialisation / checkpoint load)
@@ -197,7 +250,8 @@ extern "C" int aln_cast_f32(const void* src_f16, float* dst, int64_t n, void* st
 // out = fp16(g * mul) with mul = 1 / world (the SUM over the ranks is then the average and cannot overflow unless an input did),
 // and back: g = fp32(in), raising found_inf for a non-finite element (the step is skipped and the scale backs off, exactly as
 // for an fp16 overflow anywhere else).  8 elements per thread, 16-byte accesses on the fp16 side.
-__global__ void k_grad_pack_f16(const float* __restrict__ g, size_t n, float mul, h16* __restrict__ out) {
+template <bool CLEAR>   // CLEAR: the source is zeroed behind the read and out[n, n_pad) is zero-filled (reduce-scatter staging)
+__global__ void k_grad_pack_f16(float* __restrict__ g, size_t n, size_t n_pad, float mul, h16* __restrict__ out) {
   const size_t n8 = n / 8;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const float4 a = *(const float4*)(g + 8 * i), b = *(const float4*)(g + 8 * i + 4);
@@ -205,8 +259,12 @@ __global__ void k_grad_pack_f16(const float* __restrict__ g, size_t n, float mul
     v[0] = (h16)(a.x * mul); v[1] = (h16)(a.y * mul); v[2] = (h16)(a.z * mul); v[3] = (h16)(a.w * mul);
     v[4] = (h16)(b.x * mul); v[5] = (h16)(b.y * mul); v[6] = (h16)(b.z * mul); v[7] = (h16)(b.w * mul);
     *(h16x8*)(out + 8 * i) = v;
+    if (CLEAR) { *(float4*)(g + 8 * i) = make_float4(0.f, 0.f, 0.f, 0.f); *(float4*)(g + 8 * i + 4) = make_float4(0.f, 0.f, 0.f, 0.f); }
   }
-  if (blockIdx.x == 0) for (size_t i = 8 * n8 + threadIdx.x; i < n; i += blockDim.x) out[i] = (h16)(g[i] * mul);
+  if (blockIdx.x == 0) {
+    for (size_t i = 8 * n8 + threadIdx.x; i < n; i += blockDim.x) { out[i] = (h16)(g[i] * mul); if (CLEAR) g[i] = 0.f; }
+    if (CLEAR) for (size_t i = n + threadIdx.x; i < n_pad; i += blockDim.x) out[i] = (h16)0.f;
+  }
 }
 __global__ void k_grad_unpack_f16(const h16* __restrict__ in, size_t n, float* __restrict__ g, int* __restrict__ found_inf) {
   const size_t n8 = n / 8;
@@ -226,8 +284,21 @@ extern "C" int aln_grad_pack_f16(const float* grad, int64_t n, float mul, void* 
   ALN_REQUIRE(grad && out_f16 && n >= 0, "grad_pack_f16: bad arguments");
   ALN_REQUIRE(((uintptr_t)grad & 15) == 0 && ((uintptr_t)out_f16 & 15) == 0, "grad_pack_f16: buffers must be 16-byte aligned");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_grad_pack_f16, dim3(aln_grid_for(n / 8 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, grad, (size_t)n, mul, (h16*)out_f16);
+  hipLaunchKernelGGL(k_grad_pack_f16<false>, dim3(aln_grid_for(n / 8 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(grad), (size_t)n,
+                     (size_t)n, mul, (h16*)out_f16);
   ALN_CHECK_LAUNCH("grad_pack_f16");
+  return 0;
+}
+// Staging of a gradient bucket for a reduce-scatter: out[0, n) = fp16(grad * mul), out[n, n_pad) = 0 (the collective wants
+// world equal shards), and grad[0, n) is cleared behind the read -- the scatter of the next step adds into it, and a rank with a
+// sharded optimizer only ever clears the slice it owns.
+extern "C" int aln_grad_pack_f16_clear(float* grad, int64_t n, int64_t n_pad, float mul, void* out_f16, void* stream) {
+  ALN_REQUIRE(grad && out_f16 && n >= 0 && n_pad >= n, "grad_pack_f16_clear: bad arguments");
+  ALN_REQUIRE(((uintptr_t)grad & 15) == 0 && ((uintptr_t)out_f16 & 15) == 0, "grad_pack_f16_clear: buffers must be 16-byte aligned");
+  if (n_pad == 0) return 0;
+  hipLaunchKernelGGL(k_grad_pack_f16<true>, dim3(aln_grid_for(n / 8 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, grad, (size_t)n, (size_t)n_pad, mul,
+                     (h16*)out_f16);
+  ALN_CHECK_LAUNCH("grad_pack_f16_clear");
   return 0;
 }
 extern "C" int aln_grad_unpack_f16(const void* in_f16, int64_t n, float* grad, int32_t* found_inf, void* stream) {

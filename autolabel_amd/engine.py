@@ -17,7 +17,8 @@ SCALER_DEFAULTS = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5
 class TrainEngine:
     def __init__(self, pipe, lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6, rgb_weight=1.0, depth_weight=0.1,
                  semantic_weight=1.0, feature_weight=0.5, feature_loss=False, num_steps=128, upsample_steps=128,
-                 scaler=None, process_group=None, overlap_comm=True, grad_payload='f16', fuse_grid_adam=True):
+                 scaler=None, process_group=None, overlap_comm=True, grad_payload='f16', fuse_grid_adam=True, shard_optimizer=False,
+                 shard_gather='table'):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
         dv = self.P.device
         # the step's intermediates live in a workspace of the engine's own: a render through the same pipeline (pipe.ws) between
@@ -33,8 +34,28 @@ class TrainEngine:
         self.S1, self.S2 = int(num_steps), int(upsample_steps)
         sc = dict(SCALER_DEFAULTS, **(scaler or {}))
         self.scaler_cfg = sc
-        n = self.L.n_total
-        self.m = torch.zeros(n, device=dv)
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
+        # Sharded optimizer (data parallel only): every rank owns 1 / world of every hash-grid gradient bucket -- reduce-scatter
+        # instead of all-reduce, Adam on the owned slices with moments allocated for those slices only, all-gather of the updated
+        # fp16 table.  The fp32 masters of the other ranks' slices go stale in P.flat until sync_master() (checkpoints).
+        # shard_gather='master': the fp32 masters are all-gathered every step instead of the fp16 table (twice the bytes) -- for a
+        # caller that reads the masters between steps (the trainer's EMA)
+        assert shard_gather in ('table', 'master')
+        self.shard_gather = shard_gather
+        self.shard = None
+        if shard_optimizer and self.world > 1 and self.L.n_grid > 0:
+            from .parallel import shard_range
+            F, g = int(self.L.enc.grid.n_features), self.L.enc.grid
+            nl = int(g.n_levels)
+            buckets = sorted((int(g.offset[lo]) * F, int(g.offset[hi]) * F if hi < nl else self.L.n_grid) for lo, hi in self.level_groups())
+            assert self.L.n_grid % 4 == 0 and len(buckets) <= 8, 'sharded optimizer: table length must be a multiple of 4, at most 8 level groups'
+            own = [shard_range(a, b, self.rank, self.world)[:2] for a, b in buckets]
+            self.shard = dict(buckets=buckets, own=own, n_own=sum(hi - lo for lo, hi in own),
+                              lo=(C.c_int64 * len(own))(*[lo for lo, _ in own]), hi=(C.c_int64 * len(own))(*[hi for _, hi in own]))
+        n = self.L.n_total if self.shard is None else self.shard['n_own'] + self.L.n_total - self.L.n_grid
+        self.m = torch.zeros(n, device=dv)     # (sharded: the owned table slices back to back, then the MLP block)
         self.v = torch.zeros(n, device=dv)
         self.state_i = torch.zeros(16, dtype=torch.int32, device=dv)  # [steps, growth tracker, found_inf, scatter found_inf (DP overlap), per-block steps]
         self.state_f = torch.tensor([sc['init_scale'], float(lr), 0, 0], dtype=torch.float32, device=dv)  # [loss scale, lr]
@@ -51,8 +72,6 @@ class TrainEngine:
         self._terms = torch.zeros(int(H.lib().aln_loss_terms_floats()), device=dv)
         self.terms = self._terms[:5]  # rgb, depth, feature, semantic, total (last step); behind them: scratch of aln_loss_fwd_bwd
         pipe.found_inf = self.state_i[2:3]
-        self.pg = process_group
-        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         # data parallel: the gradient all-reduce runs in buckets on a side stream while the hash-grid scatter is still
         # working on the remaining levels (the scatter is the last and longest kernel of the backward pass)
         self.overlap_comm = self.world > 1 and bool(overlap_comm)   # False: one collective after the backward pass
@@ -146,7 +165,7 @@ class TrainEngine:
             if kind == 'mlp':   # MLP block + the overflow flag in the tail element (every rank must skip the same steps)
                 allreduce_bucket(self.P.grad, a, b, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts)
             else:
-                allreduce_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire(b - a), flag=self.state_i[3:4])
+                self._exchange_grid(a, b)
                 if a == 0:
                     # last bucket: every scatter group has run (this stream waited for the compute stream's event).  The scatter's
                     # own flag word (state_i[3]: a non-finite record) is MAX-reduced over the ranks and OR-ed into the step's flag
@@ -155,6 +174,15 @@ class TrainEngine:
                     torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.pg)
                     self.state_i[2:3] = torch.maximum(self.state_i[2:3], (flag > 0).to(self.state_i.dtype))
                     self.state_i[3:4] = 0
+
+    def _exchange_grid(self, a, b):
+        """One hash-grid bucket over the ranks on the current stream: all-reduce, or reduce-scatter under the sharded optimizer."""
+        from .parallel import allreduce_bucket, reduce_scatter_bucket, shard_range
+        if self.shard is None:
+            allreduce_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire(b - a), flag=self.state_i[3:4])
+        else:
+            S = shard_range(a, b, self.rank, self.world)[2]
+            reduce_scatter_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire((self.world + 1) * S), flag=self.state_i[3:4])
 
     def _wire(self, n):
         """fp16 staging buffer of the gradient payload (one per engine, grown to the largest bucket)."""
@@ -172,6 +200,15 @@ class TrainEngine:
         if self.world > 1:
             if self._reduced:
                 torch.cuda.current_stream().wait_stream(self._comm)
+            elif self.shard is not None:   # the same collectives as the overlapped path, one after the other on this stream
+                from .parallel import allreduce_bucket
+                allreduce_bucket(self.P.grad, self.L.n_grid, self.L.n_total, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts)
+                for a, b in self.shard['buckets']:
+                    self._exchange_grid(a, b)
+                flag = self.state_i[3:4].to(torch.float32)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+                self.state_i[2:3] = torch.maximum(self.state_i[2:3], (flag > 0).to(self.state_i.dtype))
+                self.state_i[3:4] = 0
             else:
                 from .parallel import allreduce_gradients
                 allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts, n_grid=self.L.n_grid,
@@ -179,6 +216,21 @@ class TrainEngine:
 
     def optimizer_step(self, step_dev=None, skip_grid=False):
         P, L, sc = self.P, self.L, self.scaler_cfg
+        if self.shard is not None:
+            sh = self.shard
+            H.call('aln_adam_step_ranges', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
+                   H.ptr(self.state_i), H.ptr(self.state_f), H.ptr(self.consts), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                   sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), len(self._blk_kind), self._blk_end,
+                   self._blk_kind, int(bool(self.feature_loss)), len(sh['own']), sh['lo'], sh['hi'], H.ptr(self.counts), H.ptr(step_dev), H.stream())
+            from .parallel import allgather_bucket
+            if self.shard_gather == 'master':
+                self.sync_master()
+                P.refresh_shadows(grid=True)
+                return
+            for a, b in sh['buckets']:     # the updated fp16 table of every owner (a skipped step gathers the unchanged table)
+                allgather_bucket(P.table16, a, b, self.pg, scratch=self._g.get('wire'))
+            P.refresh_shadows(grid=False)
+            return
         H.call('aln_adam_step', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
                H.ptr(self.state_i), H.ptr(self.state_f), H.ptr(self.consts), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), len(self._blk_kind), self._blk_end,
@@ -221,12 +273,43 @@ class TrainEngine:
         return GraphedStep(body, self.P.device, warmup=warmup, alt_body=body_with_refresh, alt_every=self.pipe.occ.update_interval,
                            guard=guard)
 
-    # checkpoint payload mirrors torch's {'optimizer', 'scaler'} entries (autolabel/backend.py:157-164)
+    def sync_master(self):
+        """Sharded optimizer: all-gather the fp32 masters of the hash table into P.flat on every rank (a collective: every rank
+        calls it).  The training step itself only exchanges the fp16 table; checkpoints and EMA copies want the masters."""
+        if self.shard is not None:
+            from .parallel import allgather_bucket
+            for a, b in self.shard['buckets']:
+                allgather_bucket(self.P.flat, a, b, self.pg)
+
+    def _full_moments(self, t):
+        """Sharded layout [owned slices | MLP] -> the replicated layout [table | MLP] (a collective under the sharded optimizer)."""
+        if self.shard is None:
+            return t
+        from .parallel import allgather_bucket
+        L, sh = self.L, self.shard
+        full = torch.zeros(L.n_total, dtype=t.dtype, device=t.device)
+        at = 0
+        for lo, hi in sh['own']:
+            full[lo:hi] = t[at:at + hi - lo]; at += hi - lo
+        full[L.n_grid:] = t[at:]
+        for a, b in sh['buckets']:
+            allgather_bucket(full, a, b, self.pg)
+        return full
+
+    def _own_moments(self, full):
+        if self.shard is None:
+            return full
+        return torch.cat([full[lo:hi] for lo, hi in self.shard['own']] + [full[self.L.n_grid:self.L.n_total]])
+
+    # checkpoint payload mirrors torch's {'optimizer', 'scaler'} entries (autolabel/backend.py:157-164); the moments are always
+    # stored in the replicated layout, so a checkpoint does not depend on the number of ranks it was written with
     def state_dict(self):
-        return {'m': self.m, 'v': self.v, 'state_i': self.state_i, 'state_f': self.state_f, 'lr': self.lr}
+        return {'m': self._full_moments(self.m), 'v': self._full_moments(self.v), 'state_i': self.state_i, 'state_f': self.state_f, 'lr': self.lr}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.state_i.copy_(sd['state_i']); self.state_f.copy_(sd['state_f'])
+        dv = self.m.device
+        self.m.copy_(self._own_moments(sd['m'].to(dv))); self.v.copy_(self._own_moments(sd['v'].to(dv)))
+        self.state_i.copy_(sd['state_i']); self.state_f.copy_(sd['state_f'])
         self._lr = float(sd.get('lr', self._lr))
         self.state_f[1:2].copy_(torch.tensor([self._lr], dtype=torch.float32))
 

@@ -108,6 +108,8 @@ _SIGS = {
     'aln_cast_f16': (i32, [vp, vp, i64, vp]),
     'aln_cast_f32': (i32, [vp, vp, i64, vp]),
     'aln_grad_pack_f16': (i32, [vp, i64, f32, vp, vp]),
+    'aln_grad_pack_f16_clear': (i32, [vp, i64, i64, f32, vp, vp]),
+    'aln_adam_step_ranges': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     'aln_grad_unpack_f16': (i32, [vp, i64, vp, vp, vp]),
     'aln_lzf_decompress': (i64, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
 }

@@ -3,6 +3,10 @@ ONE exchange per step -- the all-reduce of the flat gradient buffer (hash grid 1
 the hash-grid block crosses the wire as fp16 (28.5 MB per rank and step instead of 57 MB).  The reference has no multi-GPU path; this is the single data-parallel axis of 8(e).
 
 The GradScaler overflow flag rides in the tail of the same buffer so every rank skips the same steps.
+
+Sharded optimizer (TrainEngine(shard_optimizer=True)): the all-reduce of every hash-grid bucket is split into its two halves --
+reduce-scatter of the gradient, Adam on the 1 / world slice a rank owns (moments allocated for that slice only), all-gather of the
+updated fp16 table -- same wire bytes, 1 / world of the optimizer's HBM traffic and state.
 """
 import os
 
@@ -116,6 +120,63 @@ def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=N
     _avg_inplace(grad[a:b], group, world)
     if found_inf is not None:
         _unpack_tail(grad, tail, found_inf, counts)
+
+
+def shard_range(a, b, rank, world, align=8):
+    """The slice [lo, hi) of the bucket [a, b) rank `rank` owns under the sharded optimizer, and the common shard length S
+    (a multiple of `align` elements -- 16 bytes of fp16; the collectives want `world` equal shards, so the last ranks of a
+    ragged bucket own a short or empty slice and the staging buffers are padded to world * S)."""
+    n = b - a
+    S = -(-n // (world * align)) * align
+    lo = min(a + rank * S, b)
+    return lo, min(lo + S, b), S
+
+
+def reduce_scatter_bucket(grad, a, b, group=None, payload='f32', scratch=None, flag=None):
+    """Average `grad[a:b]` over the group, every rank keeping only the slice it owns (shard_range): grad[lo:hi] holds the
+    average afterwards, the rest of grad[a:b] is ZERO (the scatter of the next step adds into it; nobody reads it before).
+    Half the wire bytes of the all-reduce; the other half is the all-gather of the updated table (allgather_bucket).
+    payload='f16' (device tensors): fp16 on the wire through `scratch` (>= 2 * world * S halves); `flag` (int32[1]) is raised on
+    a non-finite element of the OWNED slice -- the caller reduces the flag over the ranks.  Returns (lo, hi)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, S = shard_range(a, b, rank, world)
+    n = b - a
+    if payload == 'f16':
+        from . import hip as H
+        if not grad.is_cuda:
+            raise RuntimeError("payload='f16' needs device tensors (the conversions are HIP kernels); use payload='f32' on the CPU")
+        assert scratch is not None and scratch.dtype == torch.float16 and scratch.numel() >= (world + 1) * S, 'fp16 staging buffer too small'
+        assert a % 4 == 0 and lo % 4 == 0, 'bucket and shard starts must keep the fp32 side 16-byte aligned'
+        wire, mine = scratch[:world * S], scratch[world * S:(world + 1) * S]
+        H.call('aln_grad_pack_f16_clear', H.ptr(grad[a:b]), n, world * S, 1.0 / world, H.ptr(wire), H.stream())
+        dist.reduce_scatter_tensor(mine, wire, op=dist.ReduceOp.SUM, group=group)
+        if hi > lo:
+            H.call('aln_grad_unpack_f16', H.ptr(mine), hi - lo, H.ptr(grad[lo:hi]), H.ptr(flag) if flag is not None else None, H.stream())
+        return lo, hi
+    wire = torch.zeros(world * S, dtype=grad.dtype, device=grad.device)
+    wire[:n] = grad[a:b]
+    mine = torch.empty(S, dtype=grad.dtype, device=grad.device)
+    dist.reduce_scatter_tensor(mine, wire, op=dist.ReduceOp.SUM, group=group)
+    grad[a:b] = 0
+    grad[lo:hi] = mine[:hi - lo] * (1.0 / world)
+    return lo, hi
+
+
+def allgather_bucket(buf, a, b, group=None, scratch=None):
+    """Every rank contributes the slice of `buf[a:b]` it owns (shard_range) and ends up with the whole bucket: the updated
+    fp16 table after a sharded optimizer step (or the fp32 masters / Adam moments for a checkpoint).  In place when the bucket
+    splits evenly (the default model's level groups do); a ragged bucket goes through `scratch` (world * S elements)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, S = shard_range(a, b, rank, world)
+    if b - a == world * S:
+        dist.all_gather_into_tensor(buf[a:b], buf[lo:hi], group=group)
+        return
+    if scratch is None or scratch.dtype != buf.dtype or scratch.numel() < (world + 1) * S:
+        scratch = torch.empty((world + 1) * S, dtype=buf.dtype, device=buf.device)
+    mine, full = scratch[world * S:(world + 1) * S], scratch[:world * S]
+    mine[:hi - lo] = buf[lo:hi]
+    dist.all_gather_into_tensor(full, mine, group=group)
+    buf[a:b] = full[:b - a]
 
 
 def broadcast_parameters(flat, group=None, src=0):

@@ -73,7 +73,7 @@ class Trainer:
                  local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
                  workspace='workspace', best_mode='min', use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint='latest', use_tensorboardX=False, scheduler_update_every_step=False, fused=None,
-                 process_group=None, use_graph=True, device_data='auto', use_graph_dp=False):
+                 process_group=None, use_graph=True, device_data='auto', use_graph_dp=False, shard_optimizer=False):
         self.name, self.opt, self.mute, self.metrics = name, opt, mute, metrics
         self.local_rank, self.world_size, self.workspace = local_rank, world_size, workspace
         self.ema_decay, self.fp16, self.best_mode = ema_decay, fp16, best_mode
@@ -84,6 +84,7 @@ class Trainer:
         self.device = device if device is not None else torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')
         self.time_stamp = time.strftime('%Y-%m-%d_%H-%M-%S')
         self.process_group = process_group
+        self.shard_optimizer = bool(shard_optimizer) and world_size > 1   # TrainEngine(shard_optimizer): 1 / world of the table's Adam per rank
         self.use_graph = bool(use_graph)   # device-resident loaders: replay the whole step from a hipGraph (engine.GraphedStep)
         # data parallel: capture the step WITH its collectives (RCCL process groups are capturable, gloo is not); opt-in until it has
         # run on a multi-GPU node -- a failed capture falls back to launch-by-launch steps with a warning
@@ -148,7 +149,8 @@ class Trainer:
                                       feature_loss=getattr(opt, 'feature_loss', False),
                                       num_steps=getattr(opt, 'num_steps', self.model.num_steps_default),
                                       upsample_steps=getattr(opt, 'upsample_steps', self.model.upsample_steps_default),
-                                      process_group=self.process_group)
+                                      process_group=self.process_group, shard_optimizer=self.shard_optimizer,
+                                      shard_gather='master' if self.ema is not None else 'table')   # (the EMA reads the fp32 masters every step)
             if old is not None:   # same parameters on a new buffer: the Adam moments / loss scale / step counters carry over
                 self.engine.load_state_dict(old.state_dict())
             self._graph = None
@@ -211,6 +213,9 @@ class Trainer:
         if name is None:
             name = f'{self.name}_ep{self.epoch:04d}'
         state = {'epoch': self.epoch, 'global_step': self.global_step, 'stats': self.stats}
+        sharded = self.engine is not None and self.engine.shard is not None
+        if sharded:   # EVERY rank calls save_checkpoint then: gathering the masters and the Adam moments is a collective; rank 0 writes
+            self.engine.sync_master()
         if full:
             state['optimizer'] = self.optimizer.state_dict()
             state['lr_scheduler'] = self.lr_scheduler.state_dict()
@@ -224,6 +229,8 @@ class Trainer:
         state['model'] = self.model.state_dict()
         if best and self.ema is not None:
             self.ema.restore()
+        if sharded and self.local_rank != 0:
+            return
         path = self.best_path if best else f'{self.ckpt_path}/{name}.pth'
         if not best:
             self.stats['checkpoints'].append(path)

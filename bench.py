@@ -102,7 +102,7 @@ class Workload:
         self.bound = float(((hi - lo) - (lo + hi) * 0.5).max())  # autolabel/model_utils.py:62-63
         self.n_classes = scene['n_classes']
 
-    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None, semantic_weight=1.0, overlap_comm=True):
+    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None, semantic_weight=1.0, overlap_comm=True, shard_optimizer=False):
         from autolabel_amd.engine import TrainEngine
         from autolabel_amd.parallel import broadcast_parameters
         from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
@@ -118,7 +118,8 @@ class Workload:
             t = self.train
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)
             pipe.mark_untrained_grid(t.world_to_camera(), (t.desc.fx, t.desc.fy, t.desc.cx, t.desc.cy), size=(t.w, t.h))
-        return TrainEngine(pipe, feature_loss=True, process_group=pg, semantic_weight=semantic_weight, overlap_comm=overlap_comm)
+        return TrainEngine(pipe, feature_loss=True, process_group=pg, semantic_weight=semantic_weight, overlap_comm=overlap_comm,
+                           shard_optimizer=shard_optimizer)
 
     def renderer(self, eng, march):
         """render callable for quality.heldout_metrics: 256 rows per ray along the whole ray (dense) / 128 rows inside occupied cells."""
@@ -631,21 +632,25 @@ def main():
         # driver's, and one exception must not cost the line.  dp_simple: ONE all-reduce of the gradient buffer after the backward
         # pass (the plainest use of the collective); dp_overlap: five buckets on a communication stream behind the scatter's level
         # groups; dp_graph: the overlapped step captured into a hipGraph, collectives included (launch-bound at small per-GPU
-        # batches otherwise).  The headline is the fastest leg that finished on EVERY rank.
+        # batches otherwise); dp_sharded: the overlapped step with the table's optimizer sharded over the ranks (reduce-scatter of the
+        # gradient buckets, Adam on 1 / world of the table, all-gather of the fp16 table).  The headline is the fastest leg that
+        # finished on EVERY rank.
         a2 = argparse.Namespace(**vars(args))
         a2.event_steps = 0
         dp_legs, best = {}, None
-        plan = [('dp_simple', False, False), ('dp_overlap', True, False)] + ([('dp_graph', True, True)] if not args.no_graph and backend == 'nccl' else [])   # (gloo collectives cannot be captured)
-        for name, overlap, graph in plan:
+        can_graph = not args.no_graph and backend == 'nccl'   # (gloo collectives cannot be captured)
+        plan = ([('dp_simple', False, False, False), ('dp_overlap', True, False, False)] + ([('dp_graph', True, True, False)] if can_graph else []) +
+                [('dp_sharded', True, False, True)] + ([('dp_sharded_graph', True, True, True)] if can_graph else []))
+        for name, overlap, graph, shard in plan:
             ok, leg = 1, None
+            info = {'overlap_comm': overlap, 'hip_graph': graph, 'shard_optimizer': shard}
             try:
-                e = wl.engine(SEEDS[0][0], world=world, pg=pg, overlap_comm=overlap)
+                e = wl.engine(SEEDS[0][0], world=world, pg=pg, overlap_comm=overlap, shard_optimizer=shard)
                 leg = timed_leg(wl, a2, e, B, dseed, mseed, frange, graph, world, sync)
-                dp_legs[name] = {'value': B * world * args.steps / leg[0], 'unit': 'rays/s', 'ms_per_step': 1000 * leg[0] / args.steps,
-                                 'overlap_comm': overlap, 'hip_graph': graph}
+                dp_legs[name] = dict(info, value=B * world * args.steps / leg[0], unit='rays/s', ms_per_step=1000 * leg[0] / args.steps)
             except Exception as ex:   # recorded, not fatal
                 ok = 0
-                dp_legs[name] = {'error': f'{type(ex).__name__}: {ex}'[:300], 'overlap_comm': overlap, 'hip_graph': graph}
+                dp_legs[name] = dict(info, error=f'{type(ex).__name__}: {ex}'[:300])
             try:
                 flag = torch.tensor([ok], device=device, dtype=torch.int32)
                 torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)

@@ -327,6 +327,17 @@ int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f
                   int32_t skip_grid /* 1: block 0 (the table) was updated by aln_encode_bwd_binned(adam); only its step counter advances */,
                   const int32_t* counts /*device, optional*/,
                   uint32_t* step_dev /*optional: += 1 once per call (the step counter of aln_raygen_train & co. under graph replay)*/, void* stream);
+/* The same step for a rank that owns only the slices [range_lo[k], range_hi[k]) of the table (n_ranges <= 8, ascending, disjoint,
+ * multiples of 4; the table must be parameter block 0 and n_grid a multiple of 4) plus the whole MLP block: the sharded optimizer
+ * of the data-parallel engine (no counterpart in the reference, which has no multi-GPU path; the arithmetic per parameter is
+ * aln_adam_step's).  m, v are COMPACT -- the owned slices back to back, then the n_total - n_grid MLP moments.  Gradients,
+ * master parameters and the fp16 table outside the owned slices are not touched (the gradient is cleared by
+ * aln_grad_pack_f16_clear on its way to the reduce-scatter; the table comes back by all-gather). */
+int aln_adam_step_ranges(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid, int64_t n_total,
+                         int32_t* state_i, float* state_f, float* consts, float lr, float beta1, float beta2, float eps, float wd_net,
+                         float growth, float backoff, int32_t growth_interval, int32_t n_blocks, const int64_t* block_end /*host*/,
+                         const int32_t* block_kind /*host*/, int32_t feature_loss, int32_t n_ranges, const int64_t* range_lo /*host*/,
+                         const int64_t* range_hi /*host*/, const int32_t* counts /*device, optional*/, uint32_t* step_dev, void* stream);
 int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
 int aln_cast_f32(const void* src_f16, float* dst, int64_t n, void* stream);
 /* fp16 wire format of the data-parallel exchange of the hash-grid gradient block (the reference has no multi-GPU path; the
@@ -334,6 +345,8 @@ int aln_cast_f32(const void* src_f16, float* dst, int64_t n, void* stream);
  * with *found_inf raised on a non-finite element.  Pointers 16-byte aligned. */
 int aln_grad_pack_f16(const float* grad, int64_t n, float mul, void* out_f16, void* stream);
 int aln_grad_unpack_f16(const void* in_f16, int64_t n, float* grad, int32_t* found_inf, void* stream);
+/* staging for a reduce-scatter: as aln_grad_pack_f16, plus out[n, n_pad) = 0 and grad[0, n) cleared behind the read */
+int aln_grad_pack_f16_clear(float* grad, int64_t n, int64_t n_pad, float mul, void* out_f16, void* stream);
 
 /* ---- feature-map file: autolabel/dataset.py:438-441 reads features.hdf through h5py, whose LZF filter (id 32000,
  * scripts/compute_feature_maps.py:85) wraps liblzf.  HOST pointers; returns the number of bytes produced or -1. */

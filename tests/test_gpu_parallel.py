@@ -94,6 +94,69 @@ def test_two_ranks_on_one_gpu_stay_in_lockstep_with_bucketed_allreduce():
         assert torch.equal(f1, f0), f'{(f1 != f0).sum().item()} parameters differ between overlapped and single-collective steps'
 
 
+def _shard_worker(rank, world, port, ret):
+    """TrainEngine(shard_optimizer=True) against the replicated optimizer: same batches, same seeds, 4 steps (one of them skipped
+    by a forced overflow), overlapped and single-stream exchange."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo')
+    torch.cuda.set_device(0)
+    from autolabel_amd import parallel, synthetic
+    from autolabel_amd.dataset import DeviceFrames
+    from autolabel_amd.engine import TrainEngine
+    from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
+    dev = torch.device('cuda', 0)
+    scene = synthetic.make_cube_scene(n_frames=8, size=32, seed=0, device=dev)
+    frames = DeviceFrames.from_scene(scene, dev)
+    layout = ModelLayout('hg+freq', 15, 128, 128, 64, scene['n_classes'], bound=3.0)
+    out = {}
+    for shard in (False, True):
+        for overlap in (True, False):
+            P = Params(layout, dev); P.init_(seed=0)
+            eng = TrainEngine(HipPipeline(layout, P), process_group=dist.group.WORLD, num_steps=32, upsample_steps=32, overlap_comm=overlap,
+                              shard_optimizer=shard)
+            lo, hi = parallel.frame_shard(8, rank, world)
+            batch = frames.alloc_batch(1024)
+            for i in range(4):
+                frames.next_train(batch, seed=parallel.rank_seed(5, rank), step=i, frame_range=(lo, hi))
+                if i == 2 and rank == 1:
+                    P.grad[5] = float('inf')   # a non-finite table gradient on ONE rank (in rank 0's shard): BOTH ranks must skip the step
+                eng.step(batch, seed=parallel.rank_seed(7, rank), step=i)
+            sd = eng.state_dict()              # (a collective under the sharded optimizer)
+            eng.sync_master()
+            torch.cuda.synchronize()
+            out[(shard, overlap)] = dict(flat=P.flat.cpu(), table=P.table16.cpu(), m=sd['m'].cpu(), v=sd['v'].cpu(), steps=int(eng.state_i[0].item()),
+                                         scale=float(eng.state_f[0].item()), grad_clean=bool((P.grad[:layout.n_total] == 0).all().item()),
+                                         m_elems=eng.m.numel(), n_total=layout.n_total, n_grid=layout.n_grid)
+            if shard and overlap:   # a checkpoint written by the sharded engine restores into a replicated one and vice versa
+                eng2 = TrainEngine(HipPipeline(layout, P), process_group=dist.group.WORLD, num_steps=32, upsample_steps=32, shard_optimizer=False)
+                eng2.load_state_dict(sd)
+                eng.load_state_dict(eng2.state_dict())
+                out['roundtrip'] = bool(torch.equal(eng2.m.cpu(), sd['m'].cpu()) and torch.equal(eng.state_dict()['v'].cpu(), sd['v'].cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = out
+
+
+def test_sharded_table_optimizer_matches_the_replicated_one_bit_for_bit():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_shard_worker, args=(world, port, ret), nprocs=world, join=True)
+        res = dict(ret)
+    ref = res[0][(False, True)]
+    assert ref['steps'] == 3 and ref['scale'] == 32768.0, 'the overflow injected on rank 1 must skip the step (and back the scale off) on both ranks'
+    for rank in range(world):
+        assert res[rank]['roundtrip']
+        for key in [(False, True), (False, False), (True, True), (True, False)]:
+            r = res[rank][key]
+            assert r['steps'] == 3 and r['grad_clean'], (rank, key, r['steps'], r['grad_clean'])
+            for name in ('flat', 'table', 'm', 'v'):
+                assert torch.equal(r[name], ref[name]), f'rank {rank} {key}: {name} differs in {(r[name] != ref[name]).sum().item()} elements'
+        sharded, full = res[rank][(True, True)], res[rank][(False, True)]
+        # the optimizer state of the table is halved
+        assert sharded['m_elems'] == full['n_grid'] // 2 + full['n_total'] - full['n_grid'] and full['m_elems'] == full['n_total']
+
+
 def _trainer_worker(rank, world, port, ret):
     """scripts/train.py's data-parallel wiring driven through SimpleTrainer: DeviceLoader over this rank's frame shard,
     rank seeds, broadcast of rank 0's initialisation, process_group handed to the trainer."""
@@ -107,30 +170,47 @@ def _trainer_worker(rank, world, port, ret):
     from autolabel_amd.models import ALNetwork
     from autolabel_amd.trainer import SimpleTrainer
     scene = synthetic.make_cube_scene(n_frames=8, size=32, seed=0, device='cuda')
-    torch.manual_seed(rank)   # different initialisations on purpose: the broadcast must make them equal
-    model = ALNetwork(encoding='hg+freq', num_layers=2, hidden_dim=128, geo_feat_dim=15, num_layers_color=2, hidden_dim_color=128,
-                      hidden_dim_semantic=64, semantic_classes=scene['n_classes'], bound=6.0, cuda_ray=False, density_scale=1)
-    model.reset_parameters(seed=rank)
     opt = Namespace(rand_pose=-1, color_space='srgb', feature_loss=False, rgb_weight=1.0, depth_weight=0.1, semantic_weight=1.0,
                     feature_weight=0.5, num_steps=32, upsample_steps=32)
     optimizer = lambda m: torch.optim.Adam([{'name': 'encoding', 'params': list(m.encoder.parameters())},
                                             {'name': 'net', 'params': m.network_parameters(), 'weight_decay': 1e-6}],
                                            lr=5e-3, betas=(0.9, 0.99), eps=1e-15)
-    tr = SimpleTrainer('ngp', opt, model, device='cuda:0', workspace=None, optimizer=optimizer,
-                       criterion=torch.nn.MSELoss(reduction='none'), fp16=True, ema_decay=None,
-                       lr_scheduler=lambda o: torch.optim.lr_scheduler.StepLR(o, gamma=0.5, step_size=10), metrics=[],
-                       use_checkpoint='scratch', local_rank=rank, world_size=world, process_group=dist.group.WORLD, mute=True)
-    parallel.broadcast_parameters(model._ensure_device().P.flat, dist.group.WORLD)
-    model._shadow_version = None
-    loader = DeviceLoader(DeviceFrames.from_scene(scene, 'cuda'), 1024, 1000, seed=parallel.rank_seed(0, rank),
-                          frame_range=parallel.frame_shard(8, rank, world))
-    tr.train_iterations(loader, 4)
-    torch.cuda.synchronize()
-    flat = model._P.flat.detach().cpu()
-    both = [None] * world
-    dist.all_gather_object(both, flat)
-    ret[rank] = dict(same=bool(torch.equal(both[0], both[1])), finite=bool(torch.isfinite(flat).all()), fused=tr.fused,
-                     steps=int(tr.engine.state_i[0].item()), world=tr.engine.world, loss=float(tr.engine.terms[4]))
+    out = {}
+    import tempfile
+    for shard, ema in [(False, None), (False, 0.95), (True, 0.95)]:
+        torch.manual_seed(rank)   # different initialisations on purpose: the broadcast must make them equal
+        model = ALNetwork(encoding='hg+freq', num_layers=2, hidden_dim=128, geo_feat_dim=15, num_layers_color=2, hidden_dim_color=128,
+                          hidden_dim_semantic=64, semantic_classes=scene['n_classes'], bound=6.0, cuda_ray=False, density_scale=1)
+        model.reset_parameters(seed=rank)
+        wsdir = tempfile.mkdtemp() if shard else None
+        tr = SimpleTrainer('ngp', opt, model, device='cuda:0', workspace=wsdir, optimizer=optimizer,
+                           criterion=torch.nn.MSELoss(reduction='none'), fp16=True, ema_decay=ema,
+                           lr_scheduler=lambda o: torch.optim.lr_scheduler.StepLR(o, gamma=0.5, step_size=10), metrics=[],
+                           use_checkpoint='scratch', local_rank=rank, world_size=world, process_group=dist.group.WORLD, mute=True,
+                           shard_optimizer=shard)
+        parallel.broadcast_parameters(model._ensure_device().P.flat, dist.group.WORLD)
+        model._shadow_version = None
+        loader = DeviceLoader(DeviceFrames.from_scene(scene, 'cuda'), 1024, 1000, seed=parallel.rank_seed(0, rank),
+                              frame_range=parallel.frame_shard(8, rank, world))
+        tr.train_iterations(loader, 4)
+        torch.cuda.synchronize()
+        flat = model._P.flat.detach().cpu()
+        both = [None] * world
+        dist.all_gather_object(both, flat)
+        r = dict(same=bool(torch.equal(both[0], both[1])), finite=bool(torch.isfinite(flat).all()), fused=tr.fused, flat=flat,
+                 steps=int(tr.engine.state_i[0].item()), world=tr.engine.world, loss=float(tr.engine.terms[4]),
+                 sharded=tr.engine.shard is not None, gather=tr.engine.shard_gather,
+                 ema=[p.detach().cpu() for p in tr.ema.shadow] if tr.ema is not None else None)
+        if shard:   # every rank calls, rank 0 writes; the file holds the full moments
+            tr.save_checkpoint('dp')
+            dist.barrier()
+            path = f'{tr.ckpt_path}/dp.pth'
+            r['ckpt_written_by_rank0_only'] = os.path.exists(path) == (rank == 0)
+            if rank == 0:
+                ck = torch.load(path, map_location='cpu', weights_only=False)
+                r['ckpt_m_elems'] = ck['engine']['m'].numel()
+        out[(shard, ema)] = r
+    ret[rank] = out
     dist.barrier()
     dist.destroy_process_group()
 
@@ -142,9 +222,16 @@ def test_simple_trainer_data_parallel_on_two_ranks():
         mp.spawn(_trainer_worker, args=(world, port, ret), nprocs=world, join=True)
         res = dict(ret)
     for rank in range(world):
-        r = res[rank]
-        assert r['fused'] and r['world'] == 2 and r['steps'] == 4, r
-        assert r['same'] and r['finite'], 'replicas must stay bit-identical after the averaged-gradient steps'
+        for key, r in res[rank].items():
+            assert r['fused'] and r['world'] == 2 and r['steps'] == 4, (key, r['fused'], r['world'], r['steps'])
+            assert r['same'] and r['finite'], 'replicas must stay bit-identical after the averaged-gradient steps'
+        rep, shd = res[rank][(False, 0.95)], res[rank][(True, 0.95)]
+        # the sharded optimizer under the trainer (EMA on: the fp32 masters are gathered every step) moves the same numbers
+        assert shd['sharded'] and shd['gather'] == 'master' and not rep['sharded']
+        assert torch.equal(rep['flat'], shd['flat'])
+        assert all(torch.equal(a, b) for a, b in zip(rep['ema'], shd['ema']))
+        assert shd['ckpt_written_by_rank0_only']
+    assert res[0][(True, 0.95)]['ckpt_m_elems'] == res[0][(True, 0.95)]['flat'].numel()
 
 
 def _equiv_worker(rank, world, port, ret):
