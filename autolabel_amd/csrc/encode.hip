@@ -395,6 +395,7 @@ static inline int bin_slice_log2(uint32_t size) {
 struct BinParams {
   EncParams p;
   const h16* d_enc;
+  int32_t* found_inf; // raised by phase 1 when a run is non-finite (before phase 2 can step anything)
   uint2* pool;        // [n_levels][ntiles][BIN_CHUNK] records
   uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  DESC_START | DESC_COUNT | DESC_SHIFT
   int ntiles;
@@ -500,10 +501,15 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     // their bits instead of flushing at the fp16 denormal step, and a run sum beyond the fp16 range (64 samples of one cell at
     // the largest loss scales) is scaled down instead of overflowing -- a record is non-finite only if d_enc was, and then
     // the producer of d_enc has raised found_inf before this kernel started (what lets phase 2 apply the optimizer itself).
-    float vmax = 0.f;
+    // (the largest magnitude as a bit pattern: non-negative floats order like their patterns, and a NaN -- which fmaxf would
+    //  silently drop -- sorts above infinity)
+    uint32_t umax = 0u;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
-    const bool emit = head && vmax > 0.f;     // NaN compares false: a NaN run is dropped here but d_enc's own watch has fired
+    for (int k = 0; k < 16; ++k) umax = max(umax, __float_as_uint(v[k]) & 0x7fffffffu);
+    // A non-finite run raises the flag HERE, in phase 1: every block of phase 2 then reads a final found_inf before it applies the
+    // optimizer to its slice (no partly stepped table), whoever produced d_enc.
+    if (head && umax >= 0x7f800000u && b.found_inf) *b.found_inf = 1;
+    const bool emit = head && umax != 0u && umax <= 0x7f800000u;     // (a NaN run is dropped; the step is skipped anyway)
     // Ranks within the slices.  The two x-neighbour corners of a cell (c, c + 1) almost always fall into the same slice (their
     // indices differ in the lowest bits: +1 in a dense level, ^1 for even x in a hashed one), so a PAIR takes one returning
     // atomic (+2) and, below, one 16-byte store.  (Measured: 325 -> 321 us only.  Stubbing out the atomics, the sorted stores or
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
       // the tile's largest magnitude: folded over the wave with shuffles, ONE LDS atomic per wave.  (atomicMax from every lane is
       // rewritten by hipcc's atomic optimizer into a scalar loop over the active lanes -- ~6 scalar instructions per lane, 370 per
       // wave and level: half of this kernel's instruction stream, profiles/r03_pmc_sq_summary.json)
-      uint32_t wm = emit ? __float_as_uint(vmax) : 0u;   // non-negative floats order like their bit patterns
+      uint32_t wm = emit ? umax : 0u;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, o));
       if (lane == 0 && wm) atomicMax(&vmax_s[par], wm);
@@ -756,6 +762,9 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
                                      int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* stream) {
   BinParams b;
   if (int rc = fill_params(b.p, e, nullptr, rays_o, rays_d, z, xyz, rows, stride1)) return rc;
+  // (with `adam` the caller's aln_adam_step(skip_grid = 1) advances the table's step counter: an empty launch must not pass for a step)
+  ALN_REQUIRE(!adam || (rows > 0 && e->use_grid && level_lo < level_hi), "encode_bwd_binned: the fused optimizer step needs rows and levels; "
+              "run aln_adam_step without skip_grid for an empty batch");
   if (rows == 0 || !e->use_grid) return 0;
   ALN_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= (int)e->grid.n_levels, "encode_bwd_binned: level range [%d, %d)",
               level_lo, level_hi);
@@ -772,7 +781,7 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
   if (level_lo == level_hi) return 0;
   const int ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
   b.p.level_lo = level_lo; b.p.level_hi = level_hi;
-  b.d_enc = (const h16*)d_enc; b.ntiles = ntiles; b.rows1 = rows_pass1; b.stride2 = stride2 > 0 ? stride2 : 1;
+  b.d_enc = (const h16*)d_enc; b.found_inf = found_inf; b.ntiles = ntiles; b.rows1 = rows_pass1; b.stride2 = stride2 > 0 ? stride2 : 1;
   b.pool = (uint2*)ws; b.perm = perm;
   b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * BIN_CHUNK * sizeof(uint2));
   AccParams a;

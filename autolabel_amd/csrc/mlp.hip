@@ -1264,9 +1264,10 @@ static int launch_bwd_recomp_occ(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int 
   const bool gt_src = ds.mode == SRC_DLOGITS || ds.mode == SRC_DSEMF_OUT;
   size_t lds = (((halves + 7) & ~(size_t)7) + TR * (size_t)(PX0 + 2 * PH + PO)) * 2 + (gt_src ? 2 * GT_RAYS * OB * 32 * sizeof(float) : 0);   // + the staged per-ray gradient rows
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_bwd_recomp: LDS %zu B exceeds 160 KiB", lds);
-  int tiles = (rows + TR - 1) / TR;
-  const int gmax = OCC2 ? 512 : 256;
-  int g = tiles < gmax ? tiles : gmax;
+  // the slab count comes from the ONE helper aln_mlp_dw_reduce_all uses as well; it knows 128-row tiles and this file's OCC2 rule
+  static_assert(RPW == 1, "bwd_recomp_blocks() assumes 128-row tiles: teach it RPW before instantiating RPW > 1");
+  const int g = bwd_recomp_blocks(m, rows);
+  ALN_REQUIRE(g == min((rows + TR - 1) / TR, OCC2 ? 512 : 256), "mlp_bwd_recomp: slab count %d disagrees with the launch shape (OCC2 = %d)", g, (int)OCC2);
   const MlpLayers LL = mlp_layers(IN, HID, OUT, NHID);
   const int n_w = (int)(LL.w_off[LL.n - 1] + (size_t)LL.in_[LL.n - 1] * LL.out_[LL.n - 1]);
   ALN_REQUIRE(!dW || (m->dw_ws && (size_t)m->dw_ws_bytes >= (size_t)g * n_w * sizeof(float)),

@@ -160,6 +160,28 @@ class Workload:
         return full.w * full.h * n / (time.time() - t1) / 1e6, frame
 
 
+def render_roofline(eng, frame, what):
+    """HBM roofline of a render pass's dominant kernel pair, the level-phased hash-grid gather + row assembly, from HIP events
+    around the launches of one frame.  Algorithmic bytes per sample row (SURVEY 8d Bytes_fwd): 16 levels x 8 fp16x2 corner reads
+    + the position in (12 B) + the encoded row out (enc_pad x 2 B)."""
+    import torch
+    eng.pipe.kernel_events = rev = []
+    frame(0)
+    torch.cuda.synchronize()
+    eng.pipe.kernel_events = None
+    gd = [(e[0].elapsed_time(e[1]) * 1e-3, t) for e, n, t in rev if n == 'aln_encode_fwd_phased']
+    if not gd:
+        return None
+    rows = sum(t[1] for _, t in gd) / len(gd)
+    avg = sum(d for d, _ in gd) / len(gd)
+    nl, pad = eng.L.enc.grid.n_levels, eng.L.enc.enc_pad
+    per_row = nl * 8 * 4 + 12 + pad * 2
+    return {'kernel': 'k_encode_grid_phased + k_encode_assemble (hash-grid gather, %s)' % what,
+            'bound': 'hbm (limiter: L1 request rate of the 8-corner gathers, DESIGN.md 4.2)',
+            'achieved': per_row * rows / avg / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': per_row * rows / avg / 1e9 / 8000.0,
+            'avg_launch_us': avg * 1e6, 'launches': len(gd), 'rows_per_launch': rows, 'algorithmic_bytes_per_row': per_row}
+
+
 def train_schedule(eng, step, done, total):
     """Continue to `total` optimizer steps under SCHEDULE (the learning rate is a device word: a captured step follows it)."""
     for frac, lr in SCHEDULE:
@@ -218,7 +240,8 @@ def scatter_roofline(eng, events, rows_per_step, n_event_steps):
     alg = alg_scatter + alg_adam
     records = eng.pipe.binned_record_count(rows_per_step, ws=eng.ws)   # records of the last launch (same state as the events)
     rec_bytes = 2 * 8 * records if records else None                  # written once by phase 1, read once by phase 2
-    return {'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair' + ("; the table's Adam step inside phase 2)" if fused else ')'), 'bound': 'hbm',
+    return {'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair' + ("; the table's Adam step inside phase 2)" if fused else ')'),
+            'bound': 'hbm (limiter: lds+valu in phase 1, record rate in phase 2)',
             'achieved': alg / avg_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / avg_s / 1e9 / 8000.0, 'traffic': None,
             'avg_launch_us': avg_s * 1e6, 'launches': len(durs), 'rows_per_launch': rows_per_step, 'algorithmic_bytes_per_launch': alg,
             'algorithmic_bytes_scatter': alg_scatter, 'algorithmic_bytes_optimizer': alg_adam, 'optimizer_fused_into_phase2': fused,
@@ -267,8 +290,9 @@ def mlp_roofline(eng, events, n_event_steps, live_rows):
         t_mlp += e[0].elapsed_time(e[1]) * 1e-3
     if t_mlp <= 0:
         return None
-    return {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + k_mlp_bwd_recomp8 + k_dw_reduce_all (all heads)' + (' + k_wide_nt / k_wide_tn' if L.sem_wide else ''),
-            'bound': 'mfma', 'achieved': flops / t_mlp / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': flops / t_mlp / 1e12 / 2500.0,
+    return {'kernels': 'k_mlp_fwd + k_sem_fwd_fused + ' + ('k_mlp_bwd_recomp8 + k_wide_nt / k_wide_tn' if L.sem_wide else 'k_mlp_bwd128 + k_sem_bwd_pair') +
+                       ' + k_dw_reduce_all (all heads)',
+            'bound': 'mfma (limiter: one wave per SIMD -- LDS operand reads and the pack / mask VALU work between MFMA groups do not overlap them)', 'achieved': flops / t_mlp / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': flops / t_mlp / 1e12 / 2500.0,
             'us_per_step': t_mlp * 1e6 / n_event_steps, 'algorithmic_gflop_per_step': flops / 1e9 / n_event_steps, 'live_color_rows': live_rows}
 
 
@@ -365,12 +389,15 @@ def marching_leg(wl, args, B):
         q = heldout_metrics(wl.renderer(eng, True), wl.test, wl.n_classes)
         q.update(steps=done[0], adam_steps_applied=int(eng.state_i[0].item()))
         quality = quality_runs(wl, args, q, march=True)
-    render_mrays = wl.render_throughput(eng, True)[0] if args.render_frames > 0 else None
+    render_mrays, render_roof = None, None
+    if args.render_frames > 0:
+        render_mrays, frame = wl.render_throughput(eng, True)
+        render_roof = render_roofline(eng, frame, 'render through the occupancy grid: %d rows per ray inside occupied cells' % max(args.march_samples, 128))
     return {'value': B * args.steps / dt, 'unit': 'rays/s', 'ms_per_step': 1000 * dt / args.steps, 'steps': args.steps, 'warmup': args.warmup,
             'samples_per_ray': args.march_samples,
             'sample_rows_per_step': rows, 'grid': '128^3, one level', 'max_steps': 1024, 'density_thresh': args.march_thresh,
             'render_Mrays_per_s': render_mrays, 'render_rows_per_ray': max(args.march_samples, 128), 'occupied_fraction': occ.occupancy(),
-            'roofline': roof, 'roofline_mlp': roof_mlp, 'quality': quality,
+            'roofline': roof, 'roofline_mlp': roof_mlp, 'roofline_render': render_roof, 'quality': quality,
             'note': 'cuda_ray=True path (dead in the reference: model_utils.py:72); timed over %d steps after %d warm-up steps like the dense '
                     'leg, grid refresh (every 16th step, its own captured graph) included; every ray gets %d rows, rows outside occupied cells '
                     'are zero-length padding (the record / byte counts of `roofline` are what the scatter actually moved)'
@@ -680,20 +707,7 @@ def main():
     render_dense, render_roof = None, None
     if rank == 0 and args.render_frames > 0:
         render_dense, frame = wl.render_throughput(eng, False)
-        eng.pipe.kernel_events = rev = []
-        frame(0)
-        torch.cuda.synchronize()
-        eng.pipe.kernel_events = None
-        gd = [(e[0].elapsed_time(e[1]) * 1e-3, t) for e, n, t in rev if n == 'aln_encode_fwd_phased']
-        if gd:
-            rows = sum(t[1] for _, t in gd) / len(gd)
-            avg = sum(d for d, _ in gd) / len(gd)
-            nl, pad = eng.L.enc.grid.n_levels, eng.L.enc.enc_pad
-            per_row = nl * 8 * 4 + 12 + pad * 2     # 16 x 8 fp16x2 corner reads + xyz in + the encoded row out (SURVEY 8d Bytes_fwd)
-            render_roof = {'kernel': 'k_encode_grid_phased + k_encode_assemble (hash-grid gather, dense render)', 'bound': 'hbm',
-                           'achieved': per_row * rows / avg / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-                           'frac': per_row * rows / avg / 1e9 / 8000.0, 'avg_launch_us': avg * 1e6, 'launches': len(gd),
-                           'rows_per_launch': rows, 'algorithmic_bytes_per_row': per_row}
+        render_roof = render_roofline(eng, frame, 'dense render: 512 rows per ray')
 
     # quality of the trained state: continue to --quality-steps optimizer steps, held-out metrics, then the other seed sets
     quality = None
@@ -713,6 +727,10 @@ def main():
             'ms_per_step': 1000 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
+            # the timed steps start from a fresh initialisation: the density field has not sharpened yet, so most sample rows are
+            # still live for the colour head (a trained field prunes them: the colour head's work shrinks, nothing else changes)
+            'timed_state': 'untrained: steps %d..%d after initialisation' % (args.warmup, args.warmup + args.steps),
+            'live_row_fraction': live_rows / float(B * (eng.S1 + eng.S2)),
             'config': {'workload': "S1 synthetic room standing in for the 'bench' scene: %d frames 640x480 trained at factor 2, " % args.frames +
                                    'DINO-like 64-d features, hg+freq L=16 T=2^19, 128+128 samples/ray',
                        'rays_per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'feature_dim': args.feature_dim,

@@ -25,6 +25,8 @@ if sem_step:
 rows = 1 << 20
 L = ModelLayout('hg+freq', 15, 128, 128, 64, 7, bound=6.0)
 P = Params(L, 'cuda'); P.init_(0)
+for _d in P.descs.values():   # stand-alone launches: fold the slabs into the gradient inside the call (HipPipeline.backward defers it)
+    _d.defer_dw_reduce = 0
 m = L.nets[head]
 x = torch.randn(rows, m.in_pad, device='cuda').half()
 d_out = (torch.randn(rows, m.out_pad, device='cuda') * 0.01).half()

@@ -9,6 +9,8 @@ N, S = 2048, 128
 rows = N * S
 L = ModelLayout('hg+freq', 15, 128, 128, 64, 7, bound=6.0)
 P = Params(L, 'cuda'); P.init_(0)
+for _d in P.descs.values():   # stand-alone launches: fold the slabs into the gradient inside the call (HipPipeline.backward defers it)
+    _d.defer_dw_reduce = 0
 g = torch.Generator().manual_seed(0)
 ro = ((torch.rand(N, 3, generator=g) - 0.5) * 4).cuda()
 rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()

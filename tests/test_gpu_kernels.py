@@ -372,6 +372,44 @@ def test_binned_encode_backward_scales_run_sums_beyond_fp16_down(H):
     assert flag.item() == 1
 
 
+def test_fused_table_optimizer_steps_nothing_when_phase_1_meets_a_non_finite_gradient(H):
+    """aln_encode_bwd_binned(adam): a non-finite d_enc that NO producer flagged (found_inf = 0 at launch) must not leave a partly
+    stepped table -- phase 1 raises the flag before any block of phase 2 reads it, so every slice skips; and an empty launch with
+    an optimizer descriptor is an error, not a silently missing step."""
+    bound = 1.0
+    e = H.make_enc_desc('hg+freq', bound)
+    N, S = 64, 32
+    rows = N * S
+    g = torch.Generator().manual_seed(9)
+    ro = ((torch.rand(N, 3, generator=g) - 0.5) * 0.5).cuda()
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()
+    z = (torch.rand(N, S, generator=g).sort(dim=1)[0] * 1.5).reshape(-1).cuda().contiguous()
+    n = int(e.grid.n_entries) * 2
+    ws = torch.empty(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), dtype=torch.uint8, device='cuda')
+    for poison in (float('inf'), float('nan'), None):
+        d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+        d_enc[:, 12:44] = (torch.randn(rows, 32, generator=g) * 0.05).half().cuda()
+        if poison is not None:
+            d_enc[rows // 2 + 3, 40] = poison          # one value of the finest level, mid-batch
+        p = (torch.rand(n, generator=g) * 1e-2).cuda()
+        m, v, t16 = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), p.half()
+        p0, t0 = p.clone(), t16.clone()
+        si = torch.zeros(16, dtype=torch.int32, device='cuda')
+        sf = torch.tensor([1024.0, 5e-3, 0, 0], device='cuda')
+        ad = H.AlnAdamFuse(p.data_ptr(), m.data_ptr(), v.data_ptr(), t16.data_ptr(), si.data_ptr(), sf.data_ptr(), 5e-3, 0.9, 0.99, 1e-15)
+        H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows, S, S, None, H.ptr(d_enc),
+               None, H.ptr(ws), 0, int(e.grid.n_levels), H.ptr(si[2:3]), C.byref(ad), H.stream())
+        torch.cuda.synchronize()
+        if poison is None:
+            assert si[2].item() == 0 and not torch.equal(p, p0) and (m != 0).any()
+        else:
+            assert si[2].item() == 1, f'{poison}: the flag must be raised'
+            assert torch.equal(p, p0) and torch.equal(t16, t0) and not m.any() and not v.any(), f'{poison}: part of the table was stepped'
+    with pytest.raises(RuntimeError):
+        H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, rows, S, S, None, H.ptr(d_enc),
+               None, H.ptr(ws), 3, 3, H.ptr(si[2:3]), C.byref(ad), H.stream())
+
+
 def test_binned_encode_backward_two_passes_and_level_groups(H):
     """Coarse + fine pass in ONE launch (rows_pass1 / two strides) and the data-parallel level groups give the gradient fp32
     autograd computes for the two passes; a non-finite upstream gradient raises found_inf."""
