@@ -3,7 +3,7 @@
 import argparse, os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument('--lib', default=None); ap.add_argument('--reps', type=int, default=20)
+ap = argparse.ArgumentParser(); ap.add_argument('--lib', default=None); ap.add_argument('--reps', type=int, default=20); ap.add_argument('--dots', action='store_true')
 a = ap.parse_args()
 import torch
 from autolabel_amd import hip as H
@@ -22,11 +22,11 @@ w_row = torch.rand(rows, device='cuda') * 0.05
 g_sem, g_feat = torch.randn(N, Ccls, device='cuda') * 0.1, torch.randn(N, D, device='cuda') * 0.1
 d_oin = torch.empty(rows, L.nets['semo'].in_pad, device='cuda', dtype=torch.float16)
 d_fin = torch.empty(rows, 16, device='cuda', dtype=torch.float16)
-grad = torch.zeros_like(P.grad); flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+dots = torch.zeros(rows, device='cuda'); grad = torch.zeros_like(P.grad); flag = torch.zeros(1, dtype=torch.int32, device='cuda')
 gpf, gpo = (C.c_void_p(grad.data_ptr() + 4 * L.offsets[k]) for k in ('semf', 'semo'))
 def run():
     H.call('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem),
-           H.ptr(g_feat), N, S1, S2, Ccls, rows, D, G, H.ptr(d_oin), H.ptr(d_fin), gpf, gpo, 1, H.ptr(flag), H.stream())
+           H.ptr(g_feat), N, S1, S2, Ccls, rows, D, G, H.ptr(d_oin), H.ptr(d_fin), gpf, gpo, 1, H.ptr(dots) if a.dots else None, H.ptr(flag), H.stream())
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -21,7 +21,7 @@ for fold in (0, 1):
     d_oin = torch.zeros(rows, 80, dtype=torch.float16, device='cuda'); d_fin = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
     dWf, dWo = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
     H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf), H.ptr(dWo), fold, H.ptr(flag), H.stream())
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf), H.ptr(dWo), fold, None, H.ptr(flag), H.stream())
     torch.cuda.synchronize()
     res[fold] = (dWf.cpu(), dWo.cpu(), d_fin.cpu(), d_oin.cpu())
 a, b = res[0], res[1]

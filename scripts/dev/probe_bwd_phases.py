@@ -46,7 +46,7 @@ if sem_step:
 def run():
     if sem_step:
         H.call('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem),
-               H.ptr(g_feat), N, S1, S2, Ccls, rows, D, G, H.ptr(d_oin), H.ptr(d_fin), gpf, gpo, 1, H.ptr(flag), H.stream())
+               H.ptr(g_feat), N, S1, S2, Ccls, rows, D, G, H.ptr(d_oin), H.ptr(d_fin), gpf, gpo, 1, None, H.ptr(flag), H.stream())
         return
     H.call('aln_mlp_bwd', C.byref(P.descs[head]), H.ptr(x), None, None, H.ptr(d_out), rows, None, None, None, H.ptr(d_in), gp,
            H.ptr(flag), H.stream())
