@@ -471,10 +471,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HID == 128
 // same 32-row tile: f goes through a wave-private LDS tile, from which it is (a) written out as whole 128-byte rows and
 // (b) read back -- ReLU applied -- in the natural k-order of semantic_out's first layer, so both heads keep their ordinary
 // fragment images and f is never re-read from HBM (the two-launch path reads it back: 128 B/sample, 24 % of a render pass).
-template <int KSG>   // k-steps of the geo_feat input of both heads (in_pad of semantic_features / 16 = 1)
+// sum over the 32 lanes of the lane's half of the wave (every lane of the half gets the total): four DPP steps inside the rows of
+// 16, one crossbar step between them
+__device__ inline float half_sum32(float v) {
+#define ALN_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  ALN_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
+  ALN_DPP_ADD(0x4E);    // quad_perm [2, 3, 0, 1]
+  ALN_DPP_ADD(0x141);   // row_half_mirror
+  ALN_DPP_ADD(0x140);   // row_mirror
+#undef ALN_DPP_ADD
+  return v + __shfl_xor(v, 16);
+}
+// SUMS (the training step): neither f nor the logits leave the CU.  A tile's 32 rows belong to one ray (both sample counts are
+// multiples of 32), and all the step needs of them is the ray's weighted sums sum_s w_s f_s, sum_s w_s logits_s (models.py:
+// 195-203): the wave leaves the partial sums of its tile -- [1 x 32] x [32 x 64] through the matrix pipe, the weights as row 0
+// (fp16 head) and row 1 (fp16 remainder of the fp32 weight) of the A operand, the tile read with the transpose load; the logits,
+// whose rows are lanes, through a lane butterfly -- in tile_sums[tile][96] (64 features, <= 32 logits), 384 B per tile instead of
+// 5 KB of rows; aln_composite_out adds a ray's tiles
+// in a fixed order.  The backward recomputes f and the logits anyway (k_sem_bwd_pair, which also hands <f, g_feat> + <logits,
+// g_sem> per row to the compositing backward).
+template <int KSG, bool SUMS>   // KSG: k-steps of the geo_feat input of both heads (in_pad of semantic_features / 16 = 1)
 __global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ wf_f, size_t halves_f, const h16* __restrict__ wf_o,
                                                       size_t halves_o, const h16* __restrict__ sigma_out, int rows, int G,
-                                                      int out_pad_o, h16* __restrict__ feat, h16* __restrict__ logits) {
+                                                      int out_pad_o, h16* __restrict__ feat, h16* __restrict__ logits,
+                                                      const float* __restrict__ w_row, float* __restrict__ tile_sums) {
   constexpr int HID = 64, D = 64, NB = 2, KS = 4, PT = D + 8;   // PT: pitch of the f tile (row-per-lane 16-byte reads conflict-free)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   h16* wl_f = (h16*)smem;
@@ -500,6 +520,8 @@ __global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ w
   };
   int tile = blockIdx.x * 4 + wave;
   if (tile < ntiles) load_x(tile);
+  const PlainV<lds_h16*> ftv{ftile, PT};
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (; tile < ntiles; tile += tstride) {
     const int row0 = tile * 32, row = row0 + c;
     const bool valid = row < rows;
@@ -509,6 +531,18 @@ __global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ w
     const h16x8* fo_ = (const h16x8*)wl_o + fo;
     f32x16 acc[NB];
     h16x8 p[KS], geo[KSG];
+    h16x8 aw[2];   // SUMS: A operand of the weighted row sum, k-step ks = rows 16 ks .. 16 ks + 15: row 0 = fp16(w), row 1 = fp16(w - row 0)
+    float wl = 0.f;   // SUMS: the weight of this lane's row
+    if constexpr (SUMS) {   // (rows is a multiple of 32 here: whole tiles)
+      wl = w_row[row];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float4 w0 = *(const float4*)(w_row + row0 + 16 * ks + 8 * hf), w1 = *(const float4*)(w_row + row0 + 16 * ks + 8 * hf + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const h16 hi = (h16)wv[j]; aw[ks][j] = c == 0 ? hi : (c == 1 ? (h16)(wv[j] - (float)hi) : (h16)0.f); }
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < KSG; ++ks) geo[ks] = xb[ks];
     chain_layer<NB, KSG>(acc, [&](int m, int ks) { return ff[((size_t)m * KSG + ks) * 64 + lane]; }, [&](int ks) { return geo[ks]; });
@@ -526,12 +560,22 @@ __global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ w
             (u32x2){cvt_pk(acc[m][4 * q], acc[m][4 * q + 1]), cvt_pk(acc[m][4 * q + 2], acc[m][4 * q + 3])};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (SUMS) {   // (a') sum_s w_s f_s of the tile: lanes 0..31 hold rows 0 (head) and 1 (remainder) of the product
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x16 sa = zero16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) sa = mfma16(aw[ks], tr_frag(ftv, 32 * nb, ks, lane), sa);
+        if (hf == 0) tile_sums[(size_t)tile * 96 + 32 * nb + c] = sa[0] + sa[1];
+      }
+    } else {
     // (a) the 32 rows of f leave as contiguous 16-byte pieces
     const int rows_here = min(32, rows - row0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pc = lane + 64 * i, r = pc >> 3, ch = pc & 7;
       if (r < rows_here) *(u32x4*)(feat + (size_t)(row0 + r) * D + 8 * ch) = *(const LDS_VEC(u32x4)*)(ftile + r * PT + 8 * ch);
+    }
     }
     // (b) semantic_out layer 0: relu(f) in natural k-order from the tile, then the geo_feat chunk
     chain_layer<NB, KS0O>(acc, [&](int m, int ks) { return fo_[((size_t)m * KS0O + ks) * 64 + lane]; },
@@ -550,7 +594,18 @@ __global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ w
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) o = mfma16(fo_[(flo + (size_t)ob * KS + ks) * 64 + lane], p[ks], o);
-      if (valid) {
+      if constexpr (SUMS) {   // (OBO == 1) sum_s w_s logits_s: the rows are the lanes here -- a butterfly over each half's 32 lanes, per class
+        const int nreg = out_pad_o / 2;    // classes (r & 3) + 8 (r >> 2) + 4 half, r < out_pad / 2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (4 * q < nreg) {
+            float4 t;
+            t.x = half_sum32(wl * (float)(h16)o[4 * q]); t.y = half_sum32(wl * (float)(h16)o[4 * q + 1]);
+            t.z = half_sum32(wl * (float)(h16)o[4 * q + 2]); t.w = half_sum32(wl * (float)(h16)o[4 * q + 3]);
+            if (c == 0) *(float4*)(tile_sums + (size_t)tile * 96 + 64 + 8 * q + 4 * hf) = t;
+          }
+        }
+      } else if (valid) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           int f = 32 * ob + 8 * q + 4 * hf;
@@ -732,19 +787,6 @@ __global__ __launch_bounds__(256) void k_dw_gemm(const h16* __restrict__ dA, int
 // hardware transpose read ds_read_b64_tr_b16 (16 lanes fetch a 4-sample x 16-feature block; lane i receives feature i of 4
 // consecutive samples -- semantics verified by scripts/dev/probe_trread.hip).  dW accumulators live in registers for the whole
 // kernel (each dW wave owns a fixed subset of 32x32 C-blocks) and leave once at the end.
-template <class TV>
-__device__ inline h16x8 tr_frag(TV t, int col0, int ks, int lane) {
-  // operand fragment for mfma 32x32x16: lane (i = lane&31, hf = lane>>5) gets tile[16ks + 8hf + 0..7][col0 + i].
-  // (the builtin lets the compiler count lgkmcnt itself, so several fragment reads stay in flight)
-  const int hf = lane >> 5;
-  const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
-  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row, col));
-  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row + 4, col));
-  union { struct { s16x4v l, h; } s; h16x8 v; } u;
-  u.s.l = lo; u.s.h = hi;
-  return u.v;
-}
 // dW accumulate over the block tile: wave owns C-blocks blk = wave + 4b (blk -> (ob, ib) = (blk / NIB, blk % NIB)).
 // When 4 % NIB == 0 the input block ib is the same for all owned blocks, so its fragment is fetched once per k-step.
 template <int NBLK, int NOB, int NIB, int TROWS = 128, class TVA, class TVB>
@@ -1371,12 +1413,12 @@ extern "C" int aln_debug_read_pair(long long* host_out, int reset) {
 #define SP_STAMP(i)
 #define SP_FLUSH
 #endif
-template <int CP>   // padded class count: semantic_out's out_pad (16 or 32)
+template <int CP, bool DOTS>   // CP: padded class count, semantic_out's out_pad (16 or 32); DOTS: also <logits, g_sem> + <f, g_feat> per row
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_sem_bwd_pair(const h16* __restrict__ wf_f, const h16* __restrict__ wb_f, const h16* __restrict__ wf_o, const h16* __restrict__ wb_o,
                     const h16* __restrict__ sigma_out, const float* __restrict__ w_row, RowSrc rs, const float* __restrict__ g_sem, int C,
                     const float* __restrict__ g_feat, int G, int rows, h16* __restrict__ d_geo, float* __restrict__ ws_f,
-                    float* __restrict__ ws_o, int* __restrict__ found_inf) {
+                    float* __restrict__ ws_o, float* __restrict__ dots_row, int* __restrict__ found_inf) {
   constexpr int D = 64, KS = 4, KSO = CP / 16, PH = hid_pitch(64), PFG = 80 + 8, PDL = 32, TR = 64;
   constexpr int SET = TR * (PFG + 7 * PH + PDL + 16);   // halves per tile set
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1407,7 +1449,7 @@ void k_sem_bwd_pair(const h16* __restrict__ wf_f, const h16* __restrict__ wb_f, 
     // =================================================================================================== the chain
     const h16x8* const ff = (const h16x8*)wf_f;
     const h16x8* const of = (const h16x8*)wf_o; const h16x8* const ob = (const h16x8*)wb_o;
-    h16x8 Wf0[2], Wf1[2][KS], Wf2[2][KS], Vf0[2][5], V1T[2][KSO], V0T[3][KS];
+    h16x8 Wf0[2], Wf1[2][KS], Wf2[2][KS], Vf0[2][5], V1T[2][KSO], V0T[3][KS], Vf1[DOTS ? KS : 1];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       Wf0[m] = ff[(size_t)m * 64 + lane];                                                    // semantic_features: layer 0 (natural k)
@@ -1425,6 +1467,10 @@ void k_sem_bwd_pair(const h16* __restrict__ wf_f, const h16* __restrict__ wb_f, 
     for (int m = 0; m < 3; ++m)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) V0T[m][ks] = ob[(size_t)(2 * KSO + m * KS + ks) * 64 + lane];   // semantic_out: V0^T (80 inputs, chained o)
+    if constexpr (DOTS) {   // semantic_out's last layer, forward: the logits are recomputed for their dot product with g_sem
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) Vf1[ks] = of[(size_t)(2 * 5 + ks) * 64 + lane];
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // the loads have landed before the loop is entered (mlp_bwd128.hip: hipcc's wait-count pass)
     const h16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int srow = 32 * wave + c;
@@ -1464,18 +1510,21 @@ void k_sem_bwd_pair(const h16* __restrict__ wf_f, const h16* __restrict__ wb_f, 
         f32x16 acc[2];
         h16x8 p1[4], p2[4], pd[4];
         const int ray = row_ray(rs, min(row, last_row));
-        float gs[KSO][8];
+        float gs[KSO][8], gsc[DOTS ? CP / 2 : 1];
         f32x4 gf[2][4];
 #pragma unroll
         for (int ks = 0; ks < KSO; ++ks)
 #pragma unroll
           for (int j = 0; j < 8; ++j) SP_LOAD32(gs[ks][j], g_sem + (size_t)ray * C + min(16 * ks + 8 * hf + j, C - 1));
+        if constexpr (DOTS) {   // g_sem once more, in the accumulator's row order: class (r & 3) + 8 (r >> 2) + 4 half of register r
+#pragma unroll
+          for (int r = 0; r < CP / 2; ++r) SP_LOAD32(gsc[r], g_sem + (size_t)ray * C + min((r & 3) + 8 * (r >> 2) + 4 * hf, C - 1));
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int q = 0; q < 4; ++q) SP_LOAD128(gf[m][q], g_feat + (size_t)ray * D + 32 * m + 8 * q + 4 * hf);
-        if constexpr (KSO == 1) asm volatile("s_waitcnt vmcnt(16)" : "+a"(lon), "+a"(hin), "+a"(wrn));
-        else asm volatile("s_waitcnt vmcnt(24)" : "+a"(lon), "+a"(hin), "+a"(wrn));
+        asm volatile("s_waitcnt vmcnt(%3)" : "+a"(lon), "+a"(hin), "+a"(wrn) : "i"(8 * KSO + 8 + (DOTS ? CP / 2 : 0)));   // the loads above are younger
         const h16x8 x0 = valid ? geo_of(__builtin_bit_cast(h16x8, lon), __builtin_bit_cast(h16x8, hin)) : z8;
         const float wr = valid ? wrn : 0.f;   // (zero weight: the row contributes nothing to any gradient)
         *(LDS_VEC(h16x8)*)T.FG.at(srow, D + 8 * hf) = x0;
@@ -1493,6 +1542,28 @@ void k_sem_bwd_pair(const h16* __restrict__ wf_f, const h16* __restrict__ wb_f, 
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int m = 0; m < 2; ++m) acc[m] = mfma16(Wf2[m][ks], p2[ks], ks == 0 ? zero16 : acc[m]);
+        // DOTS: <f_s, g_feat[ray]> + <logits_s, g_sem[ray]> for the wave's 32 rows through the matrix pipe: the per-ray gradient (fp16, like
+        // every gradient of the chain) is the A operand -- the same fragment in every lane row, so every row of the product holds the dot
+        // products -- and the packed fp16 activations are the B operand they already are for the next layer.  g_feat / g_sem sit in this
+        // lane's registers in exactly the chained k-order of its half (gf[m][q]: features 32 m + 8 q + 4 half + 0..3).
+        f32x16 dacc = zero16;
+        if constexpr (DOTS) {
+          asm volatile("s_waitcnt vmcnt(0)" : "+a"(gf[0][0]), "+a"(gf[0][1]), "+a"(gf[0][2]), "+a"(gf[0][3]), "+a"(gf[1][0]), "+a"(gf[1][1]),
+                       "+a"(gf[1][2]), "+a"(gf[1][3]));
+#pragma unroll
+          for (int r = 0; r < CP / 2; r += 8)
+            asm volatile("" : "+a"(gsc[r]), "+a"(gsc[r + 1]), "+a"(gsc[r + 2]), "+a"(gsc[r + 3]), "+a"(gsc[r + 4]), "+a"(gsc[r + 5]), "+a"(gsc[r + 6]),
+                         "+a"(gsc[r + 7]));
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 g0 = gf[ks >> 1][2 * (ks & 1)], g1 = gf[ks >> 1][2 * (ks & 1) + 1];
+            union { uint32_t w[4]; h16x8 v; } ga, fb;
+            ga.w[0] = cvt_pk(g0.x, g0.y); ga.w[1] = cvt_pk(g0.z, g0.w); ga.w[2] = cvt_pk(g1.x, g1.y); ga.w[3] = cvt_pk(g1.z, g1.w);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) fb.w[j >> 1] = cvt_pk(acc[ks >> 1][8 * (ks & 1) + j], acc[ks >> 1][8 * (ks & 1) + j + 1]);   // f as stored (fp16), before the ReLU
+            dacc = mfma16(ga.v, fb.v, dacc);
+          }
+        }
         // f is rounded to fp16 first (what the forward stored), then relu'd: relu(f) feeds semantic_out and masks dL/df of that branch
         relu_pack_store<2>(acc, pd, nullptr, hf);
         write_packed_tile<2>(T.FG, srow, pd, hf);
@@ -1522,6 +1593,23 @@ void k_sem_bwd_pair(const h16* __restrict__ wf_f, const h16* __restrict__ wb_f, 
           for (int m = 0; m < 2; ++m) acc[m] = mfma16(Vf0[m][ks], xb[ks], ks == 0 ? zero16 : acc[m]);
         relu_pack_store<2>(acc, pd, nullptr, hf);
         write_packed_tile<2>(T.G1, srow, pd, hf);
+        if constexpr (DOTS) {   // the logits (fp16, as the forward stored them) against g_sem[ray], into the same accumulator
+          f32x16 lg = zero16;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) lg = mfma16(Vf1[ks], pd[ks], lg);
+#pragma unroll
+          for (int ks = 0; ks < KSO; ++ks) {
+            union { uint32_t w[4]; h16x8 v; } ga, lb;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const int c0 = 16 * ks + 8 * (j >> 2) + 4 * hf + (j & 3);   // class of chained position j (and j + 1: c0 + 1)
+              ga.w[j >> 1] = cvt_pk(c0 < C ? gsc[8 * ks + j] : 0.f, c0 + 1 < C ? gsc[8 * ks + j + 1] : 0.f);
+              lb.w[j >> 1] = cvt_pk(lg[8 * ks + j], lg[8 * ks + j + 1]);
+            }
+            dacc = mfma16(ga.v, lb.v, dacc);
+          }
+          if (valid && hf == 0) dots_row[row] = dacc[0];
+        }
         // ---- backward: g1 (its ReLU mask from the packed g1 still in registers)
 #pragma unroll
         for (int ks = 0; ks < KSO; ++ks)
@@ -1891,9 +1979,9 @@ extern "C" int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
     if (rows <= 0) return 0;
     size_t hf_ = (size_t)aln_mlp_frag_halves(16, 64, 64, 2, 0), ho_ = (size_t)aln_mlp_frag_halves(80, 64, semo->out_pad, 1, 0);
     size_t lds = (((hf_ + 7) & ~(size_t)7) + ((ho_ + 7) & ~(size_t)7) + 4 * 32 * (64 + 8)) * 2;
-    hipFuncSetAttribute((const void*)k_sem_fwd_fused<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_sem_fwd_fused<1>), dim3(mlp_grid(rows)), dim3(256), lds, (hipStream_t)stream, (const h16*)semf->wf, hf_,
-                       (const h16*)semo->wf, ho_, (const h16*)sigma_out, rows, G, semo->out_pad, (h16*)feat, (h16*)logits);
+    hipFuncSetAttribute((const void*)k_sem_fwd_fused<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_sem_fwd_fused<1, false>), dim3(mlp_grid(rows)), dim3(256), lds, (hipStream_t)stream, (const h16*)semf->wf, hf_,
+                       (const h16*)semo->wf, ho_, (const h16*)sigma_out, rows, G, semo->out_pad, (h16*)feat, (h16*)logits, nullptr, nullptr);
     ALN_CHECK_LAUNCH("sem_fwd_fused");
     return 0;
   }
@@ -1903,19 +1991,42 @@ extern "C" int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
   return mlp_fwd_src(semo, b, rows, nullptr, nullptr, nullptr, logits, stream);
 }
 
+// The training step's forward of both heads: per-tile weighted sums instead of the rows (k_sem_fwd_fused<SUMS>).
+// tile_sums: [ceil(rows / 32)][96] fp32 -- columns [0, 64) = sum over the tile's rows of w_row * f, [64, 64 + out_pad) the same of
+// the logits.  The caller guarantees that a 32-row tile never straddles two rays (S1 % 32 == 0, S2 % 32 == 0).
+extern "C" int aln_sem_heads_fwd_sums(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, int32_t rows, int32_t D,
+                                      int32_t G, const float* w_row, float* tile_sums, void* stream) {
+  ALN_REQUIRE(semf && semo && sigma_out && w_row && tile_sums, "sem_heads_fwd_sums: NULL pointer");
+  ALN_REQUIRE(sem_pair_fused_ok(semf, semo, D, G) && semo->out_pad <= 32 && semo->out_pad % 8 == 0 && semf->wf && semo->wf,
+              "sem_heads_fwd_sums: both heads 64 wide, D = 64, <= 32 padded classes (ask aln_sem_heads_bwd_slabs)");
+  ALN_REQUIRE(rows % 32 == 0, "sem_heads_fwd_sums: whole 32-row tiles only (%d rows)", rows);
+  if (rows <= 0) return 0;
+  size_t hf_ = (size_t)aln_mlp_frag_halves(16, 64, 64, 2, 0), ho_ = (size_t)aln_mlp_frag_halves(80, 64, semo->out_pad, 1, 0);
+  size_t lds = (((hf_ + 7) & ~(size_t)7) + ((ho_ + 7) & ~(size_t)7) + 4 * 32 * (64 + 8)) * 2;
+  hipFuncSetAttribute((const void*)k_sem_fwd_fused<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_sem_fwd_fused<1, true>), dim3(mlp_grid(rows)), dim3(256), lds, (hipStream_t)stream, (const h16*)semf->wf, hf_,
+                     (const h16*)semo->wf, ho_, (const h16*)sigma_out, rows, G, semo->out_pad, nullptr, nullptr, w_row, tile_sums);
+  ALN_CHECK_LAUNCH("sem_fwd_sums");
+  return 0;
+}
+
 // backward of both heads from the per-ray output gradients: dL/dlogits[row] = w_row * g_sem[ray],
 // dL/df[row] = w_row * g_feat[ray] + relu'(f) * dL/d(semo input)[row][:D].  Writes d_semo_in [rows, semo.in_pad] and
 // d_semf_in [rows, semf.in_pad] (their geo_feat columns feed the sigma head) and accumulates both heads' dW.
 extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat,
                                  const float* w_row, const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2,
                                  int32_t C, int32_t rows, int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf,
-                                 float* dW_semo, int32_t fold_geo, int32_t* found_inf, void* stream) {
-  ALN_REQUIRE(semf && semo && sigma_out && feat && w_row && g_sem && g_feat && d_semo_in && d_semf_in,
+                                 float* dW_semo, int32_t fold_geo, float* dots_row, int32_t* found_inf, void* stream) {
+  const bool pair = fold_geo && dW_semf && dW_semo && semf && semo && sem_pair_fused_ok(semf, semo, D, G);
+  ALN_REQUIRE(semf && semo && sigma_out && (feat || pair) && w_row && g_sem && g_feat && (d_semo_in || pair) && d_semf_in,
               "sem_heads_bwd: NULL pointer");
+  ALN_REQUIRE(!dots_row || (pair && S1 % 32 == 0 && S2 % 32 == 0),
+              "sem_heads_bwd: the per-row dot products need the one-kernel path (fold_geo, both weight gradients, D = 64) and 32-row blocks of ONE ray each "
+              "(S1, S2 multiples of 32): the ray's gradient is one matrix operand for the block");
   ALN_REQUIRE(!fold_geo || (semf->in_pad == 16 && aln_mlp_has_recompute(semf->in_pad, semf->hidden, semf->out_pad, semf->n_hidden)),
               "sem_heads_bwd: fold_geo needs the 16-wide recompute backward of semantic_features");
   hipStream_t s = (hipStream_t)stream;
-  if (fold_geo && dW_semf && dW_semo && sem_pair_fused_ok(semf, semo, D, G)) {   // the training step: one kernel for both heads
+  if (pair) {   // the training step: one kernel for both heads
     if (rows <= 0) return 0;
     const int g = sem_pair_blocks(rows);
     const size_t nf = 16 * 64 + 2 * 64 * 64, no = 80 * 64 + 64 * (size_t)semo->out_pad;
@@ -1924,14 +2035,15 @@ extern "C" int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo,
     RowSrc rs{}; row_src_rays(rs, N, S1, S2);
     constexpr int PH = hid_pitch(64);
     const size_t lds = 2 * (size_t)64 * (88 + 7 * PH + 32 + 16) * 2 + 16;   // two sets of 64-row tiles, the flag word
-#define LAUNCH_PAIR(CP)                                                                                                              \
+#define LAUNCH_PAIR(CP, DOTS)                                                                                                        \
     do {                                                                                                                             \
-      hipFuncSetAttribute((const void*)k_sem_bwd_pair<CP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-      hipLaunchKernelGGL((k_sem_bwd_pair<CP>), dim3(g), dim3(256), lds, s, (const h16*)semf->wf, (const h16*)semf->wb, (const h16*)semo->wf,  \
-                         (const h16*)semo->wb, (const h16*)sigma_out, w_row, rs, g_sem, C, g_feat, G, rows, (h16*)d_semf_in,          \
-                         (float*)semf->dw_ws, (float*)semo->dw_ws, found_inf);                                                       \
+      hipFuncSetAttribute((const void*)k_sem_bwd_pair<CP, DOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      hipLaunchKernelGGL((k_sem_bwd_pair<CP, DOTS>), dim3(g), dim3(256), lds, s, (const h16*)semf->wf, (const h16*)semf->wb,         \
+                         (const h16*)semo->wf, (const h16*)semo->wb, (const h16*)sigma_out, w_row, rs, g_sem, C, g_feat, G, rows,     \
+                         (h16*)d_semf_in, (float*)semf->dw_ws, (float*)semo->dw_ws, dots_row, found_inf);                            \
     } while (0)
-    if (semo->out_pad == 16) LAUNCH_PAIR(16); else LAUNCH_PAIR(32);
+    if (semo->out_pad == 16) { if (dots_row) LAUNCH_PAIR(16, true); else LAUNCH_PAIR(16, false); }
+    else { if (dots_row) LAUNCH_PAIR(32, true); else LAUNCH_PAIR(32, false); }
 #undef LAUNCH_PAIR
     ALN_CHECK_LAUNCH("sem_bwd_pair");
     if (!semf->defer_dw_reduce || !semo->defer_dw_reduce) {

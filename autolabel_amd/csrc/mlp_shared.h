@@ -92,6 +92,20 @@ typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4v* lds_s16x4_ptr;
 
 template <class TV>
+__device__ inline h16x8 tr_frag(TV t, int col0, int ks, int lane) {
+  // operand fragment for mfma 32x32x16: lane (i = lane&31, hf = lane>>5) gets tile[16ks + 8hf + 0..7][col0 + i].
+  // (the builtin lets the compiler count lgkmcnt itself, so several fragment reads stay in flight)
+  const int hf = lane >> 5;
+  const int row = 16 * ks + 8 * hf + ((lane & 15) >> 2);
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row, col));
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row + 4, col));
+  union { struct { s16x4v l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+
+template <class TV>
 __device__ inline h16x8 tr_frag_chained(TV t, int col0, int ks, int lane) {
   // as tr_frag, but the 8 rows follow the chained k-order of the register chain: base + 8*(j>>2) + 4*hf + (j&3)
   const int hf = lane >> 5;

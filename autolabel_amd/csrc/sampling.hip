@@ -328,6 +328,7 @@ struct CompOut {
   const float* wsum;
   int N, S1, S2, C, Cpad, D; float bg;
   float* image; float* semantic; float* features;
+  const float* tile_sums;   // optional [M / 32][96]: per-tile sums of w * f (64) and w * logits (<= 32) left by aln_sem_heads_fwd_sums
 };
 
 __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
@@ -348,6 +349,18 @@ __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
     if (lane == 0) {
       float r = (1.f - p.wsum[ray]) * p.bg;
       p.image[3 * (size_t)ray] = c0 + r; p.image[3 * (size_t)ray + 1] = c1 + r; p.image[3 * (size_t)ray + 2] = c2 + r;
+    }
+    if (p.tile_sums) {   // the ray's tiles in a fixed order: coarse pass, then fine pass (bit-reproducible)
+      const int t1 = p.S1 / 32, t2 = p.S2 / 32;
+      const float* a1 = p.tile_sums + (size_t)ray * t1 * 96;
+      const float* a2 = p.tile_sums + ((size_t)p.N * t1 + (size_t)ray * t2) * 96;
+      for (int ch = lane; ch < 96; ch += 64) {
+        float a = 0.f;
+        for (int t = 0; t < t1; ++t) a += a1[t * 96 + ch];
+        for (int t = 0; t < t2; ++t) a += a2[t * 96 + ch];
+        if (ch < 64) { if (p.features) p.features[(size_t)ray * p.D + ch] = a; }
+        else if (ch - 64 < p.C && p.semantic) p.semantic[(size_t)ray * p.C + ch - 64] = a;
+      }
     }
     // channel sums: `lpr` lanes share a row (one 16-byte chunk each), so one wave instruction reads 64 / lpr whole rows;
     // every lane keeps 8 channel sums over its rows and the row groups are folded with cross-lane adds at the end
@@ -388,13 +401,15 @@ __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
 extern "C" int aln_composite_out(const float* w_row, const int32_t* cidx_row, const void* color_out, const void* logits,
                                  const void* feat, const float* wsum, int32_t N, int32_t S1, int32_t S2, int32_t C,
                                  int32_t Cpad, int32_t D, float bg, float* image, float* semantic, float* features,
-                                 void* stream) {
+                                 const float* tile_sums, void* stream) {
   ALN_REQUIRE(w_row && cidx_row && color_out && wsum && image, "composite_out: NULL pointer");
+  ALN_REQUIRE(!tile_sums || (!logits && !feat && D == 64 && C <= 32 && S1 % 32 == 0 && S2 % 32 == 0 && semantic && features),
+              "composite_out: tile sums replace the logits / feature rows (D = 64, <= 32 classes, sample counts multiples of 32)");
   ALN_REQUIRE((!logits || semantic) && (!feat || features), "composite_out: semantic / feature output buffers missing");
   ALN_REQUIRE((!logits || Cpad % 8 == 0) && (!feat || D % 8 == 0), "composite_out: Cpad and D must be multiples of 8");
   if (N <= 0) return 0;
   CompOut p{w_row, cidx_row, (const h16*)color_out, (const h16*)logits, (const h16*)feat, wsum, N, S1, S2, C, Cpad, D, bg,
-            image, semantic, features};
+            image, semantic, features, tile_sums};
   hipLaunchKernelGGL(k_composite_out, dim3(N < 65535 ? N : 65535), dim3(64), 0, (hipStream_t)stream, p);
   ALN_CHECK_LAUNCH("composite_out");
   return 0;
@@ -412,6 +427,7 @@ struct CompBwd {
   h16* d_logits;       // [M,Cpad]
   h16* d_feat;         // [M,D]
   int* found_inf;
+  const float* dots_row;   // optional [M]: <logits_s, g_sem[ray]> + <f_s, g_feat[ray]> already computed (aln_sem_heads_bwd): logits / feat are not read
 };
 
 #ifndef CB_KU
@@ -540,7 +556,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB_WPE))) vo
     const bool keep = nit <= CB_KU;    // part 3 visits the rows of part 2: its operands are requested here when they fit the registers
     size_t krow[CB_KU]; float kdel[CB_KU], kT[CB_KU], ksig[CB_KU], kh0[CB_KU];
     for (int i0 = 0; i0 < nit; i0 += CB_KU) {
-      int id[CB_KU]; size_t rowv[CB_KU]; bool ok[CB_KU]; float wv[CB_KU], zv[CB_KU]; int ci[CB_KU]; h16x4 ov[CB_KU];
+      int id[CB_KU]; size_t rowv[CB_KU]; bool ok[CB_KU]; float wv[CB_KU], zv[CB_KU], dv[CB_KU]; int ci[CB_KU]; h16x4 ov[CB_KU];
 #pragma unroll
       for (int u = 0; u < CB_KU; ++u) {
         const int k = lane + 64 * (i0 + u);
@@ -553,6 +569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB_WPE))) vo
         wv[u] = ok[u] ? p.w_row[rowv[u]] : 0.f;
         zv[u] = ok[u] ? p.z[rowv[u]] : 0.f;
         ci[u] = ok[u] ? p.cidx_row[rowv[u]] : -1;
+        dv[u] = (p.dots_row && ok[u]) ? p.dots_row[rowv[u]] : 0.f;
         if (keep) {
           krow[u] = rowv[u];
           kdel[u] = ok[u] ? p.delta_row[rowv[u]] : 0.f; kT[u] = ok[u] ? p.T_row[rowv[u]] : 0.f;
@@ -568,6 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB_WPE))) vo
         const float w = wv[u];
         float dw = -p.bg * (gi0 + gi1 + gi2) + zv[u] * gd;
         if (rowmajor_dots) dw += dsem[id[u]];
+        dw += dv[u];
         if (ci[u] >= 0) {
           const h16x4 o = ov[u];
           float r0 = 1.f / (1.f + expf(-(float)o[0])), r1 = 1.f / (1.f + expf(-(float)o[1])), r2 = 1.f / (1.f + expf(-(float)o[2]));
@@ -612,15 +630,16 @@ extern "C" int aln_composite_bwd(const float* norms, const float* z, const float
                                  const float* g_image, const float* g_depth, const float* g_sem, const float* g_feat,
                                  int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad, int32_t D, float bg,
                                  float density_scale, float* d_h0, void* d_color_out, void* d_logits, void* d_feat,
-                                 int32_t mask_feat, int32_t* found_inf, void* stream) {
+                                 int32_t mask_feat, const float* dots_row, int32_t* found_inf, void* stream) {
   ALN_REQUIRE(norms && z && sigma && perm && w_row && T_row && delta_row && cidx_row && color_out && sigma_out && g_image &&
                   g_depth && d_h0 && d_color_out, "composite_bwd: NULL pointer");
   ALN_REQUIRE((!logits || g_sem) && (!feat || g_feat), "composite_bwd: semantic / feature gradient buffers missing");
   ALN_REQUIRE(Cpad % 8 == 0 && D % 8 == 0, "composite_bwd: Cpad and D must be multiples of 8");
+  ALN_REQUIRE(!dots_row || (!logits && !feat && !d_logits && !d_feat), "composite_bwd: dots_row replaces the logits / feat rows (pass those as NULL)");
   if (N <= 0) return 0;
   CompBwd p{norms, z, sigma, perm, w_row, T_row, delta_row, cidx_row, (const h16*)color_out, (const h16*)logits,
             (const h16*)feat, (const h16*)sigma_out, g_image, g_depth, g_sem, g_feat, N, S1, S2, C, Cpad, D, mask_feat, bg,
-            density_scale, d_h0, (h16*)d_color_out, (h16*)d_logits, (h16*)d_feat, found_inf};
+            density_scale, d_h0, (h16*)d_color_out, (h16*)d_logits, (h16*)d_feat, found_inf, dots_row};
   int S = S1 + S2;
   size_t lds = (size_t)(4 * S + Cpad + D) * sizeof(float);
   hipLaunchKernelGGL(k_composite_bwd, dim3(N < 65535 ? N : 65535), dim3(64), lds, (hipStream_t)stream, p);

@@ -84,7 +84,8 @@ _SIGS = {
     'aln_density_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
     'aln_sem_heads_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
-    'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 4 + [i32] + [vp] * 2),
+    'aln_sem_heads_fwd_sums': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 4 + [i32] + [vp] * 3),
     'aln_sigma_act': (i32, [vp, i32, vp, vp]),
     'aln_compact_live_ws_ints': (i32, [i32]),
     'aln_compact_live': (i32, [vp, i32, f32, vp, vp, vp, vp, vp]),
@@ -99,8 +100,8 @@ _SIGS = {
     'aln_grid_update': (i32, [vp, vp, i32, f32, f32, f32, vp, vp, vp, vp]),
     'aln_bitfield_count': (i32, [vp, i64, vp, vp]),
     'aln_mark_untrained_grid': (i32, [vp, i32, f32, vp, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
-    'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
-    'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 4 + [i32] + [vp] * 2),
+    'aln_composite_out': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
+    'aln_composite_bwd': (i32, [vp] * 16 + [i32] * 6 + [f32, f32] + [vp] * 4 + [i32] + [vp] * 3),
     'aln_loss_terms_floats': (i32, []),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),
     'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),

@@ -445,6 +445,15 @@ class HipPipeline:
             elif c['sem_wide']:
                 logits, feat, c['wide_saved'] = self.wide_sem_fwd(sout, M, lambda n, shp: g(n, shp, f16))
                 c['feat'], c['logits'] = feat, logits
+            elif c['sem_fused'] and train and S1 % 32 == 0 and S2 % 32 == 0 and \
+                    H.lib().aln_sem_heads_bwd_slabs(C.byref(P.descs['semf']), C.byref(P.descs['semo']), M, L.D, L.G) > 0:
+                # the training step: neither f nor the logits are stored -- the forward leaves the weighted sums of every 32-row
+                # tile (one ray each), the one-kernel backward recomputes both and hands the compositing backward its dot products
+                c['sem_sums'] = True
+                feat = logits = c['feat'] = c['logits'] = None
+                tile_sums = g('sem_tile_sums', (M // 32, 96), f32_)
+                self._k('aln_sem_heads_fwd_sums', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(sout), M, L.D, L.G,
+                        H.ptr(w_row), H.ptr(tile_sums), H.stream(), tag=('sem', M))
             elif c['sem_fused']:  # inputs are built inside the kernels from sigma_out / f (no semf_in / semo_in tensors)
                 feat = c['feat'] = g('feat', (M, fs.out_pad), f16)
                 logits = c['logits'] = g('logits', (M, os_.out_pad), f16)
@@ -473,7 +482,7 @@ class HipPipeline:
             h2r16 = c['h2_ray16'] = g('h2_ray16', (N, fs.hidden), f16)
             f16r = g('feat_ray16', (N, fs.out_pad), f16)
             H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), None, H.ptr(c['feat']), H.ptr(out['weights_sum']),
-                   N, S1, S2, L.C, L.Cpad, fs.hidden, float(bg), H.ptr(out['image']), None, H.ptr(h2r), H.stream())
+                   N, S1, S2, L.C, L.Cpad, fs.hidden, float(bg), H.ptr(out['image']), None, H.ptr(h2r), None, H.stream())
             H.call('aln_cast_f16', H.ptr(h2r), H.ptr(h2r16), h2r.numel(), H.stream())
             self._nt(N, fs.out_pad, P.wide_w['semf'][2], f16r, a1=h2r16, K1=fs.hidden, tag=('sem', N))
             H.call('aln_cast_f32', H.ptr(f16r), H.ptr(out['semantic_features']), f16r.numel(), H.stream())
@@ -481,7 +490,7 @@ class HipPipeline:
             return out, c
         H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(logits), H.ptr(feat), H.ptr(out['weights_sum']),
                N, S1, S2, L.C, L.Cpad, L.D, float(bg), H.ptr(out['image']), H.ptr(out.get('semantic')),
-               H.ptr(out.get('semantic_features')), H.stream())
+               H.ptr(out.get('semantic_features')), H.ptr(tile_sums) if c.get('sem_sums') else None, H.stream())
         return out, c
 
     def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None, scatter_flag=None, grid_adam=None):
@@ -534,13 +543,25 @@ class HipPipeline:
             H.call('aln_composite_bwd', H.ptr(c['norms']), H.ptr(c['z']), H.ptr(c['sigma']), H.ptr(c['perm']), H.ptr(c['w_row']),
                    H.ptr(c['T_row']), H.ptr(c['delta_row']), H.ptr(c['cidx_row']), H.ptr(c['color_out']), None, H.ptr(c['feat']),
                    H.ptr(c['sigma_out']), H.ptr(g_image), H.ptr(g_depth), None, H.ptr(dH32), N, S1, S2, L.C, L.Cpad, fs.hidden,
-                   c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), None, H.ptr(d_feat), 1, fi, H.stream())
+                   c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), None, H.ptr(d_feat), 1, None, fi, H.stream())
         else:
+            dots = d_fin_pair = None
+            if sem_fused and c.get('sem_sums'):
+                # the semantic pair goes FIRST: it needs only the compositing weights and the per-ray output gradients, and its
+                # per-row <logits, g_sem> + <f, g_feat> is the semantic outputs' share of dL/dw the compositing backward wants
+                fs = nets['semf']
+                dots, d_fin_pair = g('sem_dots', (M,), f32_), g('d_semf_in', (M, fs.in_pad), f16)
+                self._k('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), None,
+                        H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, None, H.ptr(d_fin_pair),
+                        gp('semf'), gp('semo'), 1, H.ptr(dots), fi, H.stream(), tag=('sem', M))
+            elif sem and c.get('sem_sums'):
+                raise RuntimeError('HipPipeline.backward: the forward kept no semantic rows (sem_sums) but the one-kernel backward is not available')
             H.call('aln_composite_bwd', H.ptr(c['norms']), H.ptr(c['z']), H.ptr(c['sigma']), H.ptr(c['perm']), H.ptr(c['w_row']),
                    H.ptr(c['T_row']), H.ptr(c['delta_row']), H.ptr(c['cidx_row']), H.ptr(c['color_out']),
-                   H.ptr(c['logits']) if sem else None, H.ptr(c['feat']) if sem else None, H.ptr(c['sigma_out']), H.ptr(g_image),
-                   H.ptr(g_depth), H.ptr(g_sem) if sem else None, H.ptr(g_feat) if sem else None, N, S1, S2, L.C, L.Cpad, L.D,
-                   c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), H.ptr(d_logits), H.ptr(d_feat), 0, fi, H.stream())
+                   H.ptr(c['logits']) if sem and dots is None else None, H.ptr(c['feat']) if sem and dots is None else None, H.ptr(c['sigma_out']),
+                   H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem) if sem and dots is None else None, H.ptr(g_feat) if sem and dots is None else None,
+                   N, S1, S2, L.C, L.Cpad, L.D, c['bg'], self.density_scale, H.ptr(d_h0), H.ptr(d_cout), H.ptr(d_logits), H.ptr(d_feat), 0,
+                   H.ptr(dots), fi, H.stream())
         # color head
         rc = self.recompute
         hp = (lambda t: None) if rc else H.ptr   # saved activations are not passed on the recompute path
@@ -549,12 +570,14 @@ class HipPipeline:
         self._k('aln_mlp_bwd', C.byref(P.descs['color']), H.ptr(c['color_in']), hp(c['ch1']), hp(c['ch2']), H.ptr(d_cout),
                 M, H.ptr(c['n_live']), H.ptr(dA1), H.ptr(dA2), H.ptr(d_cin), gp('color'), fi, H.stream(), tag=('color', c['n_live']))
         d_fin = d_oin = None
-        if sem_fused:
+        if sem_fused and c.get('sem_sums'):
+            d_fin = d_fin_pair       # (ran before the compositing backward, above)
+        elif sem_fused:
             fs, os_ = nets['semf'], nets['semo']
             d_oin, d_fin = g('d_semo_in', (M, os_.in_pad), f16), g('d_semf_in', (M, fs.in_pad), f16)
             self._k('aln_sem_heads_bwd', C.byref(P.descs['semf']), C.byref(P.descs['semo']), H.ptr(c['sigma_out']), H.ptr(c['feat']),
                     H.ptr(c['w_row']), H.ptr(g_sem), H.ptr(g_feat), N, S1, S2, L.C, M, L.D, L.G, H.ptr(d_oin), H.ptr(d_fin),
-                    gp('semf'), gp('semo'), 1, fi, H.stream(), tag=('sem', M))
+                    gp('semf'), gp('semo'), 1, None, fi, H.stream(), tag=('sem', M))
             d_oin = None     # fold_geo = 1: its geo_feat columns are already inside d_fin
         elif lin:
             # semantic_features layers 2 and 1 from d h2 (the last layer was handled per ray above; semantic_out took no part)

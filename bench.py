@@ -286,7 +286,7 @@ def mlp_roofline(eng, events, n_event_steps, live_rows):
         head, r = t
         if torch.is_tensor(r):
             r = live_rows   # the device counter is reused every step; the last step's value stands for all
-        flops += (2.0 if n.endswith('_fwd') else 4.0) * mac[head] * r
+        flops += (2.0 if n.endswith(('_fwd', '_fwd_sums')) else 4.0) * mac[head] * r
         t_mlp += e[0].elapsed_time(e[1]) * 1e-3
     if t_mlp <= 0:
         return None

@@ -204,11 +204,19 @@ int aln_mlp_dw_reduce_slabs(int32_t n_heads, const AlnMlpDesc* const* descs, flo
  * columns [D, D + 16) = its dL/d(geo_feat, 1). */
 int aln_sem_heads_fwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, int32_t rows, int32_t D, int32_t G,
                       void* feat, void* logits, void* stream);
+/* the training step's forward: no rows leave the kernel, only tile_sums[ceil(rows / 32)][96] = per 32-row tile the sums of
+ * w_row * f (64 columns) and w_row * logits (out_pad <= 32 columns) -- what models.py:195-203's weighted sums need of them.  Same
+ * shapes as the one-kernel backward (aln_sem_heads_bwd_slabs > 0); a tile must not straddle two rays (S1, S2 multiples of 32). */
+int aln_sem_heads_fwd_sums(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, int32_t rows, int32_t D, int32_t G,
+                           const float* w_row, float* tile_sums, void* stream);
 int aln_sem_heads_bwd(const AlnMlpDesc* semf, const AlnMlpDesc* semo, const void* sigma_out, const void* feat, const float* w_row,
                       const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t rows,
                       int32_t D, int32_t G, void* d_semo_in, void* d_semf_in, float* dW_semf, float* dW_semo,
                       int32_t fold_geo /* 1 = d_semf_in rows also take the geo_feat columns of d_semo_in, so that
                                           aln_assemble_grads needs d_semf_in only (d_semo_in = NULL there) */,
+                      float* dots_row /* optional [rows], one-kernel form only: <logits_s, g_sem[ray]> + <f_s, g_feat[ray]> per sample row,
+                                         the semantic outputs' share of dL/dw_s (S1, S2 multiples of 32; g in fp16 like every gradient of the chain) -- aln_composite_bwd(dots_row) then needs neither f nor the
+                                         logits, and the forward need not store them (aln_sem_heads_fwd_sums) */,
                       int32_t* found_inf, void* stream);
 /* slabs per head that aln_sem_heads_bwd(..., fold_geo = 1, both dW) leaves in semf->dw_ws / semo->dw_ws when the pair runs as ONE
  * kernel (both heads 64 wide, D = 64, <= 32 padded classes: models.py:248-256 at the reference's sizes); 0 = two launches, the
@@ -293,13 +301,18 @@ int aln_composite_fwd(const float* rays_o, const float* rays_d, const float* nor
                       void* stream);
 int aln_composite_out(const float* w_row, const int32_t* cidx_row, const void* color_out, const void* logits, const void* feat,
                       const float* wsum, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad, int32_t D, float bg,
-                      float* image, float* semantic, float* features, void* stream);
+                      float* image, float* semantic, float* features,
+                      const float* tile_sums /* optional [rows / 32][96]: the per-tile weighted sums of aln_sem_heads_fwd_sums in place of
+                                                the logits / feat rows (both NULL then; D = 64, C <= 32, S1 and S2 multiples of 32) */,
+                      void* stream);
 int aln_composite_bwd(const float* norms, const float* z, const float* sigma, const uint16_t* perm, const float* w_row,
                       const float* T_row, const float* delta_row, const int32_t* cidx_row, const void* color_out,
                       const void* logits, const void* feat, const void* sigma_out, const float* g_image, const float* g_depth,
                       const float* g_sem, const float* g_feat, int32_t N, int32_t S1, int32_t S2, int32_t C, int32_t Cpad,
                       int32_t D, float bg, float density_scale, float* d_h0, void* d_color_out, void* d_logits, void* d_feat,
                       int32_t mask_feat /* 1: d_feat rows are zeroed where feat <= 0 (feat = a post-ReLU activation) */,
+                      const float* dots_row /* optional [rows]: <logits_s, g_sem> + <f_s, g_feat> from aln_sem_heads_bwd(dots_row), in place of
+                                               the logits / feat rows (NULL then, like d_logits / d_feat) */,
                       int32_t* found_inf, void* stream);
 
 /* ---- loss: autolabel/trainer.py:72-92 (rgb MSE + depth L1 over depth > 0.01 + feature L1 + CE over labelled rays), ONE launch.

@@ -670,7 +670,46 @@ def test_fused_semantic_heads_forward_is_bit_identical_to_two_launches(H):
     assert feat.abs().max() > 0 and logits.abs().max() > 0
 
 
-@pytest.mark.parametrize('N,S1,S2,Ccls,out_pad,G', [(37, 24, 20, 7, 16, 15), (41, 128, 0, 20, 32, 15), (300, 64, 64, 40, 48, 7),
+@pytest.mark.parametrize('N,S1,S2,Ccls,out_pad', [(37, 64, 32, 7, 16), (16, 128, 128, 29, 32), (50, 64, 0, 3, 16)])
+def test_semantic_forward_tile_sums_equal_the_composited_rows(H, N, S1, S2, Ccls, out_pad):
+    """The training step's forward (aln_sem_heads_fwd_sums + aln_composite_out(tile_sums)) keeps no f / logits rows: per 32-row
+    tile it leaves sum_s w_s f_s and sum_s w_s logits_s.  Against the row path (aln_sem_heads_fwd rows, then aln_composite_out over
+    them): same fp16 f and logits, the weights split into an fp16 head and remainder (exact to 2^-22), another summation order."""
+    _, dF, keepF = _mlp_setup(H, 16, 64, 64, 2, seed=3)
+    _, dO, keepO = _mlp_setup(H, 80, 64, out_pad, 1, seed=4)
+    rows = N * (S1 + S2)
+    g = torch.Generator().manual_seed(13)
+    sigma_out = torch.randn(rows, 16, generator=g).half().cuda()
+    w_row = (torch.rand(rows, generator=g) ** 4 * (torch.rand(rows, generator=g) > 0.3)).cuda()
+    cidx = torch.full((rows,), -1, dtype=torch.int32, device='cuda')
+    cout = torch.zeros(1, 16, dtype=torch.float16, device='cuda')
+    wsum = torch.zeros(N, device='cuda')
+    feat = torch.zeros(rows, 64, dtype=torch.float16, device='cuda')
+    logits = torch.zeros(rows, out_pad, dtype=torch.float16, device='cuda')
+    H.call('aln_sem_heads_fwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, 15, H.ptr(feat), H.ptr(logits), H.stream())
+    img, sem_a, feat_a = torch.zeros(N, 3, device='cuda'), torch.zeros(N, Ccls, device='cuda'), torch.zeros(N, 64, device='cuda')
+    H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(logits), H.ptr(feat), H.ptr(wsum), N, S1, S2, Ccls, out_pad, 64,
+           1.0, H.ptr(img), H.ptr(sem_a), H.ptr(feat_a), None, H.stream())
+    sums = torch.full((rows // 32, 96), float('nan'), device='cuda')
+    H.call('aln_sem_heads_fwd_sums', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, 15, H.ptr(w_row), H.ptr(sums), H.stream())
+    sem_b, feat_b = torch.full_like(sem_a, float('nan')), torch.full_like(feat_a, float('nan'))
+    H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), None, None, H.ptr(wsum), N, S1, S2, Ccls, out_pad, 64,
+           1.0, H.ptr(img), H.ptr(sem_b), H.ptr(feat_b), H.ptr(sums), H.stream())
+    # fp64 reference of the same sums from the stored rows
+    ray = torch.cat([torch.arange(N).repeat_interleave(S1), torch.arange(N).repeat_interleave(S2)]).cuda()
+    want_f = torch.zeros(N, 64, dtype=torch.float64, device='cuda').index_add_(0, ray, feat.double() * w_row.double()[:, None])
+    want_l = torch.zeros(N, Ccls, dtype=torch.float64, device='cuda').index_add_(0, ray, logits[:, :Ccls].double() * w_row.double()[:, None])
+    for got, ref, want in [(feat_b, feat_a, want_f), (sem_b, sem_a, want_l)]:
+        scale = want.abs().max().item()
+        assert scale > 0
+        assert (got.double() - want).abs().max().item() <= 2e-6 * scale + 1e-7
+        assert (ref.double() - want).abs().max().item() <= 2e-6 * scale + 1e-7     # (the row path, for scale)
+    again = torch.zeros_like(sums)
+    H.call('aln_sem_heads_fwd_sums', C.byref(dF), C.byref(dO), H.ptr(sigma_out), rows, 64, 15, H.ptr(w_row), H.ptr(again), H.stream())
+    assert torch.equal(again[:, :64 + out_pad], sums[:, :64 + out_pad])
+
+
+@pytest.mark.parametrize('N,S1,S2,Ccls,out_pad,G', [(37, 24, 20, 7, 16, 15), (41, 128, 0, 20, 32, 15), (33, 64, 32, 7, 16, 15), (300, 64, 64, 40, 48, 7),
                                                      (64, 128, 128, 64, 64, 15)])
 def test_semantic_heads_backward_matches_fp32(H, N, S1, S2, Ccls, out_pad, G):
     """aln_sem_heads_bwd (both heads, inputs and output gradients built on the fly, f re-read) against fp32 autograd of
@@ -692,12 +731,12 @@ def test_semantic_heads_backward_matches_fp32(H, N, S1, S2, Ccls, out_pad, G):
     d_fin = torch.zeros(rows, 16, dtype=torch.float16, device='cuda')
     dWf, dWo = torch.zeros(nf, device='cuda'), torch.zeros(no, device='cuda')
     H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf), H.ptr(dWo), 0, H.ptr(flag), H.stream())
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin), H.ptr(dWf), H.ptr(dWo), 0, None, H.ptr(flag), H.stream())
     d_geo = d_fin.float() + d_oin[:, 64:80].float()
     # fold_geo = 1: the same sum leaves the second launch directly (one rounding instead of two)
     d_fin_f = torch.zeros_like(d_fin); dWf3, dWo3 = torch.zeros_like(dWf), torch.zeros_like(dWo)
     H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, H.ptr(flag), H.stream())
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, None, H.ptr(flag), H.stream())
     assert flag.item() == 0
     assert (d_fin_f.float() - d_geo).abs().max().item() <= 2e-3 * d_geo.abs().max().item() + 1e-6
     fused = H.lib().aln_sem_heads_bwd_slabs(C.byref(dF), C.byref(dO), rows, 64, G) > 0
@@ -705,8 +744,24 @@ def test_semantic_heads_backward_matches_fp32(H, N, S1, S2, Ccls, out_pad, G):
         assert (dWf3 - dWf).abs().max().item() <= 2e-3 * dWf.abs().max().item() and (dWo3 - dWo).abs().max().item() <= 2e-3 * dWo.abs().max().item()
         dWf4, dWo4, d_fin_g = torch.zeros_like(dWf), torch.zeros_like(dWo), torch.zeros_like(d_fin)
         H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
-               N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_g), H.ptr(dWf4), H.ptr(dWo4), 1, H.ptr(flag), H.stream())
+               N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_g), H.ptr(dWf4), H.ptr(dWo4), 1, None, H.ptr(flag), H.stream())
         assert torch.equal(dWf4, dWf3) and torch.equal(dWo4, dWo3) and torch.equal(d_fin_g, d_fin_f), 'the fused pair must be bit-reproducible'
+        # with dots_row: the same gradients, plus <logits_s, g_sem[ray]> + <f_s, g_feat[ray]> per row from the stored fp16 outputs;
+        # neither f nor d(semantic_out input) is passed (the training step has no such buffers)
+        dots = torch.full((rows,), float('nan'), device='cuda')
+        dWf5, dWo5, d_fin_h = torch.zeros_like(dWf), torch.zeros_like(dWo), torch.zeros_like(d_fin)
+        if S1 % 32 == 0 and S2 % 32 == 0:   # (a 32-row block must belong to one ray: its gradient is one matrix operand)
+            H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), None, H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
+                   N, S1, S2, Ccls, rows, 64, G, None, H.ptr(d_fin_h), H.ptr(dWf5), H.ptr(dWo5), 1, H.ptr(dots), H.ptr(flag), H.stream())
+            assert torch.equal(dWf5, dWf3) and torch.equal(dWo5, dWo3) and torch.equal(d_fin_h, d_fin_f)
+            ray_d = torch.cat([torch.arange(N).repeat_interleave(S1), torch.arange(N).repeat_interleave(S2)]).cuda()
+            want = (logits[:, :Ccls].float() * g_sem[ray_d]).sum(1) + (feat.float() * g_feat[ray_d]).sum(1)
+            # the per-ray gradients enter the product as fp16 (2^-11 per term, like dL/dlogits = fp16(w g) of the chain itself)
+            assert (dots - want).abs().max().item() <= 1e-3 * want.abs().max().item() + 1e-6, (dots - want).abs().max().item()
+        else:
+            with pytest.raises(RuntimeError):
+                H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), None, H.ptr(w_row), H.ptr(g_sem), H.ptr(g_feat),
+                       N, S1, S2, Ccls, rows, 64, G, None, H.ptr(d_fin_h), H.ptr(dWf5), H.ptr(dWo5), 1, H.ptr(dots), H.ptr(flag), H.stream())
         dWf, dWo = dWf3, dWo3     # the fp32 comparison below then checks the fused kernel's gradients
     else:
         assert torch.equal(dWf3, dWf) and torch.equal(dWo3, dWo)
@@ -734,7 +789,7 @@ def test_semantic_heads_backward_matches_fp32(H, N, S1, S2, Ccls, out_pad, G):
     g_bad = g_feat.clone(); g_bad[0, 3] = float('inf')
     w2 = w_row.clone(); w2[0] = 1.0
     H.call('aln_sem_heads_bwd', C.byref(dF), C.byref(dO), H.ptr(sigma_out), H.ptr(feat), H.ptr(w2), H.ptr(g_sem), H.ptr(g_bad),
-           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, H.ptr(flag), H.stream())
+           N, S1, S2, Ccls, rows, 64, G, H.ptr(d_oin), H.ptr(d_fin_f), H.ptr(dWf3), H.ptr(dWo3), 1, None, H.ptr(flag), H.stream())
     assert flag.item() == 1
 
 

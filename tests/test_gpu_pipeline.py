@@ -347,15 +347,22 @@ def test_adam_step_matches_torch_adam_and_skips_on_inf():
 
 
 def test_inference_and_training_forward_agree_bitwise():
-    """train=False skips the color_in tensor (inputs built inside the color kernel) and nothing else: same outputs."""
+    """train=False skips the color_in tensor (inputs built inside the color kernel): same bits.  The semantic outputs of the training
+    forward are the same sums in another order (per-tile partial sums instead of stored f / logits rows): equal to fp32 rounding, and
+    bitwise when the sample counts rule the tile sums out."""
     _, pipe, _ = build_pair(C_=5)
     o, d, norms = make_rays(600, seed=4)
     od, dd, nd = o.cuda(), d.cuda(), norms.reshape(-1).cuda()
-    a, _ = pipe.forward(od, dd, nd, 64, 32, False, train=True)
-    a = {k: v.clone() for k, v in a.items()}
-    b, _ = pipe.forward(od, dd, nd, 64, 32, False, train=False)
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
+    for S1, S2, sums in [(64, 32, True), (64, 24, False)]:
+        a, ctx = pipe.forward(od, dd, nd, S1, S2, False, train=True)
+        assert bool(ctx.get('sem_sums')) == sums
+        a = {k: v.clone() for k, v in a.items()}
+        b, _ = pipe.forward(od, dd, nd, S1, S2, False, train=False)
+        for k in a:
+            if sums and k in ('semantic', 'semantic_features'):
+                assert (a[k] - b[k]).abs().max().item() <= 2e-6 * b[k].abs().max().item() + 1e-7, k
+            else:
+                assert torch.equal(a[k], b[k]), k
 
 
 def test_diverged_field_does_not_corrupt_memory():
