@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libautolabel_hip.so')
 OBJ = os.path.join(CSRC, 'build')
-SOURCES = ['encode.hip', 'mlp.hip', 'mlp_bwd128.hip', 'sampling.hip', 'heads.hip', 'raygen.hip', 'loss.hip', 'adam.hip', 'march.hip', 'wide.hip',
+SOURCES = ['encode.hip', 'mlp.hip', 'mlp_bwd128.hip', 'mlp_fwd128.hip', 'sampling.hip', 'heads.hip', 'raygen.hip', 'loss.hip', 'adam.hip', 'march.hip', 'wide.hip',
            'capi.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-Wno-unused-value', '-fPIC',
          '-mllvm', '-amdgpu-mfma-vgpr-form=1']  # MFMA results straight into VGPRs (no v_accvgpr_read for every epilogue)

@@ -1802,6 +1802,12 @@ static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32
   ALN_REQUIRE(m->in_pad % 16 == 0 && m->out_pad % 16 == 0, "mlp_fwd: widths must be multiples of 16");
   ALN_REQUIRE(m->in_pad <= 80, "mlp_fwd: in_pad %d exceeds the 80 input features the fused kernel holds in registers", m->in_pad);
   if (rows <= 0) return 0;
+#ifndef ALN_FWD128_OLD   // (dev builds only: A/B against k_mlp_fwd)
+  if (xs.mode == SRC_PLAIN && !h1 && !h2 && xs.lda == m->in_pad && ((uintptr_t)xs.a & 15) == 0) {   // the 128-wide heads over plain rows: mlp_fwd128.hip
+    const int rc = aln_launch_fwd128(m, xs.a, rows, rows_dev, out, sigma, (hipStream_t)stream);
+    if (rc != -3) { ALN_CHECK_LAUNCH("mlp_fwd128"); return rc; }
+  }
+#endif
   size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 0);
   size_t lds = halves * 2;
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_fwd: weights (%zu B) exceed LDS", lds);

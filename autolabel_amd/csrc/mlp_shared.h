@@ -122,3 +122,5 @@ __device__ inline h16x8 tr_frag_chained(TV t, int col0, int ks, int lane) {
 // mlp_bwd128.hip: recompute backward of the 128-wide heads (plain x / dL/dout rows); -3 = shape not instantiated
 int aln_launch_bwd128(const AlnMlpDesc* m, const void* x, const void* d_out, int rows, const int* rows_dev, void* d_in, float* ws,
                       int g, int* found_inf, hipStream_t s);
+// mlp_fwd128.hip: forward of the 128-wide heads over plain rows, weights resident in registers; -3 = shape not instantiated
+int aln_launch_fwd128(const AlnMlpDesc* m, const void* x, int rows, const int* rows_dev, void* out, float* sigma, hipStream_t s);
