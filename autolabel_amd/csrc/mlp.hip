@@ -471,17 +471,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HID == 128
 // same 32-row tile: f goes through a wave-private LDS tile, from which it is (a) written out as whole 128-byte rows and
 // (b) read back -- ReLU applied -- in the natural k-order of semantic_out's first layer, so both heads keep their ordinary
 // fragment images and f is never re-read from HBM (the two-launch path reads it back: 128 B/sample, 24 % of a render pass).
-// sum over the 32 lanes of the lane's half of the wave (every lane of the half gets the total): four DPP steps inside the rows of
-// 16, one crossbar step between them
-__device__ inline float half_sum32(float v) {
-#define ALN_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-  ALN_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
-  ALN_DPP_ADD(0x4E);    // quad_perm [2, 3, 0, 1]
-  ALN_DPP_ADD(0x141);   // row_half_mirror
-  ALN_DPP_ADD(0x140);   // row_mirror
-#undef ALN_DPP_ADD
-  return v + __shfl_xor(v, 16);
-}
 // SUMS (the training step): neither f nor the logits leave the CU.  A tile's 32 rows belong to one ray (both sample counts are
 // multiples of 32), and all the step needs of them is the ray's weighted sums sum_s w_s f_s, sum_s w_s logits_s (models.py:
 // 195-203): the wave leaves the partial sums of its tile -- [1 x 32] x [32 x 64] through the matrix pipe, the weights as row 0

@@ -229,3 +229,4 @@ int aln_launch_fwd128(const AlnMlpDesc* m, const void* x, int rows, const int* r
   else hipLaunchKernelGGL(k_mlp_fwd128<3>, dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma);
   return 0;
 }
+

@@ -119,6 +119,17 @@ __device__ inline h16x8 tr_frag_chained(TV t, int col0, int ks, int lane) {
 }
 
 
+// sum over the 32 lanes of the lane's half of the wave (every lane of the half gets the total): four DPP steps inside the rows of
+// 16, one crossbar step between them
+__device__ inline float half_sum32(float v) {
+#define ALN_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  ALN_DPP_ADD(0xB1);    // quad_perm [1, 0, 3, 2]
+  ALN_DPP_ADD(0x4E);    // quad_perm [2, 3, 0, 1]
+  ALN_DPP_ADD(0x141);   // row_half_mirror
+  ALN_DPP_ADD(0x140);   // row_mirror
+#undef ALN_DPP_ADD
+  return v + __shfl_xor(v, 16);
+}
 // mlp_bwd128.hip: recompute backward of the 128-wide heads (plain x / dL/dout rows); -3 = shape not instantiated
 int aln_launch_bwd128(const AlnMlpDesc* m, const void* x, const void* d_out, int rows, const int* rows_dev, void* d_in, float* ws,
                       int g, int* found_inf, hipStream_t s);
