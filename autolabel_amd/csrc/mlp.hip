@@ -1365,21 +1365,25 @@ __device__ inline void mfma_acc_a(f32x16& acc, h16x8 a, h16x8 b) {   // accumula
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 // NOB x NIB weight-gradient blocks of one matrix over the tile's 64 rows: dW[o][i] += sum_s A[s][o] B[s][i]
+// (tr_frag_s8: both operands take their samples in the bank-friendly order)
+#ifdef ALN_TRS8_OLD   // (dev builds only)
+#define tr_frag_s8 tr_frag
+#endif
 template <int NOB, int NIB, int OFF, int NDW, class TVA, class TVB>
 __device__ inline void dw_matrix(f32x16 (&dw)[NDW], TVA tA, int colA, TVB tB, int colB, int lane) {
   constexpr int KSTEPS = 4;
   h16x8 a[2][NOB], b[2][NIB];
 #pragma unroll
-  for (int o = 0; o < NOB; ++o) a[0][o] = tr_frag(tA, colA + 32 * o, 0, lane);
+  for (int o = 0; o < NOB; ++o) a[0][o] = tr_frag_s8(tA, colA + 32 * o, 0, lane);
 #pragma unroll
-  for (int i = 0; i < NIB; ++i) b[0][i] = tr_frag(tB, colB + 32 * i, 0, lane);
+  for (int i = 0; i < NIB; ++i) b[0][i] = tr_frag_s8(tB, colB + 32 * i, 0, lane);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     if (ks + 1 < KSTEPS) {
 #pragma unroll
-      for (int o = 0; o < NOB; ++o) a[(ks + 1) & 1][o] = tr_frag(tA, colA + 32 * o, ks + 1, lane);
+      for (int o = 0; o < NOB; ++o) a[(ks + 1) & 1][o] = tr_frag_s8(tA, colA + 32 * o, ks + 1, lane);
 #pragma unroll
-      for (int i = 0; i < NIB; ++i) b[(ks + 1) & 1][i] = tr_frag(tB, colB + 32 * i, ks + 1, lane);
+      for (int i = 0; i < NIB; ++i) b[(ks + 1) & 1][i] = tr_frag_s8(tB, colB + 32 * i, ks + 1, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

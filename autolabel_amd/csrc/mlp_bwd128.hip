@@ -38,13 +38,31 @@ __device__ inline void mfma_acc(f32x16& acc, h16x8 a, h16x8 b) {
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
+// Physical row of feature f in the [feature][sample] tiles: inside every group of 32 the row index is rotated so that four
+// CONSECUTIVE features sit eight rows apart.  The transposing read below fetches four consecutive features per 32-lane pass, 16
+// dwords of each: at the 74-dword pitch consecutive rows start 10 banks apart and their windows collide two ways (PMC: 32-35 % of
+// this kernel's LDS cycles were bank conflicts), rows eight apart start 16 banks apart and tile the 64 banks exactly.  The
+// row-per-lane accesses (write_slice, samp_frag, the ReLU masks) touch the same 32 rows in another order: still conflict-free.
+#ifdef ALN_PROW_OLD   // (dev builds only: A/B against the unrotated rows)
+__device__ inline int prow(int f) { return f; }
+#else
+__device__ inline int prow(int f) { return (f & ~31) | ((f & 3) << 3) | ((f >> 2) & 7); }
+#endif
 // A operand (lane = sample, 8 consecutive features in chained k order) from a [feature][sample] tile
 __device__ inline h16x8 act_frag(const lds_h16* T, int rb, int ks, int lane) {
-  return tr_frag_chained(PlainV<const lds_h16*>{T, PH}, 32 * rb, ks, lane);
+  const int hf = lane >> 5;
+  const int f = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * hf + ((lane & 15) >> 2);   // (tr_frag_chained's row; f + 8 stays in the group of 32)
+  const int col = 32 * rb + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const lds_h16* p0 = T + prow(f) * PH + col;
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(T + prow(f + 8) * PH + col));   // (= p0 + 2 PH)
+  union { struct { s16x4v l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
 }
 // B operand of a weight-gradient MFMA (lane = feature of block ib, 8 samples in C-register order) from the same tile
 __device__ inline h16x8 samp_frag(const lds_h16* T, int ib, int rb, int h, int lane) {
-  const lds_h16* p0 = T + (32 * ib + (lane & 31)) * PH + 32 * rb + 16 * h + 4 * (lane >> 5);
+  const lds_h16* p0 = T + prow(32 * ib + (lane & 31)) * PH + 32 * rb + 16 * h + 4 * (lane >> 5);
   const lds_h16* p1 = p0 + 8;
   asm volatile("" : "+v"(p1));   // two ds_read_b64, never one ds_read2_b64 (mlp.hip: 8+ LDS cycles and 32-bank conflicts)
   union { struct { u32x2 a, b; } s; h16x8 v; } u;
@@ -58,7 +76,7 @@ __device__ inline void relu_pack(const f32x16& acc, Pk& p) {
 }
 // write the wave's 32-feature slice of one row block: lane (n, half) holds samples 8q + 4 half + 0..3 in registers 4q..4q+3
 __device__ inline void write_slice(lds_h16* T, int wave, int rb, const Pk& p, int lane) {
-  lds_h16* row = T + (32 * wave + (lane & 31)) * PH + 32 * rb + 4 * (lane >> 5);
+  lds_h16* row = T + prow(32 * wave + (lane & 31)) * PH + 32 * rb + 4 * (lane >> 5);
 #pragma unroll
   for (int q = 0; q < 4; ++q) *(LDS_VEC(u32x2)*)(row + 8 * q) = (u32x2){p.q[q >> 1][2 * (q & 1)], p.q[q >> 1][2 * (q & 1) + 1]};
 }
@@ -276,7 +294,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
       };
       auto req_m = [&](int rb, int j) __attribute__((always_inline)) {   // h1 of the own slice, for the mask
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[j][q] = *(const LDS_VEC(u32x2)*)(t1 + (32 * wave + c) * PH + 32 * rb + 4 * hf + 8 * q);
+        for (int q = 0; q < 4; ++q) m[j][q] = *(const LDS_VEC(u32x2)*)(t1 + prow(32 * wave + c) * PH + 32 * rb + 4 * hf + 8 * q);
       };
       auto epilogue = [&](int rb, int j) __attribute__((always_inline)) {
 #pragma unroll

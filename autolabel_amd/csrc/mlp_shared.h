@@ -105,6 +105,21 @@ __device__ inline h16x8 tr_frag(TV t, int col0, int ks, int lane) {
   return u.v;
 }
 
+// as tr_frag for an operand whose 8 samples per lane may be ANY 8 rows of the tile, as long as both operands of the MFMA use the
+// same choice (a weight gradient sums over the samples: the order is free): k-step ks, half hf, read j take rows
+// 32 (ks >> 1) + 8 q + 4 (ks & 1) + 2 hf + j, q = 0..3 -- the four rows of a 32-lane pass sit 8 rows apart, which tiles the 64 banks
+// exactly for every pitch of 2 (mod 8) dwords (68 and 148 halves; consecutive rows collide two ways there).  Tiles of 32 n rows.
+template <class TV>
+__device__ inline h16x8 tr_frag_s8(TV t, int col0, int ks, int lane) {
+  const int hf = lane >> 5;
+  const int row = 32 * (ks >> 1) + 8 * ((lane & 15) >> 2) + 4 * (ks & 1) + 2 * hf;
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row, col));
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)t.at(row + 1, col));
+  union { struct { s16x4v l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
 template <class TV>
 __device__ inline h16x8 tr_frag_chained(TV t, int col0, int ks, int lane) {
   // as tr_frag, but the 8 rows follow the chained k-order of the register chain: base + 8*(j>>2) + 4*hf + (j&3)
