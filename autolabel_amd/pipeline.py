@@ -158,6 +158,15 @@ class Workspace:
             self.generation += 1
         return self.bufs[name][1]
 
+    def zeros(self, name, shape, dtype):
+        """A buffer that is zero when first handed out (kernels that keep a self-resetting scratch: tickets, ready flags)."""
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(name)
+        if t is None or t[0] != key:
+            self.bufs[name] = (key, torch.zeros(shape, dtype=dtype, device=self.device))
+            self.generation += 1
+        return self.bufs[name][1]
+
     def scratch(self, name, nbytes):
         """Byte scratch that only ever grows (callers with varying sizes share one allocation)."""
         t = self.bufs.get(name)
@@ -414,7 +423,7 @@ class HipPipeline:
         # color head on live samples only (models.py:195-203)
         n_live, live_idx, cidx = g('n_live', (1,), i32_), g('live_idx', (M,), i32_), g('cidx_row', (M,), i32_)
         c.update(n_live=n_live, live_idx=live_idx, cidx_row=cidx)
-        chunk_ws = g('compact_ws', (max(int(H.lib().aln_compact_live_ws_ints(M)), 1),), i32_)
+        chunk_ws = ws.zeros('compact_ws', (max(int(H.lib().aln_compact_live_ws_ints(M)), 1),), i32_)   # zero once; the kernel leaves it zero
         H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(chunk_ws), H.stream())
         cs = nets['color']
         cin = c['color_in'] = g('color_in', (M, cs.in_pad), f16)
