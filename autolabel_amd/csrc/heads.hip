@@ -19,83 +19,82 @@ extern "C" int aln_sigma_act(const void* sigma_out, int32_t rows, float* sigma, 
   return 0;
 }
 
-// live = w > thresh (renderer: mask = weights > 1e-4).  Ballot compaction in ROW ORDER, ONE launch: a block counts the live rows
-// of its 4096-row chunk, publishes the count with a ready bit, and takes the sum of the EARLIER chunks' counts as its base -- it
-// waits for those that are not published yet (every block of the launch is resident: at most 1024 blocks of 256 threads, and a
-// block only waits for chunks with a lower index, whose blocks need nothing from it).  The compact order is a pure function of w_row --
-// the colour head sees its rows, and forms its weight-gradient partial sums, in the same order every run.  The last block to
-// finish clears the scratch again (arrival ticket behind the counts): `chunk_ws` must be ZERO before the first launch only.
-// (Round 3: a count kernel + a write kernel, 7 us each at any batch size.)
+// live = w > thresh (renderer: mask = weights > 1e-4).  Ballot compaction in ROW ORDER: pass 1 counts the live rows of every
+// 4096-row chunk, pass 2 re-derives the bits, takes the sum of the earlier chunks' counts as its base (<= 512 chunks at 2^21
+// rows: one coalesced read per block) and writes.  The compact order is a pure function of w_row -- the color head sees its rows,
+// and forms its weight-gradient partial sums, in the same order every run (round 2 handed out chunk bases with a returning
+// atomic: block arrival order).
 #define COMPACT_ITERS 16
 #define COMPACT_CHUNK (256 * COMPACT_ITERS)
-#define COMPACT_READY 0x40000000
-__global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ w_row, int rows, float thresh, int* __restrict__ chunk_ws,
-                                                     int* __restrict__ n_live, int* __restrict__ live_idx, int* __restrict__ cidx_row) {
-  __shared__ int s_cnt[4], s_part[4], s_last;
+__global__ __launch_bounds__(256) void k_compact_count(const float* __restrict__ w_row, int rows, float thresh, int* __restrict__ chunk_cnt) {
+  __shared__ int s_cnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
-  // (a block takes its chunks in increasing order and only ever waits for LOWER chunks, which resident blocks are working on)
   for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-  const int r0 = ch * COMPACT_CHUNK + wave * 64 * COMPACT_ITERS;  // each wave owns a contiguous 1024-row span
-  unsigned bits = 0; int cnt = 0;
+    const int r0 = ch * COMPACT_CHUNK + wave * 64 * COMPACT_ITERS;
+    int cnt = 0;
 #pragma unroll
-  for (int i = 0; i < COMPACT_ITERS; ++i) {
-    int r = r0 + i * 64 + lane;
-    bool live = r < rows && w_row[r] > thresh;
-    bits |= (unsigned)live << i;
-    cnt += __popcll(__ballot(live));
-  }
-  if (lane == 0) s_cnt[wave] = cnt;
-  __syncthreads();
-  const int mine = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-  if (threadIdx.x == 0) __hip_atomic_store(chunk_ws + ch, mine | COMPACT_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  // base = number of live rows in chunks [0, ch): integer sum, any order gives the same value
-  int part = 0;
-  for (int q = threadIdx.x; q < ch; q += 256) {
-    int v;
-    while (!((v = __hip_atomic_load(chunk_ws + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & COMPACT_READY)) __builtin_amdgcn_s_sleep(2);
-    part += v & (COMPACT_READY - 1);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-  if (lane == 0) s_part[wave] = part;
-  __syncthreads();
-  int off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-  if (ch == nchunks - 1 && threadIdx.x == 0) *n_live = off + mine;
-  for (int w = 0; w < wave; ++w) off += s_cnt[w];
-#pragma unroll
-  for (int i = 0; i < COMPACT_ITERS; ++i) {
-    int r = r0 + i * 64 + lane;
-    bool live = (bits >> i) & 1u;
-    unsigned long long m = __ballot(live);
-    if (r < rows) {
-      int ci = live ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
-      cidx_row[r] = ci;
-      if (live) live_idx[ci] = r;
+    for (int i = 0; i < COMPACT_ITERS; ++i) {
+      const int r = r0 + i * 64 + lane;
+      cnt += __popcll(__ballot(r < rows && w_row[r] > thresh));
     }
-    off += __popcll(m);
-  }
-  __syncthreads();   // (s_cnt / s_part are rewritten by the block's next chunk)
-  }
-  // arrival: every block has read the counts it needs before it gets here; the last one leaves the scratch zeroed for the next launch
-  if (threadIdx.x == 0) {
-    const int ticket = __hip_atomic_fetch_add(chunk_ws + nchunks, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = ticket == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (s_last) {
-    for (int q = threadIdx.x; q <= nchunks; q += 256) __hip_atomic_store(chunk_ws + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[ch] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
   }
 }
-// chunk_ws: caller-owned scratch of aln_compact_live_ws_ints(rows) int32 (per-chunk counts + the arrival ticket), ZERO before the
-// first call; the kernel leaves it zero
-extern "C" int32_t aln_compact_live_ws_ints(int32_t rows) { return rows > 0 ? (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK + 1 : 0; }
+__global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ w_row, int rows, float thresh, const int* __restrict__ chunk_cnt,
+                                                     int* __restrict__ n_live, int* __restrict__ live_idx, int* __restrict__ cidx_row) {
+  __shared__ int s_cnt[4], s_part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    // base = number of live rows in chunks [0, ch): integer sum, any order gives the same value
+    int part = 0;
+    for (int q = threadIdx.x; q < ch; q += 256) part += chunk_cnt[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const int r0 = ch * COMPACT_CHUNK + wave * 64 * COMPACT_ITERS;  // each wave owns a contiguous 1024-row span
+    unsigned bits = 0; int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < COMPACT_ITERS; ++i) {
+      int r = r0 + i * 64 + lane;
+      bool live = r < rows && w_row[r] > thresh;
+      bits |= (unsigned)live << i;
+      cnt += __popcll(__ballot(live));
+    }
+    if (lane == 0) { s_cnt[wave] = cnt; s_part[wave] = part; }
+    __syncthreads();
+    int off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    for (int w = 0; w < wave; ++w) off += s_cnt[w];
+    if (ch == nchunks - 1 && threadIdx.x == 0) *n_live = s_part[0] + s_part[1] + s_part[2] + s_part[3] + s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+    for (int i = 0; i < COMPACT_ITERS; ++i) {
+      int r = r0 + i * 64 + lane;
+      bool live = (bits >> i) & 1u;
+      unsigned long long m = __ballot(live);
+      if (r < rows) {
+        int ci = live ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+        cidx_row[r] = ci;
+        if (live) live_idx[ci] = r;
+      }
+      off += __popcll(m);
+    }
+    __syncthreads();
+  }
+}
+// chunk_ws: caller-owned scratch of aln_compact_live_ws_ints(rows) int32 (the per-chunk counts between the two passes)
+extern "C" int32_t aln_compact_live_ws_ints(int32_t rows) { return rows > 0 ? (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK : 0; }
 extern "C" int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx,
                                 int32_t* cidx_row, int32_t* chunk_ws, void* stream) {
   ALN_REQUIRE(w_row && n_live && live_idx && cidx_row && chunk_ws, "compact_live: NULL pointer");
   if (rows <= 0) { hipMemsetAsync(n_live, 0, sizeof(int), (hipStream_t)stream); return 0; }
   const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
-  hipLaunchKernelGGL(k_compact_live, dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh, chunk_ws, n_live, live_idx, cidx_row);
+  hipLaunchKernelGGL(k_compact_count, dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh, chunk_ws);
+  ALN_CHECK_LAUNCH("compact_count");
+  hipLaunchKernelGGL(k_compact_live, dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh,
+                     (const int*)chunk_ws, n_live, live_idx, cidx_row);
   ALN_CHECK_LAUNCH("compact_live");
   return 0;
 }

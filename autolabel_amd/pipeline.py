@@ -423,7 +423,7 @@ class HipPipeline:
         # color head on live samples only (models.py:195-203)
         n_live, live_idx, cidx = g('n_live', (1,), i32_), g('live_idx', (M,), i32_), g('cidx_row', (M,), i32_)
         c.update(n_live=n_live, live_idx=live_idx, cidx_row=cidx)
-        chunk_ws = ws.zeros('compact_ws', (max(int(H.lib().aln_compact_live_ws_ints(M)), 1),), i32_)   # zero once; the kernel leaves it zero
+        chunk_ws = g('compact_ws', (max(int(H.lib().aln_compact_live_ws_ints(M)), 1),), i32_)
         H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(chunk_ws), H.stream())
         cs = nets['color']
         cin = c['color_in'] = g('color_in', (M, cs.in_pad), f16)

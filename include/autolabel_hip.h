@@ -226,8 +226,7 @@ int32_t aln_sem_heads_bwd_slabs(const AlnMlpDesc* semf, const AlnMlpDesc* semo, 
  * gather + SH(dir) ++ geo_feat), :248-256 (cat[relu(f), geo_feat]) and the matching gradient assembly */
 int aln_sigma_act(const void* sigma_out /*[rows,16] f16*/, int32_t rows, float* sigma, void* stream);
 /* live rows (w_row > thresh: the renderer's `weights > 1e-4` mask, autolabel/models.py:199-203) compacted in row order (a pure
- * function of w_row: deterministic), one launch; chunk_ws = aln_compact_live_ws_ints(rows) int32 of caller-owned scratch that must
- * be ZERO before the first call (the kernel leaves it zero) */
+ * function of w_row: deterministic); chunk_ws = aln_compact_live_ws_ints(rows) int32 of caller-owned scratch */
 int32_t aln_compact_live_ws_ints(int32_t rows);
 int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx, int32_t* cidx_row,
                      int32_t* chunk_ws, void* stream);
