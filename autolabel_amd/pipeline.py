@@ -454,10 +454,11 @@ class HipPipeline:
             elif c['sem_wide']:
                 logits, feat, c['wide_saved'] = self.wide_sem_fwd(sout, M, lambda n, shp: g(n, shp, f16))
                 c['feat'], c['logits'] = feat, logits
-            elif c['sem_fused'] and train and S1 % 32 == 0 and S2 % 32 == 0 and \
+            elif c['sem_fused'] and S1 % 32 == 0 and S2 % 32 == 0 and \
                     H.lib().aln_sem_heads_bwd_slabs(C.byref(P.descs['semf']), C.byref(P.descs['semo']), M, L.D, L.G) > 0:
-                # the training step: neither f nor the logits are stored -- the forward leaves the weighted sums of every 32-row
-                # tile (one ray each), the one-kernel backward recomputes both and hands the compositing backward its dot products
+                # neither f nor the logits are stored (all anybody needs of them are the per-ray weighted sums): the forward leaves
+                # the weighted sums of every 32-row tile (one ray each); in the training step the one-kernel backward recomputes
+                # both and hands the compositing backward its dot products.  Rendering takes the same path (512 / 128 rows per ray).
                 c['sem_sums'] = True
                 feat = logits = c['feat'] = c['logits'] = None
                 tile_sums = g('sem_tile_sums', (M // 32, 96), f32_)

@@ -347,22 +347,36 @@ def test_adam_step_matches_torch_adam_and_skips_on_inf():
 
 
 def test_inference_and_training_forward_agree_bitwise():
-    """train=False skips the color_in tensor (inputs built inside the color kernel): same bits.  The semantic outputs of the training
-    forward are the same sums in another order (per-tile partial sums instead of stored f / logits rows): equal to fp32 rounding, and
-    bitwise when the sample counts rule the tile sums out."""
+    """train=False skips the color_in tensor (inputs built inside the color kernel): same bits -- with the semantic outputs as
+    per-tile sums (sample counts multiples of 32: no f / logits rows in either mode) and as composited rows (other counts); the
+    two forms of the same sums agree to fp32 rounding."""
     _, pipe, _ = build_pair(C_=5)
     o, d, norms = make_rays(600, seed=4)
     od, dd, nd = o.cuda(), d.cuda(), norms.reshape(-1).cuda()
+    got = {}
     for S1, S2, sums in [(64, 32, True), (64, 24, False)]:
         a, ctx = pipe.forward(od, dd, nd, S1, S2, False, train=True)
         assert bool(ctx.get('sem_sums')) == sums
         a = {k: v.clone() for k, v in a.items()}
-        b, _ = pipe.forward(od, dd, nd, S1, S2, False, train=False)
+        b, ctx_b = pipe.forward(od, dd, nd, S1, S2, False, train=False)
+        assert bool(ctx_b.get('sem_sums')) == sums
         for k in a:
-            if sums and k in ('semantic', 'semantic_features'):
-                assert (a[k] - b[k]).abs().max().item() <= 2e-6 * b[k].abs().max().item() + 1e-7, k
-            else:
-                assert torch.equal(a[k], b[k]), k
+            assert torch.equal(a[k], b[k]), k
+    # the row path against the sums path on the same samples: force rows by handing the fused pair a sample count it refuses
+    a, _ = pipe.forward(od, dd, nd, 64, 32, False, train=False)
+    a = {k: v.clone() for k, v in a.items()}
+    from autolabel_amd import hip as hip_mod
+    lib = hip_mod.lib()
+    saved = lib.aln_sem_heads_bwd_slabs
+    try:
+        lib.aln_sem_heads_bwd_slabs = lambda *args: 0
+        b, ctx_b = pipe.forward(od, dd, nd, 64, 32, False, train=False)
+    finally:
+        lib.aln_sem_heads_bwd_slabs = saved
+    assert not ctx_b.get('sem_sums')
+    for k in ('semantic', 'semantic_features'):
+        assert (a[k] - b[k]).abs().max().item() <= 2e-6 * b[k].abs().max().item() + 1e-7, k
+    assert torch.equal(a['image'], b['image'])
 
 
 def test_diverged_field_does_not_corrupt_memory():
