@@ -158,15 +158,6 @@ class Workspace:
             self.generation += 1
         return self.bufs[name][1]
 
-    def zeros(self, name, shape, dtype):
-        """A buffer that is zero when first handed out (kernels that keep a self-resetting scratch: tickets, ready flags)."""
-        key = (name, tuple(shape), dtype)
-        t = self.bufs.get(name)
-        if t is None or t[0] != key:
-            self.bufs[name] = (key, torch.zeros(shape, dtype=dtype, device=self.device))
-            self.generation += 1
-        return self.bufs[name][1]
-
     def scratch(self, name, nbytes):
         """Byte scratch that only ever grows (callers with varying sizes share one allocation)."""
         t = self.bufs.get(name)
