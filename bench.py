@@ -51,6 +51,8 @@ def parse():
     p.add_argument('--event-steps', type=int, default=20, help='launch-by-launch steps with HIP events (roofline); 0 = skip')
     p.add_argument('--quality-steps', type=int, default=1500, help='total optimizer steps before the held-out metrics; 0 = skip')
     p.add_argument('--quality-seeds', type=int, default=3, help='runs (seed sets) the reported quality is the mean / min over')
+    p.add_argument('--dp-leg-timeout', type=float, default=300.0, help='--gpus N: seconds a data-parallel leg may take before the watchdog prints the best finished leg and exits')
+    p.add_argument('--dp-tail-timeout', type=float, default=1200.0, help='--gpus N: the same for everything after the legs')
     p.add_argument('--no-march', action='store_true', help='skip the occupancy-grid marching leg (second config)')
     p.add_argument('--march-samples', type=int, default=64)
     p.add_argument('--march-thresh', type=float, default=10.0)
@@ -666,11 +668,43 @@ def main():
         a2.event_steps = 0
         dp_legs, best = {}, None
         can_graph = not args.no_graph and backend == 'nccl'   # (gloo collectives cannot be captured)
-        plan = ([('dp_simple', False, False, False), ('dp_overlap', True, False, False)] + ([('dp_graph', True, True, False)] if can_graph else []) +
-                [('dp_sharded', True, False, True)] + ([('dp_sharded_graph', True, True, True)] if can_graph else []))
+        # (the eager legs first: a capture that goes wrong can then only cost the graph legs)
+        plan = ([('dp_simple', False, False, False), ('dp_overlap', True, False, False), ('dp_sharded', True, False, True)] +
+                ([('dp_graph', True, True, False), ('dp_sharded_graph', True, True, True)] if can_graph else []))
+
+        # A collective that never returns (a rank lost, a communicator poisoned by a failed capture) would take the line with it: every
+        # leg, and the rest of the run after the legs, runs under a watchdog that prints the line of the best leg finished so far
+        # (rank 0) and ends the process on every rank.
+        def fallback_line(why):
+            line = {'metric': 'train rays/sec (640x480 synthetic RGB-D scene, hg+freq, DINO-like features)', 'value': None, 'unit': 'rays/s',
+                    'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True,
+                    'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+                    'config': {'workload': "S1 synthetic room standing in for the 'bench' scene: %d frames 640x480 trained at factor 2, " % args.frames +
+                                           'DINO-like 64-d features, hg+freq L=16 T=2^19, 128+128 samples/ray',
+                               'rays_per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}', 'dp_leg': best[0] if best else None},
+                    'n_ranks_seen': n_ranks_seen, 'dp_legs': dp_legs, 'watchdog': why}
+            if best:
+                line.update(value=B * world * args.steps / best[1][0], ms_per_step=1000 * best[1][0] / args.steps)
+            else:
+                line['error'] = 'no data-parallel leg finished'
+            return line
+
+        def watchdog(seconds, why):
+            import threading
+
+            def fire():
+                if rank == 0:
+                    print(json.dumps(fallback_line(why)), flush=True)
+                os._exit(0 if best else 1)
+            t = threading.Timer(seconds, fire)
+            t.daemon = True
+            t.start()
+            return t
         for name, overlap, graph, shard in plan:
             ok, leg = 1, None
             info = {'overlap_comm': overlap, 'hip_graph': graph, 'shard_optimizer': shard}
+            dp_legs[name] = dict(info, error='did not finish (watchdog)')
+            guard = watchdog(args.dp_leg_timeout, f'leg {name} did not finish within {args.dp_leg_timeout} s')
             try:
                 e = wl.engine(SEEDS[0][0], world=world, pg=pg, overlap_comm=overlap, shard_optimizer=shard)
                 leg = timed_leg(wl, a2, e, B, dseed, mseed, frange, graph, world, sync)
@@ -685,6 +719,7 @@ def main():
             except Exception as ex:
                 dp_legs[name].setdefault('error', f'agreement all-reduce failed: {ex}'[:200])
                 ok = 0
+            guard.cancel()
             dp_legs[name]['finished_on_every_rank'] = bool(ok)
             if ok and leg is not None and (best is None or leg[0] < best[1][0]):
                 best = (name, leg, e)
@@ -698,6 +733,7 @@ def main():
             sys.exit(1)
         (dp_best, (dt, terms, events, step, done), eng) = best
         use_graph = dp_legs[dp_best]['hip_graph']
+        tail_guard = watchdog(args.dp_tail_timeout, f'the run after the legs (quality steps, held-out render) did not finish within {args.dp_tail_timeout} s')
     rays_per_s = B * world * args.steps / dt
     live_rows = float(eng.ws.get('n_live', (1,), torch.int32).item())   # color-head rows of the last step (w > 1e-4)
     roof = scatter_roofline(eng, events, B * (eng.S1 + eng.S2), args.event_steps) if events else None
@@ -771,8 +807,11 @@ def main():
                 res['cpu_baseline'] = cpu_baseline(wl, args)
         else:
             res['render_Mrays_per_s'] = res['render_dense_Mrays_per_s'] = render_dense
+        if world > 1:
+            tail_guard.cancel()
         print(json.dumps(res), flush=True)
     if world > 1:
+        tail_guard.cancel()
         torch.distributed.destroy_process_group()
 
 

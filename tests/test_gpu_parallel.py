@@ -337,3 +337,25 @@ def test_bench_contract_with_two_ranks_sharing_the_device():
     assert d['n_ranks_seen'] == 2 and d['value'] > 0 and d['higher_is_better'] is True
     assert abs(d['value'] - 2 * 512 * 4 / (d['ms_per_step'] * 4e-3)) <= 1e-6 * d['value'], 'value = rays of ALL ranks / max-over-ranks time'
     assert d['config']['gradient_exchange_bytes_per_rank_and_step'] > 0 and d['config']['parallelism'] == 'dp2'
+
+
+def test_bench_watchdog_prints_a_line_when_a_leg_never_finishes():
+    """A collective that never returns must not cost the JSON line: with a leg timeout far below a leg's duration the watchdog fires
+    in the first leg, rank 0 prints ONE line naming the watchdog, and every rank ends (no leg finished: exit code 1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALN_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+           '--batch', '512', '--no-cpu-baseline', '--no-pmc', '--no-march', '--no-lseg', '--quality-steps', '0', '--render-frames', '0',
+           '--event-steps', '0', '--dp-leg-timeout', '0.05']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert 'watchdog' in d and d['value'] is None and d['n_gpus'] == 2 and 'dp_simple' in d['dp_legs']
+    assert r.returncode != 0
