@@ -65,6 +65,9 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
   const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (rows_dev) rows = min(rows, *rows_dev);
+  // no live row (a batch whose compositing weights are all below the threshold): the clamped row index of the prefetch below would
+  // be -1 and the requests would read up to 4 KB BEFORE the input buffer (a memory access fault when that page is unmapped)
+  if (rows <= 0) return;
   const h16x8* frag = (const h16x8*)wf;
   constexpr int F1 = NB * KS0, FL = F1 + NB * KS;
   h16x8 W0[NB][KS0], W1[NB][KS], W2[KS];

@@ -116,10 +116,13 @@ class IndexSampler:
         self.image_weights = {}  # class id -> probability per image
         self.has_semantics = False
         self.image_range = np.array([])
+        self.version = 0         # counts update() calls: every label-edit route of the reference ends in one (semantic_map_updated,
+                                 # update_sampler), so a device-resident copy of the labels knows when it is stale (trainer.resident_loader)
 
     def update(self, semantic_maps):
         """0 is the null class, 1 background, 2.. object classes."""
         assert len(semantic_maps.shape) == 2
+        self.version += 1
         labels = np.unique(semantic_maps)
         self.classes = labels[labels != 0]
         n = len(semantic_maps)
@@ -456,6 +459,9 @@ class DeviceFrames:
         classes = np.unique(sem)
         classes = classes[classes != 0]
         fr = self.desc
+        # the descriptor is passed BY VALUE into aln_raygen_train: a captured step keeps the old pointers / class count, so whoever
+        # replays one compares `version` (engine.TrainEngine.graphed's guard)
+        self.version = getattr(self, 'version', 0) + 1
         fr.n_classes, fr.sem_ratio = 0, 0.0
         if len(classes) == 0:
             return

@@ -18,7 +18,7 @@ class TrainEngine:
     def __init__(self, pipe, lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6, rgb_weight=1.0, depth_weight=0.1,
                  semantic_weight=1.0, feature_weight=0.5, feature_loss=False, num_steps=128, upsample_steps=128,
                  scaler=None, process_group=None, overlap_comm=True, grad_payload='f16', fuse_grid_adam=True, shard_optimizer=False,
-                 shard_gather='table'):
+                 shard_gather='table', exchange_at_world_1=False):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
         dv = self.P.device
         # the step's intermediates live in a workspace of the engine's own: a render through the same pipeline (pipe.ws) between
@@ -37,6 +37,11 @@ class TrainEngine:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
+        # `dp`: the step takes the data-parallel route (gradient through P.grad, collectives, separate optimizer pass).  With
+        # exchange_at_world_1 a process group of ONE rank takes it too: every collective is then really issued (RCCL communicator
+        # set-up, AVG, in-place reduce-scatter / all-gather, stream ordering, hipGraph capture with collectives) although it moves
+        # nothing -- how the RCCL code is exercised on a box with one GPU (tests/test_gpu_rccl.py)
+        self.dp = self.world > 1 or (bool(exchange_at_world_1) and process_group is not None)
         # Sharded optimizer (data parallel only): every rank owns 1 / world of every hash-grid gradient bucket -- reduce-scatter
         # instead of all-reduce, Adam on the owned slices with moments allocated for those slices only, all-gather of the updated
         # fp16 table.  The fp32 masters of the other ranks' slices go stale in P.flat until sync_master() (checkpoints).
@@ -45,7 +50,7 @@ class TrainEngine:
         assert shard_gather in ('table', 'master')
         self.shard_gather = shard_gather
         self.shard = None
-        if shard_optimizer and self.world > 1 and self.L.n_grid > 0:
+        if shard_optimizer and self.dp and self.L.n_grid > 0:
             from .parallel import shard_range
             F, g = int(self.L.enc.grid.n_features), self.L.enc.grid
             nl = int(g.n_levels)
@@ -74,12 +79,12 @@ class TrainEngine:
         pipe.found_inf = self.state_i[2:3]
         # data parallel: the gradient all-reduce runs in buckets on a side stream while the hash-grid scatter is still
         # working on the remaining levels (the scatter is the last and longest kernel of the backward pass)
-        self.overlap_comm = self.world > 1 and bool(overlap_comm)   # False: one collective after the backward pass
+        self.overlap_comm = self.dp and bool(overlap_comm)   # False: one collective after the backward pass
         # single GPU: the scatter's second phase holds the table's exact gradient sums in LDS and takes the Adam step for the table
         # itself (step()); with more ranks the gradient has to be averaged first, so it goes through P.grad and aln_adam_step
-        self.fuse_grid_adam = bool(fuse_grid_adam) and self.world == 1 and L.n_grid > 0 and int(L.enc.grid.n_features) == 2
+        self.fuse_grid_adam = bool(fuse_grid_adam) and not self.dp and L.n_grid > 0 and int(L.enc.grid.n_features) == 2
         self.grad_payload = grad_payload     # 'f16': the hash-grid gradient crosses the wire as fp16 (parallel.allreduce_bucket)
-        self._comm = torch.cuda.Stream(device=dv) if self.world > 1 else None
+        self._comm = torch.cuda.Stream(device=dv) if self.dp else None
         self._g = {}
         # occupancy-grid marching (pipe.occ set by enable_marching / ALNetwork(cuda_ray=True)): S1 rows per ray inside occupied
         # cells, no importance pass; the density grid is refreshed every occ.update_interval steps (autolabel/trainer.py:34-36)
@@ -126,7 +131,7 @@ class TrainEngine:
                H.ptr(out['semantic_features']), H.ptr(batch['pixels']), H.ptr(batch['depth']), H.ptr(batch['semantic']),
                H.ptr(gt_feat), N, L.C, L.D, Cf, w[0], w[1], w[2], w[3] if gt_feat is not None else 0.0, H.ptr(self.state_f),
                H.ptr(self.counts), H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem), H.ptr(g_feat), H.ptr(self.terms), H.stream())
-        if self.world > 1 and self.overlap_comm:
+        if self.dp and self.overlap_comm:
             self._reduced = True
             # the scatter raises its own flag word: the MLP bucket's tail overwrites state_i[2] on the communication stream while
             # the scatter is still running on the compute stream, so a flag stored there in between could be lost
@@ -139,7 +144,7 @@ class TrainEngine:
 
     def _adam_fuse(self):
         P, L = self.P, self.L
-        assert self.world == 1 and self._blk_end[0] == L.n_grid and self._blk_kind[0] == 0
+        assert not self.dp and self._blk_end[0] == L.n_grid and self._blk_kind[0] == 0
         return H.AlnAdamFuse(P.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), P.table16.data_ptr(), self.state_i.data_ptr(),
                              self.state_f.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps)
 
@@ -163,7 +168,7 @@ class TrainEngine:
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ev)
             if kind == 'mlp':   # MLP block + the overflow flag in the tail element (every rank must skip the same steps)
-                allreduce_bucket(self.P.grad, a, b, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts)
+                allreduce_bucket(self.P.grad, a, b, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts, force=True)
             else:
                 self._exchange_grid(a, b)
                 if a == 0:
@@ -179,7 +184,7 @@ class TrainEngine:
         """One hash-grid bucket over the ranks on the current stream: all-reduce, or reduce-scatter under the sharded optimizer."""
         from .parallel import allreduce_bucket, reduce_scatter_bucket, shard_range
         if self.shard is None:
-            allreduce_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire(b - a), flag=self.state_i[3:4])
+            allreduce_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire(b - a), flag=self.state_i[3:4], force=True)
         else:
             S = shard_range(a, b, self.rank, self.world)[2]
             reduce_scatter_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire((self.world + 1) * S), flag=self.state_i[3:4])
@@ -197,12 +202,12 @@ class TrainEngine:
         """Average every gradient over the ranks.  With overlap the buckets are already in flight on the communication
         stream and this only makes the compute stream wait for them; otherwise ONE collective over the flat buffer with
         the overflow flag riding in its tail."""
-        if self.world > 1:
+        if self.dp:
             if self._reduced:
                 torch.cuda.current_stream().wait_stream(self._comm)
             elif self.shard is not None:   # the same collectives as the overlapped path, one after the other on this stream
                 from .parallel import allreduce_bucket
-                allreduce_bucket(self.P.grad, self.L.n_grid, self.L.n_total, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts)
+                allreduce_bucket(self.P.grad, self.L.n_grid, self.L.n_total, self.pg, found_inf=self.state_i[2:3], tail=self.L.n_total, counts=self.counts, force=True)
                 for a, b in self.shard['buckets']:
                     self._exchange_grid(a, b)
                 flag = self.state_i[3:4].to(torch.float32)
@@ -212,7 +217,7 @@ class TrainEngine:
             else:
                 from .parallel import allreduce_gradients
                 allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts, n_grid=self.L.n_grid,
-                                    payload=self.grad_payload, scratch=self._wire(self.L.n_grid))
+                                    payload=self.grad_payload, scratch=self._wire(self.L.n_grid), force=True)
 
     def optimizer_step(self, step_dev=None, skip_grid=False):
         P, L, sc = self.P, self.L, self.scaler_cfg
@@ -229,6 +234,7 @@ class TrainEngine:
                 return
             for a, b in sh['buckets']:     # the updated fp16 table of every owner (a skipped step gathers the unchanged table)
                 allgather_bucket(P.table16, a, b, self.pg, scratch=self._g.get('wire'))
+            P.masters_stale = True         # (until sync_master: state_dict / shadow refreshes refuse to read the masters)
             P.refresh_shadows(grid=False)
             return
         H.call('aln_adam_step', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
@@ -262,7 +268,7 @@ class TrainEngine:
         def body(step_dev):
             frames.next_train(batch, seed=data_seed, step=first_step, frame_range=frame_range, step_dev=step_dev)
             self.step(batch, seed=seed, step=first_step, step_dev=step_dev, grid_update=False)
-        guard = lambda: (self.ws.generation, batch['rays_o'].data_ptr())
+        guard = lambda: (self.ws.generation, batch['rays_o'].data_ptr(), getattr(frames, 'version', 0))
         if not self.march:
             return GraphedStep(body, self.P.device, warmup=warmup, guard=guard)
         # marching: every update_interval-th step starts with the density-grid refresh (see maybe_update_grid); that
@@ -280,6 +286,7 @@ class TrainEngine:
             from .parallel import allgather_bucket
             for a, b in self.shard['buckets']:
                 allgather_bucket(self.P.flat, a, b, self.pg)
+            self.P.masters_stale = False
 
     def _full_moments(self, t):
         """Sharded layout [owned slices | MLP] -> the replicated layout [table | MLP] (a collective under the sharded optimizer)."""

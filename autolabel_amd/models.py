@@ -168,6 +168,12 @@ class ALNetwork(NeRFRenderer):
             self._shadow_version = ver
         return self._pipe
 
+    def state_dict(self, *args, **kwargs):
+        if self._P is not None and self._P.masters_stale:
+            raise RuntimeError('ALNetwork.state_dict: the hash table\'s fp32 masters are sharded over the ranks (TrainEngine(shard_optimizer=True)); '
+                               'call TrainEngine.sync_master() on every rank first (Trainer.save_checkpoint does)')
+        return super().state_dict(*args, **kwargs)
+
     def load_state_dict(self, state_dict, strict=True):
         res = super().load_state_dict(state_dict, strict=strict)
         self._shadow_version = None

@@ -6,7 +6,8 @@ The GradScaler overflow flag rides in the tail of the same buffer so every rank 
 
 Sharded optimizer (TrainEngine(shard_optimizer=True)): the all-reduce of every hash-grid bucket is split into its two halves --
 reduce-scatter of the gradient, Adam on the 1 / world slice a rank owns (moments allocated for that slice only), all-gather of the
-updated fp16 table -- same wire bytes, 1 / world of the optimizer's HBM traffic and state.
+updated fp16 table -- same wire bytes, 1 / world of the optimizer's HBM traffic and state (a trainer with an EMA reads the fp32
+masters every step and gathers THOSE instead, shard_gather='master': twice the all-gather bytes).
 """
 import os
 
@@ -84,14 +85,15 @@ def wire_bytes(n_grid, n_total, payload='f16'):
     return n_grid * (2 if payload == 'f16' else 4) + (n_total - n_grid + 2) * 4
 
 
-def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None, n_grid=0, payload='f32', scratch=None):
+def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None, n_grid=0, payload='f32', scratch=None, force=False):
     """Average `grad[:n_total]` over the group in place; `found_inf` (int32[1]) becomes the logical OR over ranks, and so does
     "some rank had labelled rays" (`counts[1] > 0`, which decides whether the semantic heads take an optimizer step).  `grad`
     must have at least two spare elements at index n_total.  payload='f32': ONE collective over the flat buffer.
     payload='f16': the hash-grid block grad[:n_grid] crosses the wire as fp16 (28.5 MB instead of 57 MB at the default model),
-    the small MLP block + flags stay fp32 (two collectives)."""
+    the small MLP block + flags stay fp32 (two collectives).  `force`: issue the collectives for a group of one rank too (they move
+    nothing; TrainEngine(exchange_at_world_1=True) runs the RCCL code this way on a single GPU)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return
     _pack_tail(grad, n_total, found_inf, counts)
     if payload == 'f16' and n_grid > 0:
@@ -103,12 +105,12 @@ def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None, n_gri
     _unpack_tail(grad, n_total, found_inf, counts)
 
 
-def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=None, payload='f32', scratch=None, flag=None):
+def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=None, payload='f32', scratch=None, flag=None, force=False):
     """Average `grad[a:b]` over the group in place (one collective on the current stream).  With `found_inf` the bucket
     must end at `tail` (= n_total): the flags travel in `grad[tail:tail + 2]` and come back as the OR over ranks.
     payload='f16' (hash-grid buckets): fp16 on the wire through `scratch`; `flag` (int32[1]) is raised on a non-finite result."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return
     if found_inf is not None:
         assert b == tail, 'the overflow flag rides right behind the bucket'

@@ -74,6 +74,9 @@ class Params:
         self.grad = torch.zeros(L.n_total + 8, dtype=torch.float32, device=device)  # +8: side channel for DP (found_inf)
         self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
         self.frags, self.descs, self.wide_w, self.wide_wt = {}, {}, {}, {}
+        # sharded table optimizer (engine.TrainEngine(shard_optimizer=True, shard_gather='table')): the fp32 masters of the slices other
+        # ranks own are stale in `flat` until TrainEngine.sync_master() (a collective) -- readers of the masters check this flag
+        self.masters_stale = False
         for k, s in L.nets.items():
             if L.sem_wide and k in ('semf', 'semo'):   # row-major fp16 [out, in] per layer (+ transposes for the data gradients)
                 self.wide_w[k] = [torch.zeros(o, i, dtype=torch.float16, device=device) for o, i in s.shapes]
@@ -120,6 +123,9 @@ class Params:
     def refresh_shadows(self, grid=True):
         """fp32 master -> fp16 table + MFMA fragments (after init / checkpoint load / optimizer step)."""
         L = self.layout
+        if grid and L.n_grid and self.masters_stale:
+            raise RuntimeError('Params.refresh_shadows: the fp32 table masters of the other ranks\' slices are stale (sharded optimizer); '
+                               'call TrainEngine.sync_master() on every rank before anything rewrites or re-reads the parameters')
         if grid and L.n_grid:
             H.call('aln_cast_f16', H.ptr(self.flat), H.ptr(self.table16), L.n_grid, H.stream())
         fused = []
@@ -147,14 +153,46 @@ class Workspace:
     a Workspace of its own (TrainEngine.ws): renders through the same pipeline use ``HipPipeline.ws`` and can never move the
     buffers a captured training step points into."""
 
+    # Debug aid (tests/test_gpu_kernels.py, scripts/dev/stress_determinism.py): with guard_bytes > 0 every buffer is carved out of a
+    # larger allocation with a canary band on either side, and new buffers are filled with NaN bytes (0xFF) instead of being left as
+    # the allocator returned them -- check_guards() then shows a kernel that wrote outside its buffer, and a kernel that READS
+    # scratch it did not write produces NaNs instead of plausible stale values.  Off (0) in the product: plain torch.empty.
+    guard_bytes = 0
+    CANARY = 0xA5
+
     def __init__(self, device):
         self.device, self.bufs, self.generation = device, {}, 0
+        self._guarded = {}
+
+    def _alloc(self, name, shape, dtype):
+        if not Workspace.guard_bytes:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        g = int(Workspace.guard_bytes)
+        assert g % 256 == 0
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        pad = (nbytes + 255) // 256 * 256
+        raw = torch.full((g + pad + g,), Workspace.CANARY, dtype=torch.uint8, device=self.device)
+        raw[g:g + nbytes] = 0xFF
+        self._guarded[name] = (raw, g, nbytes)
+        return raw[g:g + nbytes].view(dtype).reshape(shape)
+
+    def check_guards(self):
+        """Names of the buffers whose canary bands were overwritten (guard_bytes > 0 only)."""
+        bad = []
+        for name, (raw, g, nbytes) in self._guarded.items():
+            lo, hi = raw[:g], raw[g + nbytes:]
+            if bool((lo != Workspace.CANARY).any()) or bool((hi != Workspace.CANARY).any()):
+                bad.append((name, int((lo != Workspace.CANARY).sum()), int((hi != Workspace.CANARY).sum())))
+        return bad
 
     def get(self, name, shape, dtype):
         key = (name, tuple(shape), dtype)
         t = self.bufs.get(name)
         if t is None or t[0] != key:
-            self.bufs[name] = (key, torch.empty(shape, dtype=dtype, device=self.device))
+            self.bufs[name] = (key, self._alloc(name, shape, dtype))
             self.generation += 1
         return self.bufs[name][1]
 
@@ -162,7 +200,7 @@ class Workspace:
         """Byte scratch that only ever grows (callers with varying sizes share one allocation)."""
         t = self.bufs.get(name)
         if t is None or t[1].numel() < nbytes:
-            self.bufs[name] = (('scratch', name), torch.empty(int(nbytes), dtype=torch.uint8, device=self.device))
+            self.bufs[name] = (('scratch', name), self._alloc(name, (int(nbytes),), torch.uint8))
             self.generation += 1
         return self.bufs[name][1]
 

@@ -171,6 +171,10 @@ class Trainer:
             return dataloader
         ds = getattr(dataloader, '_data', None)
         if self._resident is not None and self._resident[0] is ds:
+            # the reference's label-edit flows only touch the host dataset (scripts/simulate_user.py:89 update_sampler(), backend.py:155
+            # semantic_map_updated()); both end in IndexSampler.update, whose call count says when the device copy is stale
+            if getattr(ds.index_sampler, 'version', 0) != self._resident[2]:
+                self.refresh_resident_labels()
             return self._resident[1]
         ok = isinstance(ds, BaseDataset) and not isinstance(ds, DynamicDataset) and isinstance(getattr(ds, 'images', None), np.ndarray)
         if ok:
@@ -188,17 +192,19 @@ class Trainer:
         loader = DeviceLoader(ds.device_frames(self.device), ds.batch_size, length, seed=parallel.rank_seed(0, self.local_rank),
                               frame_range=parallel.frame_shard(ds.n_examples, self.local_rank, self.world_size))
         loader._data = ds
-        self._resident = (ds, loader)
+        self._resident = (ds, loader, getattr(ds.index_sampler, 'version', 0))
         self.log(f'[INFO] {ds.n_examples} frames resident in HBM ({need / 2 ** 20:.0f} MB): batches are assembled on the device')
         return loader
 
     def refresh_resident_labels(self):
         """Re-upload the semantic maps and the class index after the labels changed on the host (semantic_map_updated)."""
         if self._resident is not None:
-            ds, loader = self._resident
+            ds, loader = self._resident[:2]
             fr = loader.frames
             fr.semantics.copy_(torch.as_tensor(ds.semantics).reshape(fr.semantics.shape))
             fr.set_class_index(ds.semantics)
+            self._resident = (ds, loader, getattr(ds.index_sampler, 'version', 0))
+            self._graph = None    # the captured step holds the old class-index pointers and class count by value
 
     def _to_device_batch(self, data):
         as_t = lambda v, dt: torch.as_tensor(v).to(self.device, dtype=dt, non_blocking=True).contiguous()
@@ -347,6 +353,7 @@ class SimpleTrainer(Trainer):
         if cur is None or cur[0] is not loader or cur[1] is not eng or not cur[2].valid():
             if iterations <= 0:
                 return eng.terms[4]
+            err = g = None
             try:
                 g = eng.graphed(loader.frames, loader.batch, loader.seed, self.model._seed, frame_range=loader.frame_range,
                                 first_step=self.global_step, warmup=1)
@@ -355,12 +362,25 @@ class SimpleTrainer(Trainer):
                     self.log(f'[WARN] hipGraph replay disabled, stepping launch by launch: {e}')
                     self._graph_warned = True
                 self.use_graph = False
-                return None
+                err = e
             except Exception as e:
                 if self.world_size == 1:
                     raise
-                self.log(f'[WARN] the data-parallel step could not be captured ({type(e).__name__}: {e}); stepping launch by launch')
-                self.use_graph_dp = False
+                err = e
+            if self.world_size > 1:
+                # the fallback is a GROUP decision: a rank stepping launch by launch beside ranks that replay captured collectives
+                # would issue another collective sequence and hang the job instead of degrading it
+                ok = torch.tensor([0.0 if err is not None else 1.0], device=self.device)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+                if float(ok.item()) == 0.0:
+                    why = f'{type(err).__name__}: {err}' if err is not None else 'another rank could not capture it'
+                    self.log(f'[WARN] the data-parallel step could not be captured ({why}); every rank steps launch by launch')
+                    self.use_graph_dp = False
+                    if g is not None:     # this rank's warm-up steps did run
+                        self.global_step += g.steps
+                        loader.step += g.steps
+                    return None
+            elif err is not None:
                 return None
             self.global_step += g.steps
             loader.step += g.steps

@@ -689,13 +689,16 @@ def main():
                 line['error'] = 'no data-parallel leg finished'
             return line
 
-        def watchdog(seconds, why):
-            import threading
+        import threading
+        line_lock = threading.Lock()     # ONE JSON line: the watchdog's fallback and the normal print exclude each other
 
+        def watchdog(seconds, why):
             def fire():
+                # a hang is a failure for the launcher even when a finished leg gives the line a value (exit code 3; 1 = no leg at all)
+                line_lock.acquire()
                 if rank == 0:
                     print(json.dumps(fallback_line(why)), flush=True)
-                os._exit(0 if best else 1)
+                os._exit(3 if best else 1)
             t = threading.Timer(seconds, fire)
             t.daemon = True
             t.start()
@@ -809,6 +812,7 @@ def main():
             res['render_Mrays_per_s'] = res['render_dense_Mrays_per_s'] = render_dense
         if world > 1:
             tail_guard.cancel()
+            line_lock.acquire()    # (never released: a watchdog already past its cancel point must not print a second line)
         print(json.dumps(res), flush=True)
     if world > 1:
         tail_guard.cancel()

@@ -18,3 +18,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+_LAST = ('test_gpu_quality.py', 'test_gpu_rccl.py', 'test_parallel_gloo.py', 'test_gpu_parallel.py')
+
+
+def pytest_collection_modifyitems(session, config, items):
+    """With `-x`, a failure in the multi-process data-parallel tests must not hide the single-GPU rows (8a R1-R15):
+    the long quality gate and the multi-process files are collected last, whatever their names sort as."""
+    rank = lambda it: next((i + 1 for i, name in enumerate(_LAST) if it.nodeid.split('::')[0].endswith(name)), 0)
+    items.sort(key=rank)      # (stable: the order inside a file and among the other files is kept)

@@ -492,6 +492,36 @@ def test_host_loader_over_a_dataset_is_replaced_by_device_resident_frames():
             ds.index_sampler.update(ds.semantics)
 
 
+def test_label_edits_on_the_host_dataset_reach_the_captured_step():
+    """The reference's label-edit flows only touch the host dataset (scripts/simulate_user.py:89 update_sampler(), backend.py:155
+    semantic_map_updated()) and never tell the trainer.  The device-resident copy follows the IndexSampler's update count, and the
+    captured step -- which holds the class-index pointers and the class count BY VALUE -- is captured again."""
+    from autolabel_amd.dataset import DeviceLoader, LenDataset
+    ds, _ = _host_batches(1, B=512)
+    ds.semantics[:] = 0                       # no labels at all to begin with
+    ds.index_sampler.update(ds.semantics)
+    bound = float(((ds.max_bounds - ds.min_bounds) - (ds.min_bounds + ds.max_bounds) * 0.5).max())
+    torch.manual_seed(0)
+    tr = _trainer(make_model(D=64, C_=7, bound=bound, grid_scale=1.0), True)
+    loader = torch.utils.data.DataLoader(LenDataset(ds, 1000), batch_size=None, num_workers=0)
+    loader._data = ds
+    tr.train_iterations(loader, 3)
+    used = tr.resident_loader(loader)
+    assert isinstance(used, DeviceLoader) and tr._graph is not None
+    g0 = tr._graph[2]
+    assert int(used.frames.desc.n_classes) == 0 and bool((used.batch['semantic'] == -1).all())
+    ds.semantics[1, :100] = 3                 # the user paints 100 pixels of frame 1 (class 3 -> label 2 in the batch) ...
+    ds.index_sampler.update(ds.semantics)     # ... and the host flow refreshes the sampler; nobody calls the trainer
+    seen = False
+    for _ in range(8):                        # a 512-ray batch is one chunk: class-weighted with probability 0.5 (dataset.py:207-211)
+        tr.train_iterations(loader, 1)
+        seen |= bool((used.batch['semantic'] == 2).all())
+    assert tr.resident_loader(loader) is used and tr._graph[2] is not g0, 'the step must be captured again after the class index moved'
+    assert int(used.frames.desc.n_classes) == 1 and int(used.frames.semantics.reshape(ds.n_examples, -1)[1, :100].min()) == 3
+    assert seen, 'no class-weighted chunk drew from the newly labelled pixels in 8 steps'
+    assert np.isfinite(float(tr.engine.terms[4])) and int(tr.engine.state_i[0]) == 11
+
+
 def test_interactive_trainer_and_eval_steps():
     """InteractiveTrainer.init/take_step (GUI / ROS loop) and SimpleTrainer.test_step / eval_step / evaluate shapes."""
     from autolabel_amd.trainer import InteractiveTrainer

@@ -16,6 +16,22 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _block_checksums(layout, *bufs):
+    """(names, device int64 scalars): the wrapped sum of the bit patterns of every hash-grid level and every MLP block of each buffer
+    (no host sync: the values are read after the last step)."""
+    g, F = layout.enc.grid, 2
+    nl = int(g.n_levels)
+    spans = [(f'level{l:02d}', int(g.offset[l]) * F, int(g.offset[l + 1]) * F if l + 1 < nl else layout.n_grid) for l in range(nl)]
+    spans += [(k, layout.offsets[k], layout.offsets[k] + layout.nets[k].n_params) for k in layout.nets]
+    names, sums = [], []
+    for which, buf in zip(('p', 'm', 'v'), bufs):
+        bits = buf.view(torch.int32)
+        for name, a, b in spans:
+            names.append(f'{which}/{name}')
+            sums.append(bits[a:b].to(torch.int64).sum())
+    return names, sums
+
+
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
     dist.init_process_group('gloo')
@@ -41,9 +57,11 @@ def _worker(rank, world, port, ret):
             eng._bucket_ready = lambda kind, a, b: (buckets.append((kind, a, b)), inner(kind, a, b))[1]
         lo, hi = parallel.frame_shard(8, rank, world)
         batch = frames.alloc_batch(1024)
-        for i in range(3):
+        trail = []     # per step: a bit-exact checksum of every parameter block (and of the Adam moments), so that a divergence between the
+        for i in range(3):   # two exchange modes is reported with the step and the block it started in
             frames.next_train(batch, seed=parallel.rank_seed(5, rank), step=i, frame_range=(lo, hi))
             eng.step(batch, seed=parallel.rank_seed(7, rank), step=i)
+            trail.append(_block_checksums(layout, P.flat, eng.m, eng.v))
         torch.cuda.synchronize()
         flat = P.flat.detach().cpu()
         both = [None] * world
@@ -60,6 +78,7 @@ def _worker(rank, world, port, ret):
             out['render'] = {k: float((whole[k].float() - shard[k].float()).abs().max()) for k in whole}
             out['render_shape'] = tuple(shard['image'].shape) == tuple(whole['image'].shape)
         out[overlap] = dict(same=bool(torch.equal(both[0], both[1])), finite=bool(torch.isfinite(flat).all()), flat=flat,
+                            trail=[{k: int(v) for k, v in zip(t[0], torch.stack(t[1]).cpu().tolist())} for t in trail],
                             steps=int(eng.state_i[0].item()), buckets=buckets, n_total=layout.n_total, n_grid=layout.n_grid)
     dist.barrier()
     dist.destroy_process_group()
@@ -91,7 +110,10 @@ def test_two_ranks_on_one_gpu_stay_in_lockstep_with_bucketed_allreduce():
         # overlapped buckets and the single exchange after the backward pass move the same numbers: every kernel of the step is
         # order-independent and the level groups reproduce the single scatter launch bit for bit
         f1, f0 = res[rank][True]['flat'], res[rank][False]['flat']
-        assert torch.equal(f1, f0), f'{(f1 != f0).sum().item()} parameters differ between overlapped and single-collective steps'
+        t1, t0 = res[rank][True]['trail'], res[rank][False]['trail']
+        first = next(((i, sorted(k for k in a if a[k] != b[k])) for i, (a, b) in enumerate(zip(t1, t0)) if a != b), None)
+        assert torch.equal(f1, f0) and first is None, (f'{(f1 != f0).sum().item()} parameters differ between overlapped and single-collective '
+                                                        f'steps; first divergence at step {first[0] if first else None} in {first[1] if first else None}')
 
 
 def _shard_worker(rank, world, port, ret):
