@@ -43,11 +43,18 @@ __device__ inline h16x8 wide_chunk(const WideSrc& s, size_t row, int k0, int K) 
     return v;
   }
   const int j0 = k0 - s.K1;   // 0 or 8 within the geo block
+  // columns j0 .. j0 + 7 of [geo1 .. geoG, 1, 1, ...] = halves 1 + j0 .. 8 + j0 of the 32-byte row: ONE 16-byte load and one more half
+  // (round 4 read the eight halves one by one -- unaligned by one -- and a wave's 2-byte loads at a 32-byte stride cost 16-32 cache
+  //  lines per instruction: the weight-gradient kernels, which rebuild the block for every 64-row tile, spent more L1 lookups on these
+  //  16 columns than on their whole gradient tile)
   const h16* g = s.geo + row * 16;
+  const h16x8 a = *(const h16x8*)(g + j0);
+  const h16 nxt = j0 == 0 ? g[8] : (h16)1.0f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = j0 + j;                 // column of [geo1 .. geoG, 1, 1, ...]
-    v[j] = c < s.G ? g[1 + c] : (h16)1.0f;
+    const int c = j0 + j;
+    const h16 src = j < 7 ? a[j + 1] : nxt;
+    v[j] = c < s.G ? src : (h16)1.0f;
   }
   return v;
 }
@@ -60,7 +67,36 @@ struct WideNT {
   const h16* mask; int ldm;     // multiply by (mask[m][n] > 0) (ReLU' of the layer this gradient flows into) or NULL
   const h16* add; int lda;      // + add[m][n] before the store or NULL
   int* found_inf;               // raised when an output is not finite in fp16
+  // "generated" first hidden layer (h1 = relu([geo_feat, 1] W0^T) is never stored: 1 GB at 2^20 rows x 512): the ReLU' mask of the
+  // layer this gradient flows into is recomputed in the accumulator layout -- ONE matrix instruction per 32 x 32 block (K = 16) --
+  // from the density head's output rows and W0 [N, 16] instead of being read back
+  const h16* mgeo; const h16* mw0; int mG;
 };
+
+// h1 = relu([geo_feat, 1] W0^T) on the fly.  wmfma(W0 fragment, geo fragment) leaves C[feature][sample]: lane = sample, register r
+// = feature 8 (r / 4) + 4 hf + r % 4 of the 32-feature block -- registers 0..7 and 8..15 are, as they stand, the B operands of two
+// 16-wide k-steps of the NEXT layer with the contraction index permuted inside every group of 16 (order 0-3, 8-11 | 4-7, 12-15):
+// the weight matrix of that layer is stored with its columns in the same order (`wide_kperm`, pipeline.Params.wide_wp), so its
+// fragments stay contiguous 16-byte reads.  A permutation of the contraction index changes nothing but the summation order.
+typedef short ws16x2 __attribute__((ext_vector_type(2)));
+typedef float wf32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t wu32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t wu32x4 __attribute__((ext_vector_type(4)));
+// fp16(relu(a)), fp16(relu(b)) in two instructions (mlp_shared.h relu2: v_cvt_pk_f16_f32, then max on the packed halves as signed integers)
+__device__ inline uint32_t wrelu2(float a, float b) {
+  union { h16x2 h; ws16x2 i; uint32_t w; } u; u.h = __builtin_convertvector((wf32x2){a, b}, h16x2);
+  u.i = __builtin_elementwise_max(u.i, (ws16x2){0, 0});
+  return u.w;
+}
+__device__ inline void wide_gen_pack(const f32x16& h, h16x8& lo, h16x8& hi) {
+  const wu32x4 l = {wrelu2(h[0], h[1]), wrelu2(h[2], h[3]), wrelu2(h[4], h[5]), wrelu2(h[6], h[7])};
+  const wu32x4 u = {wrelu2(h[8], h[9]), wrelu2(h[10], h[11]), wrelu2(h[12], h[13]), wrelu2(h[14], h[15])};
+  lo = __builtin_bit_cast(h16x8, l); hi = __builtin_bit_cast(h16x8, u);
+}
+__device__ inline h16x8 wide_geo_chunk(const h16* geo, int G, size_t row, int hf) {
+  const WideSrc s{nullptr, 0, 0, 0, geo, G};
+  return wide_chunk(s, row, 8 * hf, 16);
+}
 
 // Epilogue shared by the two NT kernels.  In the accumulators a lane holds ONE sample row (register r of block b = output column
 // 32 b + 8 (r / 4) + 4 hf + r % 4): storing from there writes 8-byte pieces to 32 different rows per instruction (measured: the
@@ -217,7 +253,7 @@ __global__ __launch_bounds__(256) void k_wide_nt(WideNT p) {
 // bank-conflict swizzle sits on both sides instead: logical 16-byte chunk c of row r lives in slot c ^ (r & 7) -- the lane that
 // fills slot s of row r fetches chunk s ^ (r & 7) from global memory, the fragment read of chunk c goes to slot c ^ (r & 7).
 // Rows beyond M / N are clamped to the last valid row (their results are never stored).  Needs K % 64 == 0 and a plain A operand.
-template <int BN>
+template <int BN, bool MASKGEN = false>
 __global__ __launch_bounds__(256) void k_wide_nt_dma(WideNT p) {
   constexpr int BM = 128, NB = BN / 32, BK = 64, CG = BN < 64 ? BN : 64, EP = CG + 4;
   constexpr int OPER = (BM + BN) * BK * 2, EPIL = 4 * 32 * EP * 4;
@@ -272,7 +308,102 @@ __global__ __launch_bounds__(256) void k_wide_nt_dma(WideNT p) {
     }
     __syncthreads();            // the tile has been consumed
   }
+  if constexpr (MASKGEN) {   // ReLU' of the generated layer: acc *= (h1 > 0), h1 recomputed block by block in the accumulators' own layout
+    const h16x8 gb = wide_geo_chunk(p.mgeo, p.mG, (size_t)min(m0 + wave * 32 + c, p.M - 1), hf);
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const h16x8 fa = *(const h16x8*)(p.mw0 + (size_t)min(n0 + b * 32 + c, p.N - 1) * 16 + 8 * hf);
+      const f32x16 h = wmfma(fa, gb, zero);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {   // (h1 > 0 as stored: fp16 of the ReLU'd value)
+        const uint32_t hp = wrelu2(h[r], h[r + 1]);
+        acc[0][b][r] = (hp & 0xFFFFu) ? acc[0][b][r] : 0.f;
+        acc[0][b][r + 1] = (hp >> 16) ? acc[0][b][r + 1] : 0.f;
+      }
+    }
+  }
   const bool bad = wide_epilogue<BN, 1>(p, acc, smem_w, m0, n0, wave, lane);
+  if (bad && p.found_inf) *p.found_inf = 1;
+}
+
+// Y = epi(relu([geo_feat, 1] W0^T) W^T): the first TWO layers of semantic_features in one launch (models.py:117-125).  The K = 16
+// layer is one matrix instruction per 32 features and wave (12 % more matrix work than the 512 x 512 layer alone, redone by each of
+// the N / 128 column tiles of a row tile); its 1 GB output, the launch that wrote it (414 us: the slowest of the forward pass) and
+// this layer's 1 GB read are gone, and no sample tile passes through LDS at all -- the generated registers ARE the B operands.
+// Weight tiles as in k_wide_nt_dma (global_load_lds, swizzled slots); `w` has its columns in wide_kperm order.  K % 64 == 0.
+struct WideGen { const h16* geo; int G; const h16* w0; };
+// MT row blocks of 32 samples per wave (block = 128 MT rows): with MT = 2 a k-step reads four weight fragments for eight matrix
+// instructions -- half the LDS bytes per instruction of the 32-row wave tile, which sits at the LDS bandwidth (4 x 1 KB per 128 clk and
+// SIMD) -- and there is no sample tile whose staging registers would push the 64-row tile past 256 VGPRs (k_wide_nt).
+template <int BN, int MT>
+__global__ __launch_bounds__(256) void k_wide_nt_gen(WideNT p, WideGen g) {
+  constexpr int BM = 128 * MT, NB = BN / 32, BK = 64, CG = BN < 64 ? BN : 64, EP = CG + 4;
+  constexpr int OPER = BN * BK * 2, EPIL = 4 * 32 * EP * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_w[OPER > EPIL ? OPER : EPIL];
+  h16* Ws = (h16*)smem_w;
+  const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = (p.N + BN - 1) / BN, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int mt_i = (jj / ntn) * 8 + xcd;
+  if (mt_i * BM >= p.M) return;
+  const int m0 = mt_i * BM, n0 = (jj % ntn) * BN;
+  f32x16 acc[MT][NB], zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[t][b] = zero;
+  const int sub = lane >> 3, slot = lane & 7;
+  const h16* wsrc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (wave * NB + i) * 8 + sub;
+    wsrc[i] = p.w + (size_t)min(n0 + row, p.N - 1) * p.ldw + ((slot ^ (row & 7)) * 8);
+  }
+  h16x8 gb[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) gb[t] = wide_geo_chunk(g.geo, g.G, (size_t)min(m0 + (wave * MT + t) * 32 + c, p.M - 1), hf);
+  const int nkt = p.K / BK;
+  // the generated operands run one 32-feature block ahead of the matrix instructions that consume them
+  h16x8 xb[2][MT][2];
+  auto gen = [&](int fb, int buf) {
+    const h16x8 fa = *(const h16x8*)(g.w0 + (size_t)(fb * 32 + c) * 16 + 8 * hf);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const f32x16 h = wmfma(fa, gb[t], zero);
+      wide_gen_pack(h, xb[buf][t][0], xb[buf][t][1]);
+    }
+  };
+  gen(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(Ws + (wave * NB + i) * 512), 16, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int f2 = 0; f2 < 2; ++f2) {
+      const int fb = 2 * kt + f2;
+      if (fb + 1 < 2 * nkt) gen(fb + 1, (f2 + 1) & 1);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int ks = 2 * f2 + k2;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int wr_ = b * 32 + c;
+          const h16x8 wa = *(const h16x8*)(Ws + wr_ * BK + (((ks * 2 + hf) ^ (wr_ & 7)) * 8));
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t][b] = wmfma(wa, xb[f2 & 1][t][k2], acc[t][b]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const bool bad = wide_epilogue<BN, MT>(p, acc, smem_w, m0, n0, wave, lane);
   if (bad && p.found_inf) *p.found_inf = 1;
 }
 
@@ -288,6 +419,7 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
   p.M = M; p.N = N; p.K = p.a.K1 + (geo ? 16 : 0);
   p.w = (const h16*)w; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = relu;
   p.mask = (const h16*)mask; p.ldm = ldm; p.add = (const h16*)add; p.lda = lda; p.found_inf = found_inf;
+  p.mgeo = nullptr; p.mw0 = nullptr; p.mG = 0;
   ALN_REQUIRE(ldw >= p.K, "wide_nt: weight rows shorter than K");
   hipStream_t s = (hipStream_t)stream;
   // (measured on the 1M x 512 x 512 layers: wave tile 32 x 128 at 2 waves/SIMD 1.3 ms; 64 x 128 needs > 256 VGPRs, one wave per
@@ -308,6 +440,48 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
   return 0;
 }
 
+// Y[M, N] = epi(relu([geo_feat, 1] W0[K, 16]^T) W[N, K]^T): semantic_features' first two layers in one launch, the first one generated
+// (k_wide_nt_gen).  `w_perm`: W with the columns of every group of 16 in wide_kperm order (0-3, 8-11, 4-7, 12-15).
+extern "C" int aln_wide_nt_gen(const void* geo, int32_t G, const void* w0, int32_t M, int32_t N, int32_t K, const void* w_perm, int32_t ldw,
+                               void* y, int32_t ldy, int32_t relu, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(geo && w0 && w_perm && y && M >= 0 && N > 0, "wide_nt_gen: bad arguments");
+  ALN_REQUIRE(K > 0 && K % 64 == 0 && N % 4 == 0 && ldw % 8 == 0 && ldw >= K && ldy % 4 == 0, "wide_nt_gen: K must be a multiple of 64, N / leading dimensions of 4 / 8");
+  ALN_REQUIRE(((uintptr_t)w_perm & 15) == 0 && ((uintptr_t)w0 & 15) == 0 && ((uintptr_t)geo & 15) == 0, "wide_nt_gen: operands must be 16-byte aligned");
+  if (M == 0) return 0;
+  WideNT p;
+  p.a = WideSrc{nullptr, 0, 0, 0, nullptr, 0};
+  p.M = M; p.N = N; p.K = K; p.w = (const h16*)w_perm; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = relu;
+  p.mask = nullptr; p.ldm = 0; p.add = nullptr; p.lda = 0; p.found_inf = found_inf; p.mgeo = nullptr; p.mw0 = nullptr; p.mG = 0;
+  const WideGen g{(const h16*)geo, G, (const h16*)w0};
+  auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm + 7) / 8 * 8 * ((N + bn - 1) / bn))); };
+  // (MT = 2, a 64-row wave tile at two waves per SIMD, measured slower in the step: 711 vs 669 us at 2^20 rows)
+  if (N > 64) hipLaunchKernelGGL((k_wide_nt_gen<128, 1>), grid(128, 128), dim3(256), 0, (hipStream_t)stream, p, g);
+  else if (N > 32) hipLaunchKernelGGL((k_wide_nt_gen<64, 1>), grid(128, 64), dim3(256), 0, (hipStream_t)stream, p, g);
+  else hipLaunchKernelGGL((k_wide_nt_gen<32, 1>), grid(128, 32), dim3(256), 0, (hipStream_t)stream, p, g);
+  ALN_CHECK_LAUNCH("wide_nt_gen");
+  return 0;
+}
+// Y[M, N] = (A[M, K] W[N, K]^T) * (h1 > 0) with h1 = relu([geo_feat, 1] W0[N, 16]^T) recomputed in the accumulators (no mask rows are
+// read): the data gradient that flows into the generated layer.  Plain A operand, K % 64 == 0.
+extern "C" int aln_wide_nt_maskgen(const void* a1, int32_t lda1, int32_t M, int32_t N, int32_t K, const void* w, int32_t ldw, void* y,
+                                   int32_t ldy, const void* geo, int32_t G, const void* w0, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(a1 && w && y && geo && w0 && M >= 0 && N > 0, "wide_nt_maskgen: bad arguments");
+  ALN_REQUIRE(K > 0 && K % 64 == 0 && N % 4 == 0 && ldw % 8 == 0 && ldw >= K && lda1 % 8 == 0 && ldy % 4 == 0, "wide_nt_maskgen: K must be a multiple of 64, N / leading dimensions of 4 / 8");
+  ALN_REQUIRE(((uintptr_t)a1 & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)w0 & 15) == 0, "wide_nt_maskgen: operands must be 16-byte aligned");
+  if (M == 0) return 0;
+  WideNT p;
+  p.a = WideSrc{(const h16*)a1, lda1, K, 0, nullptr, 0};
+  p.M = M; p.N = N; p.K = K; p.w = (const h16*)w; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = 0;
+  p.mask = nullptr; p.ldm = 0; p.add = nullptr; p.lda = 0; p.found_inf = found_inf;
+  p.mgeo = (const h16*)geo; p.mw0 = (const h16*)w0; p.mG = G;
+  auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm + 7) / 8 * 8 * ((N + bn - 1) / bn))); };
+  if (N > 64) hipLaunchKernelGGL((k_wide_nt_dma<128, true>), grid(128, 128), dim3(256), 0, (hipStream_t)stream, p);
+  else if (N > 32) hipLaunchKernelGGL((k_wide_nt_dma<64, true>), grid(128, 64), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((k_wide_nt_dma<32, true>), grid(128, 32), dim3(256), 0, (hipStream_t)stream, p);
+  ALN_CHECK_LAUNCH("wide_nt_maskgen");
+  return 0;
+}
+
 // ---------------------------------------------------------------- weight gradients
 struct WideTN {
   WideSrc a; int M, N, K;
@@ -318,7 +492,7 @@ struct WideTN {
 };
 
 #define WTN_BM 64            // sample rows per LDS tile
-#define WTN_TN 128           // tile edge in n
+#define WTN_TN 128           // tile edge in n  (2 x 2 waves of 64 n x 128 k)
 #define WTN_TK 256           // tile edge in k
 #define WTN_PG (WTN_TN + 24) // halves (304 B: rows stay 16-byte aligned for the staging stores)
 #define WTN_PA (WTN_TK + 24)
@@ -341,20 +515,24 @@ __device__ inline h16x8 wtr_frag(T t, int col0, int ks, int lane) {
   return u.v;
 }
 
+// Wave layout NWN x NWK (= 4 waves), every wave a 64 (n) x 128 (k) tile: 2 x 2 for the square layers (tile 128 x 256); 4 x 1 (tile
+// 256 x 128) for an operand of at most 128 columns -- the 16-wide [geo_feat, 1] block of the first layer, whose 2 x 2 launch left
+// the two waves of the second k half without a single column (745 us for a 17 GFLOP product, round 4).
+template <int NWN, int NWK>
 __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
-  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PG];
-  __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * WTN_PA];
+  constexpr int TN = 64 * NWN, TK = 128 * NWK, PG = TN + 24, PA = TK + 24, GC = TN / 32, AC = TK / 32;
+  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * PG];
+  __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * PA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
   // XCD-aware order (see k_wide_nt): the tn x tk output tiles of one sample slab share an XCD, so the slab's rows of G and A
   // come from HBM once
   const int ntile = p.tn * p.tk, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int slab_i = (jj / ntile) * 8 + xcd, tile_i = jj % ntile;
   if (slab_i * p.slab >= p.M) return;
-  const int n0 = (tile_i % p.tn) * WTN_TN, k0 = (tile_i / p.tn) * WTN_TK;
+  const int n0 = (tile_i % p.tn) * TN, k0 = (tile_i / p.tn) * TK;
   const int mlo = slab_i * p.slab, mhi = min(p.M, mlo + p.slab);
-  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;   // wave tile 64 (n) x 128 (k): 6 fragment reads per 8 MFMAs
-  // 32-column blocks of this wave's k range that exist at all (the 16-wide geo_feat operand of the first layer fills ONE block of one
-  // wave column: multiplying the 15 empty ones made that 512 x 16 GEMM cost as much as a 512 x 256 one)
+  const int wn = (wave / NWK) * 64, wk = (wave % NWK) * 128;   // wave tile 64 (n) x 128 (k): 6 fragment reads per 8 MFMAs
+  // 32-column blocks of this wave's k range that exist at all (the 16-wide geo_feat operand of the first layer fills ONE block)
   const int nbj = __builtin_amdgcn_readfirstlane(max(0, min(4, (p.K - k0 - wk + 31) / 32)));
   f32x16 acc[2][4];
 #pragma unroll
@@ -363,23 +541,23 @@ __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const WTile<WTN_PG> tG{(lds_h16w*)Gs};
-  const WTile<WTN_PA> tA{(lds_h16w*)As};
-  // G tile: 64 rows x 16 chunks (4 per thread); A tile: 64 rows x 32 chunks (8 per thread)
-  h16x8 gr[4], ar[8];
+  const WTile<PG> tG{(lds_h16w*)Gs};
+  const WTile<PA> tA{(lds_h16w*)As};
+  // G tile: 64 rows x TN / 8 chunks (GC per thread); A tile: 64 rows x TK / 8 chunks (AC per thread)
+  h16x8 gr[GC], ar[AC];
   auto fetch = [&](int mt) {
     h16x8 z;
 #pragma unroll
     for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
+    for (int i = 0; i < GC; ++i) {
+      const int ch = tid + 256 * i, r = ch / (TN / 8), cc = (ch % (TN / 8)) * 8;
       gr[i] = z;
       if (mt + r < mhi && n0 + cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)(mt + r) * p.ldg + n0 + cc);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ch = tid + 256 * i, r = ch >> 5, cc = (ch & 31) * 8;
+    for (int i = 0; i < AC; ++i) {
+      const int ch = tid + 256 * i, r = ch / (TK / 8), cc = (ch % (TK / 8)) * 8;
       ar[i] = z;
       if (mt + r < mhi) ar[i] = wide_chunk(p.a, (size_t)(mt + r), k0 + cc, p.K);
     }
@@ -388,9 +566,9 @@ __global__ __launch_bounds__(256) void k_wide_tn(WideTN p) {
   for (int mt = mlo; mt < mhi; mt += WTN_BM) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Gs + (ch >> 4) * WTN_PG + (ch & 15) * 8) = gr[i]; }
+    for (int i = 0; i < GC; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Gs + (ch / (TN / 8)) * PG + (ch % (TN / 8)) * 8) = gr[i]; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const int ch = tid + 256 * i; *(h16x8*)(As + (ch >> 5) * WTN_PA + (ch & 31) * 8) = ar[i]; }
+    for (int i = 0; i < AC; ++i) { const int ch = tid + 256 * i; *(h16x8*)(As + (ch / (TK / 8)) * PA + (ch % (TK / 8)) * 8) = ar[i]; }
     __syncthreads();
     if (mt + WTN_BM < mhi) fetch(mt + WTN_BM);
 #pragma unroll
@@ -439,8 +617,10 @@ __global__ __launch_bounds__(256) void k_wide_dw_reduce(const float* __restrict_
     dw[(e / K) * (size_t)lddw + e % K] += acc;
   }
 }
+static bool wide_tn_narrow(int K) { return K <= 128; }   // 4 x 1 wave layout (tile 256 x 128) instead of 2 x 2 (128 x 256)
 static void wide_tn_split(int M, int N, int K, int& tn, int& tk, int& slab, int& slabs) {
-  tn = (N + WTN_TN - 1) / WTN_TN; tk = (K + WTN_TK - 1) / WTN_TK;
+  const int TN = wide_tn_narrow(K) ? 256 : WTN_TN, TK = wide_tn_narrow(K) ? 128 : WTN_TK;
+  tn = (N + TN - 1) / TN; tk = (K + TK - 1) / TK;
   // enough slabs to fill the chip (>= ~1024 blocks), each a multiple of the 64-row tile
   slabs = (1024 + tn * tk - 1) / (tn * tk);
   slab = ((M + slabs - 1) / slabs + WTN_BM - 1) / WTN_BM * WTN_BM;
@@ -466,11 +646,216 @@ extern "C" int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t l
   int tn, tk, slab, slabs;
   wide_tn_split(M, N, p.K, tn, tk, slab, slabs);
   p.slab = slab; p.tn = tn; p.tk = tk;
-  hipLaunchKernelGGL(k_wide_tn, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p);
+  if (wide_tn_narrow(p.K)) hipLaunchKernelGGL((k_wide_tn<4, 1>), dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((k_wide_tn<2, 2>), dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p);
   ALN_CHECK_LAUNCH("wide_tn");
   const int64_t nk = (int64_t)N * p.K;
   hipLaunchKernelGGL(k_wide_dw_reduce, dim3((unsigned)((nk + 255) / 256 < 2048 ? (nk + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)ws, slabs, N, p.K, dw, lddw);
+  ALN_CHECK_LAUNCH("wide_dw_reduce");
+  return 0;
+}
+
+// dW[N, K] += G[M, N]^T relu([geo_feat, 1] W0[K, 16]^T): the weight gradient of the layer BEHIND the generated one.  k_wide_tn with its A
+// tile (64 samples x 256 features of h1) GENERATED into LDS instead of fetched: wave w computes the features [64 w, 64 w + 64) of the
+// tile's 64 samples -- four matrix instructions, ReLU + pack, sixteen 8-byte LDS stores -- while the G tile is staged as before.  h1 (1 GB
+// at 2^20 rows) is neither stored nor read; 12 % more matrix work, the same fragment reads.
+__global__ __launch_bounds__(256) void k_wide_tn_gen(WideTN p, WideGen g) {
+  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PG];
+  __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * WTN_PA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
+  const int ntile = p.tn * p.tk, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int slab_i = (jj / ntile) * 8 + xcd, tile_i = jj % ntile;
+  if (slab_i * p.slab >= p.M) return;
+  const int n0 = (tile_i % p.tn) * WTN_TN, k0 = (tile_i / p.tn) * WTN_TK;
+  const int mlo = slab_i * p.slab, mhi = min(p.M, mlo + p.slab);
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+  const int nbj = __builtin_amdgcn_readfirstlane(max(0, min(4, (p.K - k0 - wk + 31) / 32)));
+  f32x16 acc[2][4], zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = zero;
+  const WTile<WTN_PG> tG{(lds_h16w*)Gs};
+  const WTile<WTN_PA> tA{(lds_h16w*)As};
+  // W0 rows of this wave's two feature blocks of the tile (A operand of the generating instruction): resident
+  h16x8 w0f[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) w0f[f] = *(const h16x8*)(g.w0 + (size_t)min(k0 + 64 * wave + 32 * f + c, p.K - 1) * 16 + 8 * hf);
+  h16x8 gr[4], gs[2];   // staged G chunks; [geo_feat, 1] rows of the tile's two 32-sample blocks (B operand of the generating instruction)
+  auto fetch = [&](int mt) {
+    h16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
+      gr[i] = z;
+      if (mt + r < mhi && n0 + cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)(mt + r) * p.ldg + n0 + cc);
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int m = mt + 32 * sb + c;
+      gs[sb] = m < mhi ? wide_geo_chunk(g.geo, g.G, (size_t)m, hf) : z;   // (rows beyond the slab: G is zero there as well)
+    }
+  };
+  fetch(mlo);
+  for (int mt = mlo; mt < mhi; mt += WTN_BM) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Gs + (ch >> 4) * WTN_PG + (ch & 15) * 8) = gr[i]; }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        // D[feature][sample]: lane = sample 32 sb + c, register r = feature 64 wave + 32 f + 8 (r / 4) + 4 hf + r % 4
+        const f32x16 h = wmfma(w0f[f], gs[sb], zero);
+        h16* row = As + (32 * sb + c) * WTN_PA + 64 * wave + 32 * f + 4 * hf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(wu32x2*)(row + 8 * q) = (wu32x2){wrelu2(h[4 * q], h[4 * q + 1]), wrelu2(h[4 * q + 2], h[4 * q + 3])};
+      }
+    __syncthreads();
+    if (mt + WTN_BM < mhi) fetch(mt + WTN_BM);
+#pragma unroll
+    for (int ks = 0; ks < WTN_BM / 16; ++ks) {
+      h16x8 ga[2], ab[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ga[i] = wtr_frag(tG, wn + 32 * i, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (j < nbj) ab[j] = wtr_frag(tA, wk + 32 * j, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nbj) acc[i][j] = wmfma(ga[i], ab[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk + 32 * j + c;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn + 32 * i + 8 * (r >> 2) + 4 * hf + (r & 3);
+        if (n < p.N) p.ws[((size_t)slab_i * p.N + n) * p.K + k] = acc[i][j][r];
+      }
+    }
+}
+// (A/B candidate) register form: h1^T straight from the generating instruction's accumulators into the B operands, samples permuted
+template <class T>
+__device__ inline h16x8 wtr_frag_perm(T t, int col0, int ks, int lane) {
+  const int hf = lane >> 5;
+  const int row = 16 * ks + 4 * hf + ((lane & 15) >> 2);
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w_ptr)t.at(row, col));
+  s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w_ptr)t.at(row + 8, col));
+  union { struct { s16x4w l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+__global__ __launch_bounds__(256) void k_wide_tn_genr(WideTN p, WideGen g) {
+  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
+  const int ntile = p.tn * p.tk, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int slab_i = (jj / ntile) * 8 + xcd, tile_i = jj % ntile;
+  if (slab_i * p.slab >= p.M) return;
+  const int n0 = (tile_i % p.tn) * WTN_TN, k0 = (tile_i / p.tn) * WTN_TK;
+  const int mlo = slab_i * p.slab, mhi = min(p.M, mlo + p.slab);
+  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
+  f32x16 acc[2][4], zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = zero;
+  const WTile<WTN_PG> tG{(lds_h16w*)Gs};
+  h16x8 w0f[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w0f[j] = *(const h16x8*)(g.w0 + (size_t)min(k0 + wk + 32 * j + c, p.K - 1) * 16 + 8 * hf);
+  h16x8 gr[4], ga_[2];
+  auto fetch = [&](int mt) {
+    h16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
+      gr[i] = z;
+      if (mt + r < mhi && n0 + cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)(mt + r) * p.ldg + n0 + cc);
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int m = mt + 32 * sb + c;
+      ga_[sb] = m < mhi ? wide_geo_chunk(g.geo, g.G, (size_t)m, hf) : z;
+    }
+  };
+  fetch(mlo);
+  for (int mt = mlo; mt < mhi; mt += WTN_BM) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Gs + (ch >> 4) * WTN_PG + (ch & 15) * 8) = gr[i]; }
+    const h16x8 gcur[2] = {ga_[0], ga_[1]};
+    __syncthreads();
+    if (mt + WTN_BM < mhi) fetch(mt + WTN_BM);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      h16x8 ab[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x16 h = wmfma(gcur[sb], w0f[j], zero);   // C[sample][feature]: lane = feature, registers = samples
+        wide_gen_pack(h, ab[j][0], ab[j][1]);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int ks = 2 * sb + k2;
+        h16x8 ga[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ga[i] = wtr_frag_perm(tG, wn + 32 * i, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = wmfma(ga[i], ab[j][k2], acc[i][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk + 32 * j + c;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn + 32 * i + 8 * (r >> 2) + 4 * hf + (r & 3);
+        if (n < p.N) p.ws[((size_t)slab_i * p.N + n) * p.K + k] = acc[i][j][r];
+      }
+    }
+}
+static int g_wide_variant = 0;
+extern "C" int aln_debug_wide_variant(int v) { g_wide_variant = v; return 0; }
+extern "C" int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int32_t G, const void* w0, int32_t M, int32_t N, int32_t K,
+                               float* dw, int32_t lddw, void* ws, void* stream) {
+  ALN_REQUIRE(g && dw && ws && geo && w0 && M >= 0 && N > 0, "wide_tn_gen: bad arguments");
+  ALN_REQUIRE(ldg % 8 == 0 && N % 8 == 0 && K > 0 && K % 32 == 0 && lddw >= K, "wide_tn_gen: N / K / leading dimensions must be multiples of 8 / 32");
+  ALN_REQUIRE(((uintptr_t)w0 & 15) == 0 && ((uintptr_t)g & 15) == 0, "wide_tn_gen: operands must be 16-byte aligned");
+  if (M == 0) return 0;
+  WideTN p;
+  p.a = WideSrc{nullptr, 0, 0, 0, nullptr, 0};
+  p.M = M; p.N = N; p.K = K; p.g = (const h16*)g; p.ldg = ldg; p.ws = (float*)ws;
+  int tn, tk, slab, slabs;
+  wide_tn_split(M, N, K, tn, tk, slab, slabs);
+  p.slab = slab; p.tn = tn; p.tk = tk;
+  const WideGen gg{(const h16*)geo, G, (const h16*)w0};
+  if (g_wide_variant & 1) hipLaunchKernelGGL(k_wide_tn_genr, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p, gg);
+  else hipLaunchKernelGGL(k_wide_tn_gen, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p, gg);
+  ALN_CHECK_LAUNCH("wide_tn_gen");
+  const int64_t nk = (int64_t)N * K;
+  hipLaunchKernelGGL(k_wide_dw_reduce, dim3((unsigned)((nk + 255) / 256 < 2048 ? (nk + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)ws, slabs, N, K, dw, lddw);
   ALN_CHECK_LAUNCH("wide_dw_reduce");
   return 0;
 }

@@ -11,7 +11,7 @@ import torch
 from .build import LIB
 
 ALN_MAX_LEVELS = 16
-ABI_VERSION = 5   # include/autolabel_hip.h: ALN_ABI_VERSION
+ABI_VERSION = 6   # include/autolabel_hip.h: ALN_ABI_VERSION
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
 
@@ -70,6 +70,9 @@ _SIGS = {
     'aln_wide_tn_ws_bytes': (i64, [i32, i32, i32]),
     'aln_wide_tn': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]),
     'aln_transpose_f16': (i32, [vp, i32, i32, vp, vp]),
+    'aln_wide_nt_gen': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, vp]),
+    'aln_wide_nt_maskgen': (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]),
+    'aln_wide_tn_gen': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp]),
     'aln_mlp_repack': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),
     'aln_mlp_repack_all': (i32, [i32, vp, vp, vp]),

@@ -74,6 +74,8 @@ class Params:
         self.grad = torch.zeros(L.n_total + 8, dtype=torch.float32, device=device)  # +8: side channel for DP (found_inf)
         self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
         self.frags, self.descs, self.wide_w, self.wide_wt = {}, {}, {}, {}
+        self.wide_wp = None    # semantic_features' second matrix with the columns of every group of 16 in the order the generated first
+                               # layer leaves them in (aln_wide_nt_gen, wide.hip: wide_gen_pack)
         # sharded table optimizer (engine.TrainEngine(shard_optimizer=True, shard_gather='table')): the fp32 masters of the slices other
         # ranks own are stale in `flat` until TrainEngine.sync_master() (a collective) -- readers of the masters check this flag
         self.masters_stale = False
@@ -81,6 +83,10 @@ class Params:
             if L.sem_wide and k in ('semf', 'semo'):   # row-major fp16 [out, in] per layer (+ transposes for the data gradients)
                 self.wide_w[k] = [torch.zeros(o, i, dtype=torch.float16, device=device) for o, i in s.shapes]
                 self.wide_wt[k] = [torch.zeros(i, o, dtype=torch.float16, device=device) for o, i in s.shapes]
+                if k == 'semf' and s.hidden % 64 == 0 and s.in_pad == 16:
+                    self.wide_wp = torch.zeros(s.hidden, s.hidden, dtype=torch.float16, device=device)
+                    perm16 = [4 * (q >> 3) + (q & 3) + 8 * ((q & 7) >> 2) for q in range(16)]
+                    self._kperm = torch.tensor([16 * (c // 16) + perm16[c % 16] for c in range(s.hidden)], device=device)
                 continue
             nf = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 0)
             nb = H.lib().aln_mlp_frag_halves(s.in_pad, s.hidden, s.out_pad, s.n_hidden, 1)
@@ -136,6 +142,8 @@ class Params:
                     w.copy_(self.flat[o:o + w.numel()].view_as(w))
                     H.call('aln_transpose_f16', H.ptr(w), w.shape[0], w.shape[1], H.ptr(wt), H.stream())
                     o += w.numel()
+                if k == 'semf' and self.wide_wp is not None:
+                    torch.index_select(self.wide_w[k][1], 1, self._kperm, out=self.wide_wp)
             else:
                 fused.append(k)
         if fused:   # one launch for all fused heads
@@ -330,6 +338,26 @@ class HipPipeline:
         self._k('aln_wide_tn', H.ptr(g), g.shape[1], H.ptr(a1), a1.shape[1] if a1 is not None else 0, K1, relu1, H.ptr(geo), self.L.G, M, N,
                 C.c_void_p(self.P.grad.data_ptr() + 4 * dw_off), ldw, H.ptr(scratch), H.stream(), tag=('wide', M, N * K))
 
+    # generated first layer of semantic_features (wide.hip): h1 = relu([geo_feat, 1] W0^T) is recomputed by whoever needs it
+    def _gen(self):
+        return self.P.wide_wp is not None
+
+    def _nt_gen(self, M, y, sout, relu=1, tag=None):
+        fs, W = self.L.nets['semf'], self.P.wide_w['semf']
+        self._k('aln_wide_nt_gen', H.ptr(sout), self.L.G, H.ptr(W[0]), M, fs.hidden, fs.hidden, H.ptr(self.P.wide_wp), fs.hidden, H.ptr(y), y.shape[1], relu,
+                None, H.stream(), tag=('wide', M, fs.hidden * (fs.hidden + 16)))
+
+    def _nt_maskgen(self, M, wt, y, a1, sout, tag=None):
+        fs = self.L.nets['semf']
+        self._k('aln_wide_nt_maskgen', H.ptr(a1), a1.shape[1], M, fs.hidden, fs.hidden, H.ptr(wt), wt.shape[1], H.ptr(y), y.shape[1], H.ptr(sout), self.L.G,
+                H.ptr(self.P.wide_w['semf'][0]), H.ptr(self.found_inf), H.stream(), tag=('wide', M, fs.hidden * (fs.hidden + 16)))
+
+    def _tn_gen(self, M, g, dw_off, sout, tag=None):
+        fs = self.L.nets['semf']
+        scratch = self._tn_ws.scratch('wide_tn_slabs', int(H.lib().aln_wide_tn_ws_bytes(M, fs.hidden, fs.hidden)))
+        self._k('aln_wide_tn_gen', H.ptr(g), g.shape[1], H.ptr(sout), self.L.G, H.ptr(self.P.wide_w['semf'][0]), M, fs.hidden, fs.hidden,
+                C.c_void_p(self.P.grad.data_ptr() + 4 * dw_off), fs.hidden, H.ptr(scratch), H.stream(), tag=('wide', M, fs.hidden * (fs.hidden + 16)))
+
     def wide_sem_fwd(self, sout, M, bufs):
         """f = semantic_features([geo, 1]); logits = semantic_out([relu(f), geo, 1]) for M rows of the density head's output.
         bufs: callable name, shape -> fp16 buffer.  Returns (logits [M, Cpad], f [M, D], saved activations)."""
@@ -337,11 +365,16 @@ class HipPipeline:
         fs, os_ = L.nets['semf'], L.nets['semo']
         Wf, Wo = self.P.wide_w['semf'], self.P.wide_w['semo']
         fl = ('sem', M)
-        h1, h2 = bufs('wide_h1', (M, fs.hidden)), bufs('wide_h2', (M, fs.hidden))
+        h2 = bufs('wide_h2', (M, fs.hidden))
         feat, ho = bufs('feat', (M, fs.out_pad)), bufs('wide_ho', (M, os_.hidden))
         logits = bufs('logits', (M, os_.out_pad))
-        self._nt(M, fs.hidden, Wf[0], h1, geo=sout, relu=1, tag=fl)
-        self._nt(M, fs.hidden, Wf[1], h2, a1=h1, K1=fs.hidden, relu=1, tag=fl)
+        if self._gen():    # layers 1 + 2 in one launch, h1 never stored
+            h1 = None
+            self._nt_gen(M, h2, sout, tag=fl)
+        else:
+            h1 = bufs('wide_h1', (M, fs.hidden))
+            self._nt(M, fs.hidden, Wf[0], h1, geo=sout, relu=1, tag=fl)
+            self._nt(M, fs.hidden, Wf[1], h2, a1=h1, K1=fs.hidden, relu=1, tag=fl)
         self._nt(M, fs.out_pad, Wf[2], feat, a1=h2, K1=fs.hidden, tag=fl)
         self._nt(M, os_.hidden, Wo[0], ho, a1=feat, K1=L.D, relu1=1, geo=sout, relu=1, tag=fl)
         self._nt(M, os_.out_pad, Wo[1], logits, a1=ho, K1=os_.hidden, tag=fl)
@@ -370,8 +403,12 @@ class HipPipeline:
         n0, n1 = sf[0][0] * sf[0][1], sf[1][0] * sf[1][1]
         self._nt(M, fs.hidden, Wft[2], dh2, a1=d_feat, K1=fs.out_pad, mask=h2, watch=True, tag=bl)
         self._tn(M, fs.out_pad, d_feat, of + n0 + n1, fs.hidden, a1=h2, K1=fs.hidden, tag=bl)
-        self._nt(M, fs.hidden, Wft[1], dh1, a1=dh2, K1=fs.hidden, mask=h1, watch=True, tag=bl)
-        self._tn(M, fs.hidden, dh2, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=bl)
+        if h1 is None:
+            self._nt_maskgen(M, Wft[1], dh1, dh2, sout, tag=bl)
+            self._tn_gen(M, dh2, of + n0, sout, tag=bl)
+        else:
+            self._nt(M, fs.hidden, Wft[1], dh1, a1=dh2, K1=fs.hidden, mask=h1, watch=True, tag=bl)
+            self._tn(M, fs.hidden, dh2, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=bl)
         d_fin = bufs('d_semf_in', (M, fs.in_pad))
         self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=bl)
         self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=sout, tag=bl)
@@ -475,9 +512,14 @@ class HipPipeline:
             c['sem_linear'] = bool(sem_linear and L.sem_wide and train)
             if c['sem_linear']:
                 Wf = P.wide_w['semf']
-                h1, h2 = g('wide_h1', (M, fs.hidden), f16), g('wide_h2', (M, fs.hidden), f16)
-                self._nt(M, fs.hidden, Wf[0], h1, geo=sout, relu=1, tag=('sem', M))
-                self._nt(M, fs.hidden, Wf[1], h2, a1=h1, K1=fs.hidden, relu=1, tag=('sem', M))
+                h2 = g('wide_h2', (M, fs.hidden), f16)
+                if self._gen():
+                    h1 = None
+                    self._nt_gen(M, h2, sout, tag=('sem', M))
+                else:
+                    h1 = g('wide_h1', (M, fs.hidden), f16)
+                    self._nt(M, fs.hidden, Wf[0], h1, geo=sout, relu=1, tag=('sem', M))
+                    self._nt(M, fs.hidden, Wf[1], h2, a1=h1, K1=fs.hidden, relu=1, tag=('sem', M))
                 c['wide_saved'] = (h1, h2, None)
                 c['feat'], c['logits'] = h2, None      # what the compositing kernels sum / differentiate: the hidden activation
             elif c['sem_wide']:
@@ -626,8 +668,12 @@ class HipPipeline:
             of = L.offsets['semf']
             n0 = fs.shapes[0][0] * fs.shapes[0][1]
             dh1 = g('wide_dh1', (M, fs.hidden), f16)
-            self._nt(M, fs.hidden, Wft[1], dh1, a1=d_feat, K1=fs.hidden, mask=h1, watch=True, tag=('sem', M))
-            self._tn(M, fs.hidden, d_feat, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=('sem', M))
+            if h1 is None:
+                self._nt_maskgen(M, Wft[1], dh1, d_feat, c['sigma_out'], tag=('sem', M))
+                self._tn_gen(M, d_feat, of + n0, c['sigma_out'], tag=('sem', M))
+            else:
+                self._nt(M, fs.hidden, Wft[1], dh1, a1=d_feat, K1=fs.hidden, mask=h1, watch=True, tag=('sem', M))
+                self._tn(M, fs.hidden, d_feat, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=('sem', M))
             d_fin = g('d_semf_in', (M, fs.in_pad), f16)
             self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=('sem', M))
             self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=c['sigma_out'], tag=('sem', M))

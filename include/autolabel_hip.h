@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 5
+#define ALN_ABI_VERSION 6
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -267,6 +267,19 @@ int64_t aln_wide_tn_ws_bytes(int32_t M, int32_t N, int32_t K);
 int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t lda1, int32_t K1, int32_t relu1, const void* geo, int32_t G,
                 int32_t M, int32_t N, float* dw, int32_t lddw, void* ws, void* stream);
 int aln_transpose_f16(const void* src /*[R,C]*/, int32_t R, int32_t C, void* dst /*[C,R]*/, void* stream);
+/* "Generated" first hidden layer (round 5): h1 = relu([geo_feat, 1] W0[K,16]^T) of semantic_features (autolabel/models.py:117-125 at LSeg
+ * width) is one matrix instruction per 32 x 32 block, so it is recomputed wherever it is needed instead of being stored (1 GB at 2^20
+ * rows x 512) and read back three times:
+ *   aln_wide_nt_gen      Y[M,N] = epi(h1 W[N,K]^T): layers 1 + 2 in one launch.  w_perm = W with the columns of every group of 16 in
+ *                        the order 0-3, 8-11, 4-7, 12-15 (the generated registers are the B operands in that contraction order)
+ *   aln_wide_nt_maskgen  Y[M,N] = (A[M,K] W[N,K]^T) * (h1 > 0): the data gradient flowing into the generated layer (h1: [M,N], W0: [N,16])
+ *   aln_wide_tn_gen      dW[N,K] += G[M,N]^T h1[M,K]: the weight gradient of the layer behind it (ws: aln_wide_tn_ws_bytes(M, N, K)) */
+int aln_wide_nt_gen(const void* geo /*sigma_out [M,16]*/, int32_t G, const void* w0 /*[K,16] f16*/, int32_t M, int32_t N, int32_t K,
+                    const void* w_perm, int32_t ldw, void* y, int32_t ldy, int32_t relu, int32_t* found_inf, void* stream);
+int aln_wide_nt_maskgen(const void* a1, int32_t lda1, int32_t M, int32_t N, int32_t K, const void* w, int32_t ldw, void* y, int32_t ldy,
+                        const void* geo, int32_t G, const void* w0 /*[N,16]*/, int32_t* found_inf, void* stream);
+int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int32_t G, const void* w0 /*[K,16]*/, int32_t M, int32_t N, int32_t K,
+                    float* dw, int32_t lddw, void* ws, void* stream);
 
 /* ---- occupancy-grid marching (march.hip): the cuda_ray hooks of autolabel/trainer.py:21-23,34-36,176 and
  * NeRFRenderer.mark_untrained_grid / update_extra_state of the torch-ngp fork (dead in the reference: model_utils.py:72).

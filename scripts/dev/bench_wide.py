@@ -36,3 +36,17 @@ for (N, K1, geo, name) in [(512, 512, False, 'dW 512x512'), (64, 512, True, 'dW 
     tn_ws = torch.empty(int(H.lib().aln_wide_tn_ws_bytes(M, N, K)), dtype=torch.uint8, device='cuda')
     t = timeit(lambda: H.call('aln_wide_tn', H.ptr(gg), N, H.ptr(x) if K1 else None, 512, K1, 0, H.ptr(sout) if geo else None, 15, M, N, H.ptr(dw), K, H.ptr(tn_ws), H.stream()))
     print(f'tn {name:22s}: {t * 1e6:8.0f} us  {2.0 * M * N * K / t / 1e12:7.1f} TFLOP/s')
+# ---- round 5: generated first layer (h1 never stored)
+w0 = (torch.randn(512, 16, device=dev) / 4).half()
+w1 = (torch.randn(512, 512, device=dev) / 22).half()
+t = timeit(lambda: H.call('aln_wide_nt_gen', H.ptr(sout), 15, H.ptr(w0), M, 512, 512, H.ptr(w1), 512, H.ptr(y), 512, 1, None, H.stream()))
+print(f'nt_gen (layers 1+2)       : {t * 1e6:8.0f} us  {2.0 * M * 512 * 528 / t / 1e12:7.1f} TFLOP/s')
+y2 = torch.empty_like(y)
+t = timeit(lambda: H.call('aln_wide_nt_maskgen', H.ptr(x), 512, M, 512, 512, H.ptr(w1), 512, H.ptr(y2), 512, H.ptr(sout), 15, H.ptr(w0), None, H.stream()))
+print(f'nt_maskgen 512x512        : {t * 1e6:8.0f} us  {2.0 * M * 512 * 512 / t / 1e12:7.1f} TFLOP/s')
+t = timeit(lambda: H.call('aln_wide_nt', H.ptr(x), 512, 512, 0, None, 15, M, 512, H.ptr(w1), 512, H.ptr(y2), 512, 0, H.ptr(mk), 512, None, 0, None, H.stream()))
+print(f'nt stored mask 512x512    : {t * 1e6:8.0f} us  {2.0 * M * 512 * 512 / t / 1e12:7.1f} TFLOP/s')
+tn_ws = torch.empty(int(H.lib().aln_wide_tn_ws_bytes(M, 512, 512)), dtype=torch.uint8, device='cuda')
+dw2 = torch.zeros(512, 512, device=dev)
+t = timeit(lambda: H.call('aln_wide_tn_gen', H.ptr(g), 512, H.ptr(sout), 15, H.ptr(w0), M, 512, 512, H.ptr(dw2), 512, H.ptr(tn_ws), H.stream()))
+print(f'tn_gen dW 512x512         : {t * 1e6:8.0f} us  {2.0 * M * 512 * 512 / t / 1e12:7.1f} TFLOP/s')

@@ -939,6 +939,59 @@ def test_wide_tn_weight_gradient_matches_fp32(H, M, N, K1, geo, relu1):
     assert torch.equal(again, dw)
 
 
+@pytest.mark.parametrize('M', [1000, 4500])
+def test_wide_generated_first_layer_kernels(H, M):
+    """semantic_features at LSeg width with its first hidden layer h1 = relu([geo_feat, 1] W0^T) GENERATED instead of stored
+    (autolabel/models.py:117-125; wide.hip round 5): layers 1 + 2 in one launch, the data gradient's ReLU' mask recomputed in the
+    accumulators, the weight gradient's operand recomputed per 32 x 32 block.  Against the stored-h1 launches: the mask is bit for
+    bit the same (one matrix instruction over the same 16 inputs), the two GEMMs differ by the summation order only; plus fp32."""
+    g = torch.Generator().manual_seed(M)
+    G, Hd = 15, 512
+    sout = (torch.randn(M, 16, generator=g) * 0.5).half().cuda()
+    w0 = (torch.randn(Hd, 16, generator=g) / 4.0).half().cuda()
+    w1 = (torch.randn(Hd, Hd, generator=g) / Hd ** 0.5).half().cuda()
+    perm16 = [4 * (q >> 3) + (q & 3) + 8 * ((q & 7) >> 2) for q in range(16)]
+    kperm = torch.tensor([16 * (c // 16) + perm16[c % 16] for c in range(Hd)], device='cuda')
+    w1p = w1[:, kperm].contiguous()
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    nan = lambda *shape: torch.full(shape, float('nan'), dtype=torch.float16, device='cuda')
+    # stored route: h1, then h2
+    h1, h2 = nan(M, Hd), nan(M, Hd)
+    H.call('aln_wide_nt', None, 0, 0, 0, H.ptr(sout), G, M, Hd, H.ptr(w0), 16, H.ptr(h1), Hd, 1, None, 0, None, 0, H.ptr(flag), H.stream())
+    H.call('aln_wide_nt', H.ptr(h1), Hd, Hd, 0, None, G, M, Hd, H.ptr(w1), Hd, H.ptr(h2), Hd, 1, None, 0, None, 0, H.ptr(flag), H.stream())
+    h2g = nan(M, Hd)
+    H.call('aln_wide_nt_gen', H.ptr(sout), G, H.ptr(w0), M, Hd, Hd, H.ptr(w1p), Hd, H.ptr(h2g), Hd, 1, H.ptr(flag), H.stream())
+    A = _geo_block(sout.cpu(), G)
+    want_h1 = torch.relu(A @ w0.cpu().float().t()).half().float()
+    want_h2 = torch.relu(want_h1 @ w1.cpu().float().t())
+    assert flag.item() == 0 and torch.isfinite(h2g).all(), 'every output tile written'
+    assert torch.equal(h1.cpu().float(), want_h1) or (h1.cpu().float() - want_h1).abs().max() <= 1e-3
+    tol = 2e-3 * max(1.0, want_h2.abs().max().item())
+    assert (h2g.cpu().float() - want_h2).abs().max().item() <= tol
+    assert (h2g.float() - h2.float()).abs().max().item() <= 2e-3 * max(1.0, want_h2.abs().max().item())
+    # data gradient into the generated layer: (dH2 W1) * (h1 > 0), W = W1^T as [N = h1 features][K = h2 features]
+    dh2 = (torch.randn(M, Hd, generator=g) * 0.1).half().cuda()
+    w1t = w1.t().contiguous()
+    d_a, d_b = nan(M, Hd), nan(M, Hd)
+    H.call('aln_wide_nt', H.ptr(dh2), Hd, Hd, 0, None, G, M, Hd, H.ptr(w1t), Hd, H.ptr(d_a), Hd, 0, H.ptr(h1), Hd, None, 0, H.ptr(flag), H.stream())
+    H.call('aln_wide_nt_maskgen', H.ptr(dh2), Hd, M, Hd, Hd, H.ptr(w1t), Hd, H.ptr(d_b), Hd, H.ptr(sout), G, H.ptr(w0), H.ptr(flag), H.stream())
+    assert torch.equal(d_a, d_b), f'{(d_a != d_b).sum().item()} elements differ between the stored and the recomputed mask'
+    want_d = (dh2.cpu().float() @ w1t.cpu().float().t()) * (want_h1 > 0)
+    assert (d_b.cpu().float() - want_d).abs().max().item() <= 2e-3 * max(1.0, want_d.abs().max().item())
+    # weight gradient behind the generated layer: dW1 += dH2^T h1
+    nbytes = int(H.lib().aln_wide_tn_ws_bytes(M, Hd, Hd))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    dw_a, dw_b, dw_c = (torch.ones(Hd, Hd, device='cuda') for _ in range(3))
+    H.call('aln_wide_tn', H.ptr(dh2), Hd, H.ptr(h1), Hd, Hd, 0, None, G, M, Hd, H.ptr(dw_a), Hd, H.ptr(ws), H.stream())
+    H.call('aln_wide_tn_gen', H.ptr(dh2), Hd, H.ptr(sout), G, H.ptr(w0), M, Hd, Hd, H.ptr(dw_b), Hd, H.ptr(ws), H.stream())
+    H.call('aln_wide_tn_gen', H.ptr(dh2), Hd, H.ptr(sout), G, H.ptr(w0), M, Hd, Hd, H.ptr(dw_c), Hd, H.ptr(ws), H.stream())
+    want_dw = dh2.cpu().float().t() @ want_h1
+    scale = max(1.0, want_dw.abs().max().item())
+    assert (dw_b.cpu() - 1.0 - want_dw).abs().max().item() <= 2e-3 * scale
+    assert (dw_b - dw_a).abs().max().item() <= 1e-3 * scale
+    assert torch.equal(dw_b, dw_c), 'fixed-order slab reduction: bit-reproducible'
+
+
 def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
     """aln_encode_fwd_cells generates the jittered cell points inside the kernel: same bits as encoding aln_grid_points' output,
     for both the tile kernel and the level-phased kernels, at a cell offset."""
