@@ -14,6 +14,7 @@
 // v_mfma_f32_32x32x16_f16 throughout; operand tiles staged in LDS; k_wide_tn reads them with ds_read_b64_tr_b16.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) h16 lds_h16w;
 typedef short s16x4w __attribute__((__vector_size__(4 * sizeof(short))));
@@ -341,7 +342,7 @@ struct WideGen { const h16* geo; int G; const h16* w0; };
 template <int BN, int MT>
 __global__ __launch_bounds__(256) void k_wide_nt_gen(WideNT p, WideGen g) {
   constexpr int BM = 128 * MT, NB = BN / 32, BK = 64, CG = BN < 64 ? BN : 64, EP = CG + 4;
-  constexpr int OPER = BN * BK * 2, EPIL = 4 * 32 * EP * 4;
+  constexpr int OPER = 2 * BN * BK * 2, EPIL = 4 * 32 * EP * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem_w[OPER > EPIL ? OPER : EPIL];
   h16* Ws = (h16*)smem_w;
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5, c = lane & 31;
@@ -379,12 +380,21 @@ __global__ __launch_bounds__(256) void k_wide_nt_gen(WideNT p, WideGen g) {
     }
   };
   gen(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
+  // weight tiles double-buffered: the tile of k-step kt + 1 is in flight while kt is multiplied (ONE barrier per tile; with a single
+  // buffer the whole load latency sat between two barriers and only other blocks' waves could hide it).  Buffer indices are
+  // compile-time constants (two k-tiles per loop trip).
+  auto load_w = [&](int kt, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(Ws + (wave * NB + i) * 512), 16, 0, 0);
-    __syncthreads();
+                                       (__attribute__((address_space(3))) void*)(Ws + buf * (BN * BK) + (wave * NB + i) * 512), 16, 0, 0);
+  };
+  auto tile = [&](int kt, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    __syncthreads();            // (vmcnt drained before the barrier: tile kt has landed; every wave is done with the other buffer)
+    if (kt + 1 < nkt) load_w(kt + 1, std::integral_constant<int, buf ^ 1>{});
+    const h16* Wt = Ws + buf * (BN * BK);
 #pragma unroll
     for (int f2 = 0; f2 < 2; ++f2) {
       const int fb = 2 * kt + f2;
@@ -395,13 +405,17 @@ __global__ __launch_bounds__(256) void k_wide_nt_gen(WideNT p, WideGen g) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const int wr_ = b * 32 + c;
-          const h16x8 wa = *(const h16x8*)(Ws + wr_ * BK + (((ks * 2 + hf) ^ (wr_ & 7)) * 8));
+          const h16x8 wa = *(const h16x8*)(Wt + wr_ * BK + (((ks * 2 + hf) ^ (wr_ & 7)) * 8));
 #pragma unroll
           for (int t = 0; t < MT; ++t) acc[t][b] = wmfma(wa, xb[f2 & 1][t][k2], acc[t][b]);
         }
       }
     }
-    __syncthreads();
+  };
+  load_w(0, std::integral_constant<int, 0>{});
+  for (int kt = 0; kt < nkt; kt += 2) {
+    tile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
   }
   const bool bad = wide_epilogue<BN, MT>(p, acc, smem_w, m0, n0, wave, lane);
   if (bad && p.found_inf) *p.found_inf = 1;
@@ -656,95 +670,14 @@ extern "C" int aln_wide_tn(const void* g, int32_t ldg, const void* a1, int32_t l
   return 0;
 }
 
-// dW[N, K] += G[M, N]^T relu([geo_feat, 1] W0[K, 16]^T): the weight gradient of the layer BEHIND the generated one.  k_wide_tn with its A
-// tile (64 samples x 256 features of h1) GENERATED into LDS instead of fetched: wave w computes the features [64 w, 64 w + 64) of the
-// tile's 64 samples -- four matrix instructions, ReLU + pack, sixteen 8-byte LDS stores -- while the G tile is staged as before.  h1 (1 GB
-// at 2^20 rows) is neither stored nor read; 12 % more matrix work, the same fragment reads.
-__global__ __launch_bounds__(256) void k_wide_tn_gen(WideTN p, WideGen g) {
-  __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PG];
-  __shared__ __attribute__((aligned(16))) h16 As[WTN_BM * WTN_PA];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
-  const int ntile = p.tn * p.tk, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int slab_i = (jj / ntile) * 8 + xcd, tile_i = jj % ntile;
-  if (slab_i * p.slab >= p.M) return;
-  const int n0 = (tile_i % p.tn) * WTN_TN, k0 = (tile_i / p.tn) * WTN_TK;
-  const int mlo = slab_i * p.slab, mhi = min(p.M, mlo + p.slab);
-  const int wn = (wave >> 1) * 64, wk = (wave & 1) * 128;
-  const int nbj = __builtin_amdgcn_readfirstlane(max(0, min(4, (p.K - k0 - wk + 31) / 32)));
-  f32x16 acc[2][4], zero;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = zero;
-  const WTile<WTN_PG> tG{(lds_h16w*)Gs};
-  const WTile<WTN_PA> tA{(lds_h16w*)As};
-  // W0 rows of this wave's two feature blocks of the tile (A operand of the generating instruction): resident
-  h16x8 w0f[2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) w0f[f] = *(const h16x8*)(g.w0 + (size_t)min(k0 + 64 * wave + 32 * f + c, p.K - 1) * 16 + 8 * hf);
-  h16x8 gr[4], gs[2];   // staged G chunks; [geo_feat, 1] rows of the tile's two 32-sample blocks (B operand of the generating instruction)
-  auto fetch = [&](int mt) {
-    h16x8 z;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + 256 * i, r = ch >> 4, cc = (ch & 15) * 8;
-      gr[i] = z;
-      if (mt + r < mhi && n0 + cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)(mt + r) * p.ldg + n0 + cc);
-    }
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      const int m = mt + 32 * sb + c;
-      gs[sb] = m < mhi ? wide_geo_chunk(g.geo, g.G, (size_t)m, hf) : z;   // (rows beyond the slab: G is zero there as well)
-    }
-  };
-  fetch(mlo);
-  for (int mt = mlo; mt < mhi; mt += WTN_BM) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Gs + (ch >> 4) * WTN_PG + (ch & 15) * 8) = gr[i]; }
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        // D[feature][sample]: lane = sample 32 sb + c, register r = feature 64 wave + 32 f + 8 (r / 4) + 4 hf + r % 4
-        const f32x16 h = wmfma(w0f[f], gs[sb], zero);
-        h16* row = As + (32 * sb + c) * WTN_PA + 64 * wave + 32 * f + 4 * hf;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *(wu32x2*)(row + 8 * q) = (wu32x2){wrelu2(h[4 * q], h[4 * q + 1]), wrelu2(h[4 * q + 2], h[4 * q + 3])};
-      }
-    __syncthreads();
-    if (mt + WTN_BM < mhi) fetch(mt + WTN_BM);
-#pragma unroll
-    for (int ks = 0; ks < WTN_BM / 16; ++ks) {
-      h16x8 ga[2], ab[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) ga[i] = wtr_frag(tG, wn + 32 * i, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (j < nbj) ab[j] = wtr_frag(tA, wk + 32 * j, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < nbj) acc[i][j] = wmfma(ga[i], ab[j], acc[i][j]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + wk + 32 * j + c;
-      if (k >= p.K) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn + 32 * i + 8 * (r >> 2) + 4 * hf + (r & 3);
-        if (n < p.N) p.ws[((size_t)slab_i * p.N + n) * p.K + k] = acc[i][j][r];
-      }
-    }
-}
-// (A/B candidate) register form: h1^T straight from the generating instruction's accumulators into the B operands, samples permuted
+// dW[N, K] += G[M, N]^T relu([geo_feat, 1] W0[K, 16]^T): the weight gradient of the layer BEHIND the generated one.  The A operand (h1,
+// 1 GB at 2^20 rows) is neither read nor staged: per 32 samples and 32 features ONE matrix instruction leaves h1^T in the
+// accumulator layout (lane = feature, registers = samples 8 (r / 4) + 4 hf + r % 4), whose halves are the B operands of two 16-sample
+// k-steps with the SAMPLE index permuted inside every group of 16; the G fragments take the same sample order through the row
+// offsets of their transposing reads.  Same tiles, slabs and fixed-order reduction as k_wide_tn; a third of its LDS reads, 25 % more
+// matrix instructions (both waves of a k half generate the same block).  Measured in the LSeg step (2^20 rows): 771 us, against 728
+// for k_wide_tn reading a stored h1 and 818 for a form that generates the A tile into LDS once per block -- the stored form is
+// the faster KERNEL; what pays is that h1 no longer exists (the launch that wrote it: 414 us, and its read by the second layer).
 template <class T>
 __device__ inline h16x8 wtr_frag_perm(T t, int col0, int ks, int lane) {
   const int hf = lane >> 5;
@@ -756,7 +689,7 @@ __device__ inline h16x8 wtr_frag_perm(T t, int col0, int ks, int lane) {
   u.s.l = lo; u.s.h = hi;
   return u.v;
 }
-__global__ __launch_bounds__(256) void k_wide_tn_genr(WideTN p, WideGen g) {
+__global__ __launch_bounds__(256) void k_wide_tn_gen(WideTN p, WideGen g) {
   __shared__ __attribute__((aligned(16))) h16 Gs[WTN_BM * WTN_PG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
   const int ntile = p.tn * p.tk, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -835,8 +768,6 @@ __global__ __launch_bounds__(256) void k_wide_tn_genr(WideTN p, WideGen g) {
       }
     }
 }
-static int g_wide_variant = 0;
-extern "C" int aln_debug_wide_variant(int v) { g_wide_variant = v; return 0; }
 extern "C" int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int32_t G, const void* w0, int32_t M, int32_t N, int32_t K,
                                float* dw, int32_t lddw, void* ws, void* stream) {
   ALN_REQUIRE(g && dw && ws && geo && w0 && M >= 0 && N > 0, "wide_tn_gen: bad arguments");
@@ -850,8 +781,7 @@ extern "C" int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int3
   wide_tn_split(M, N, K, tn, tk, slab, slabs);
   p.slab = slab; p.tn = tn; p.tk = tk;
   const WideGen gg{(const h16*)geo, G, (const h16*)w0};
-  if (g_wide_variant & 1) hipLaunchKernelGGL(k_wide_tn_genr, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p, gg);
-  else hipLaunchKernelGGL(k_wide_tn_gen, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p, gg);
+  hipLaunchKernelGGL(k_wide_tn_gen, dim3((unsigned)((slabs + 7) / 8 * 8 * tn * tk)), dim3(256), 0, (hipStream_t)stream, p, gg);
   ALN_CHECK_LAUNCH("wide_tn_gen");
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(k_wide_dw_reduce, dim3((unsigned)((nk + 255) / 256 < 2048 ? (nk + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream,

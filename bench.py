@@ -57,8 +57,10 @@ def parse():
     p.add_argument('--march-samples', type=int, default=64)
     p.add_argument('--march-thresh', type=float, default=10.0)
     p.add_argument('--no-lseg', action='store_true', help='skip the LSeg-width (512-d feature head) leg')
+    p.add_argument('--no-dp1', action='store_true', help='skip the leg that runs the data-parallel forms of the step through a one-rank RCCL group')
     p.add_argument('--no-dropin', action='store_true', help="skip the leg that times the reference's own route (scene directory -> SimpleTrainer)")
     p.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 PMC passes behind roofline.traffic')
+    p.add_argument('--dp1-child', action='store_true', help=argparse.SUPPRESS)    # the child run behind `dp_world1`
     p.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)   # the run rocprofv3 wraps: a few eager steps, no JSON
     return p.parse_args()
 
@@ -104,7 +106,8 @@ class Workload:
         self.bound = float(((hi - lo) - (lo + hi) * 0.5).max())  # autolabel/model_utils.py:62-63
         self.n_classes = scene['n_classes']
 
-    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None, semantic_weight=1.0, overlap_comm=True, shard_optimizer=False):
+    def engine(self, init_seed=0, march=False, feature_dim=None, world=1, pg=None, semantic_weight=1.0, overlap_comm=True, shard_optimizer=False,
+               exchange_at_world_1=False):
         from autolabel_amd.engine import TrainEngine
         from autolabel_amd.parallel import broadcast_parameters
         from autolabel_amd.pipeline import HipPipeline, ModelLayout, Params
@@ -121,7 +124,7 @@ class Workload:
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)
             pipe.mark_untrained_grid(t.world_to_camera(), (t.desc.fx, t.desc.fy, t.desc.cx, t.desc.cy), size=(t.w, t.h))
         return TrainEngine(pipe, feature_loss=True, process_group=pg, semantic_weight=semantic_weight, overlap_comm=overlap_comm,
-                           shard_optimizer=shard_optimizer)
+                           shard_optimizer=shard_optimizer, exchange_at_world_1=exchange_at_world_1)
 
     def renderer(self, eng, march):
         """render callable for quality.heldout_metrics: 256 rows per ray along the whole ray (dense) / 128 rows inside occupied cells."""
@@ -216,12 +219,27 @@ def quality_runs(wl, args, first, march):
         torch.cuda.empty_cache()
     agg = lambda k, f: float(f([r[k] for r in runs]))
     mean = lambda v: sum(v) / len(v)
-    return {'psnr_db_mean': agg('psnr_db', mean), 'psnr_db_min': agg('psnr_db', min), 'miou_mean': agg('miou', mean), 'miou_min': agg('miou', min),
+    return {'vs_oracle': None if march else oracle_gate_record(), 'psnr_db_mean': agg('psnr_db', mean), 'psnr_db_min': agg('psnr_db', min), 'miou_mean': agg('miou', mean), 'miou_min': agg('miou', min),
             'depth_l1_m_mean': agg('depth_l1_m', mean), 'depth_l1_m_max': agg('depth_l1_m', max), 'n_runs': len(runs),
             'steps': args.quality_steps, 'batch_per_gpu': B, 'lr': '5e-3, halved at 60 % and 80 % of the steps', 'runs': runs,
             'note': 'held-out frames (every 20th) of the bench scene at the training resolution; labels on every 10th training frame only; '
                     'seeds = (initialisation, data, sample noise); training is bit-reproducible, so a seed set always gives these numbers; '
                     'oracle parity of the same metrics: tests/test_gpu_quality.py'}
+
+
+def oracle_gate_record():
+    """HIP-vs-oracle quality deltas of the matched-quality gate, read from the COMMITTED record of its last multi-seed run
+    (profiles/r05_quality_gate_5x5.json, written by scripts/dev/quality_gate_run.py = tests/test_gpu_quality.run_gate with 5 + 5 seeds):
+    the oracle trainees are far too slow to run inside a bench; this only carries their numbers next to the bench's own quality."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r05_quality_gate_5x5.json')
+    try:
+        r = json.load(open(path))
+    except Exception:
+        return None
+    return {'source': 'profiles/r05_quality_gate_5x5.json (committed record, not measured in this run)',
+            'delta_psnr_db': r.get('delta_psnr_db'), 'delta_miou_pt': r.get('delta_miou_pt'), 'se_delta_psnr_db': r.get('se_delta_psnr_db'),
+            'se_delta_miou_pt': r.get('se_delta_miou_pt'), 'n_hip_runs': len(r.get('hip', [])), 'n_oracle_runs': len(r.get('oracle_runs', [])),
+            'two_sided_ok': r.get('two_sided_ok'), 'gate_model': r.get('model'), 'gate_scene': r.get('scene')}
 
 
 def scatter_roofline(eng, events, rows_per_step, n_event_steps):
@@ -363,6 +381,63 @@ def timed_leg(wl, args, eng, B, dseed, mseed, frange, use_graph, world, sync):
             graphed.counter.fill_(done[0])
             graphed.steps = done[0]
     return dt, terms, events, step, done
+
+
+def dp_world1_leg(wl, args, B):
+    """The data-parallel forms of the step on ONE GPU: a one-rank `nccl` (= RCCL) process group, every collective really issued
+    (TrainEngine(exchange_at_world_1=True)).  What this measures is what a rank's step costs once the gradient takes the data-parallel
+    route -- table gradient through HBM instead of the optimizer inside the scatter, wire-format kernels, collectives, the communication
+    stream, a separate optimizer pass over the table (replicated) or its owned slices (sharded) -- NOT scaling: nothing crosses xGMI."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return {'skipped': 'a process group already exists'}
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=wl.device)
+    out = {'backend': 'nccl (RCCL)', 'world': 1, 'note': 'one rank: the collectives run but move nothing; per-rank cost of the data-parallel '
+           'route, not a scaling measurement'}
+    a2 = argparse.Namespace(**vars(args))
+    a2.event_steps = 0
+    try:
+        for name, overlap, graph, shard in [('dp_simple', False, False, False), ('dp_overlap', True, False, False), ('dp_sharded', True, False, True),
+                                            ('dp_graph', True, True, False), ('dp_sharded_graph', True, True, True)]:
+            try:
+                e = wl.engine(SEEDS[0][0], pg=dist.group.WORLD, overlap_comm=overlap, shard_optimizer=shard, exchange_at_world_1=True)
+                dt = timed_leg(wl, a2, e, B, SEEDS[0][1], SEEDS[0][2], None, graph, 1, torch.cuda.synchronize)[0]
+                out[name] = {'ms_per_step': 1000 * dt / args.steps, 'rays_per_s': B * args.steps / dt, 'hip_graph': graph}
+                del e
+            except Exception as ex:
+                out[name] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
+            torch.cuda.empty_cache()
+    finally:
+        dist.destroy_process_group()
+    return out
+
+
+def dp_world1_in_child(args, B, timeout=240):
+    """dp_world1_leg in a child process under a timeout: RCCL set-up is the one part of a default run that could hang on a box where it
+    has never run, and the JSON line of this process must not depend on it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--dp1-child', '--steps', str(args.steps), '--warmup', str(args.warmup), '--batch', str(B),
+           '--frames', str(args.frames), '--feature-dim', str(args.feature_dim)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {'error': f'did not finish within {timeout} s'}
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'error': f'child exited with {r.returncode}: {r.stderr[-300:]}'}
+    return json.loads(lines[-1])
+
+
+def dp1_child(args):
+    import torch
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    wl = Workload(args, device)
+    print(json.dumps(dp_world1_leg(wl, args, args.batch)), flush=True)
 
 
 def marching_leg(wl, args, B):
@@ -611,6 +686,8 @@ def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    if args.dp1_child:
+        return dp1_child(args)
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -795,6 +872,8 @@ def main():
             res['render_dense_Mrays_per_s'] = render_dense
             if not args.no_lseg and args.feature_dim != 512:
                 res['lseg'] = lseg_leg(wl, args, B)
+            if not args.no_dp1:
+                res['dp_world1'] = dp_world1_in_child(args, B)
             if not args.no_dropin:
                 try:
                     res['dropin'] = dropin_leg(wl, args, B)

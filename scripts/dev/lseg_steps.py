@@ -5,10 +5,6 @@ import argparse, torch
 import bench
 sys.argv = [sys.argv[0], "--feature-dim", "512"]; args = bench.parse()
 args.feature_dim = 512
-import ctypes
-from autolabel_amd import hip as _H
-if os.environ.get('ALN_WIDE_VARIANT'):
-    _H.lib().aln_debug_wide_variant(int(os.environ['ALN_WIDE_VARIANT']))
 wl = bench.Workload(args, torch.device('cuda', 0))
 eng = wl.engine(bench.SEEDS[0][0], feature_dim=512, semantic_weight=0.0)
 batch = wl.train.alloc_batch(4096)

@@ -3,7 +3,7 @@
 export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/st
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --render-frames 0 --no-graph --event-steps 0 --quality-steps 0 --no-march --no-lseg --no-pmc --no-dropin > /tmp/st.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --render-frames 0 --no-graph --event-steps 0 --quality-steps 0 --no-march --no-lseg --no-pmc --no-dropin --no-dp1 > /tmp/st.log 2>&1 < /dev/null
 cp /tmp/st/*/*kernel_stats.csv $O/r04_train_kernel_stats.csv
 python3 - <<'PY'
 import csv,os

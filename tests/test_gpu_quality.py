@@ -124,6 +124,14 @@ def run_gate(steps, batch, s1, s2, n_frames, w, h, levels, log2_T, hip_seeds, or
            'mean_oracle': {k: mean(q_o, k) for k in ('psnr_db', 'depth_l1_m', 'miou')},
            'spread_hip_psnr_db': float(np.ptp([q['psnr_db'] for q in q_h])), 'spread_oracle_psnr_db': float(np.ptp([q['psnr_db'] for q in q_o])),
            'loss_hip_every_100': lh, 'loss_oracle_every_100': lo}
+    # standard error of each side's mean and of the difference (seeds are independent draws of the sample noise; n is small, so this is
+    # an indication of what the gate can resolve, not a test statistic)
+    se = lambda qs, k: float(np.std([q[k] for q in qs], ddof=1) / np.sqrt(len(qs))) if len(qs) > 1 else None
+    rec['se_hip'] = {k: se(q_h, k) for k in ('psnr_db', 'miou')}
+    rec['se_oracle'] = {k: se(q_o, k) for k in ('psnr_db', 'miou')}
+    both = rec['se_hip']['psnr_db'] is not None and rec['se_oracle']['psnr_db'] is not None
+    rec['se_delta_psnr_db'] = float(np.hypot(rec['se_hip']['psnr_db'], rec['se_oracle']['psnr_db'])) if both else None
+    rec['se_delta_miou_pt'] = float(100 * np.hypot(rec['se_hip']['miou'], rec['se_oracle']['miou'])) if both else None
     rec['delta_psnr_db'] = rec['mean_hip']['psnr_db'] - rec['mean_oracle']['psnr_db']
     rec['delta_miou_pt'] = 100 * (rec['mean_hip']['miou'] - rec['mean_oracle']['miou'])
     rec['delta_depth_l1_m'] = rec['mean_hip']['depth_l1_m'] - rec['mean_oracle']['depth_l1_m']
