@@ -193,7 +193,10 @@ static int adam_launch(float* params, float* grads, float* m, float* v, void* ta
     }
     rg.n = n_ranges; rg.mlp_mv = at; n_work += at;
   }
-  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_work > 0 ? n_work : 1, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
+  // four parameters per thread at least: the arrival ticket at the end is ONE address, so the launch cannot be shorter than its
+  // blocks' atomics one after the other (~20 ns each) -- 243 blocks for the 62 K MLP parameters of the single-GPU step took 10.7 us,
+  // 2048 blocks for the 0.57 M of the LSeg heads 48 us (profiles/r05_lseg_leg_kernel_stats_rocprofv3.csv), for microseconds of work
+  hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_work > 0 ? (n_work + 3) / 4 : 1, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
                      (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, rg, counts, step_dev);
   ALN_CHECK_LAUNCH("adam");
   return 0;
