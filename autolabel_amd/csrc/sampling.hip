@@ -329,6 +329,7 @@ struct CompOut {
   int N, S1, S2, C, Cpad, D; float bg;
   float* image; float* semantic; float* features;
   const float* tile_sums;   // optional [M / 32][96]: per-tile sums of w * f (64) and w * logits (<= 32) left by aln_sem_heads_fwd_sums
+  const float* feat_sums;   // optional [M / 32][D]: per-tile sums of w * feat left by the producer of feat (aln_wide_nt_gen): feat rows are not read
 };
 
 __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
@@ -360,6 +361,17 @@ __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
         for (int t = 0; t < t2; ++t) a += a2[t * 96 + ch];
         if (ch < 64) { if (p.features) p.features[(size_t)ray * p.D + ch] = a; }
         else if (ch - 64 < p.C && p.semantic) p.semantic[(size_t)ray * p.C + ch - 64] = a;
+      }
+    }
+    if (p.feat_sums) {   // the ray's tiles in a fixed order: coarse pass, then fine pass
+      const int t1 = p.S1 / 32, t2 = p.S2 / 32;
+      const float* a1 = p.feat_sums + (size_t)ray * t1 * p.D;
+      const float* a2 = p.feat_sums + ((size_t)p.N * t1 + (size_t)ray * t2) * p.D;
+      for (int ch = lane; ch < p.D; ch += 64) {
+        float a = 0.f;
+        for (int t = 0; t < t1; ++t) a += a1[(size_t)t * p.D + ch];
+        for (int t = 0; t < t2; ++t) a += a2[(size_t)t * p.D + ch];
+        p.features[(size_t)ray * p.D + ch] = a;
       }
     }
     // channel sums: `lpr` lanes share a row (one 16-byte chunk each), so one wave instruction reads 64 / lpr whole rows;
@@ -409,9 +421,22 @@ extern "C" int aln_composite_out(const float* w_row, const int32_t* cidx_row, co
   ALN_REQUIRE((!logits || Cpad % 8 == 0) && (!feat || D % 8 == 0), "composite_out: Cpad and D must be multiples of 8");
   if (N <= 0) return 0;
   CompOut p{w_row, cidx_row, (const h16*)color_out, (const h16*)logits, (const h16*)feat, wsum, N, S1, S2, C, Cpad, D, bg,
-            image, semantic, features, tile_sums};
+            image, semantic, features, tile_sums, nullptr};
   hipLaunchKernelGGL(k_composite_out, dim3(N < 65535 ? N : 65535), dim3(64), 0, (hipStream_t)stream, p);
   ALN_CHECK_LAUNCH("composite_out");
+  return 0;
+}
+// image as aln_composite_out; features[ray][0 .. D) = the ray's per-tile sums feat_sums[M / 32][D] added up in a fixed order (the producer
+// of the per-sample activation left them: aln_wide_nt_gen).  No per-sample rows are read.  Sample counts must be multiples of 32.
+extern "C" int aln_composite_out_featsums(const float* w_row, const int32_t* cidx_row, const void* color_out, const float* wsum, int32_t N,
+                                          int32_t S1, int32_t S2, int32_t D, float bg, float* image, float* features, const float* feat_sums,
+                                          void* stream) {
+  ALN_REQUIRE(w_row && cidx_row && color_out && wsum && image && features && feat_sums, "composite_out_featsums: NULL pointer");
+  ALN_REQUIRE(S1 % 32 == 0 && S2 % 32 == 0 && D > 0, "composite_out_featsums: sample counts must be multiples of 32");
+  if (N <= 0) return 0;
+  CompOut p{w_row, cidx_row, (const h16*)color_out, nullptr, nullptr, wsum, N, S1, S2, 0, 0, D, bg, image, nullptr, features, nullptr, feat_sums};
+  hipLaunchKernelGGL(k_composite_out, dim3(N < 65535 ? N : 65535), dim3(64), 0, (hipStream_t)stream, p);
+  ALN_CHECK_LAUNCH("composite_out_featsums");
   return 0;
 }
 

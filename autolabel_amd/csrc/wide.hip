@@ -72,6 +72,9 @@ struct WideNT {
   // layer this gradient flows into is recomputed in the accumulator layout -- ONE matrix instruction per 32 x 32 block (K = 16) --
   // from the density head's output rows and W0 [N, 16] instead of being read back
   const h16* mgeo; const h16* mw0; int mG;
+  // per 32-row tile sums of w[row] * y[row][n] (fp32 [ceil(M / 32)][N]): the compositing of a per-sample activation without a second
+  // pass over its rows (k_wide_nt_gen<.., SUMS>; a tile must lie inside one ray: sample counts multiples of 32)
+  const float* w_row; float* tsums;
 };
 
 // h1 = relu([geo_feat, 1] W0^T) on the fly.  wmfma(W0 fragment, geo fragment) leaves C[feature][sample]: lane = sample, register r
@@ -103,8 +106,9 @@ __device__ inline h16x8 wide_geo_chunk(const h16* geo, int G, size_t row, int hf
 // 32 b + 8 (r / 4) + 4 hf + r % 4): storing from there writes 8-byte pieces to 32 different rows per instruction (measured: the
 // 1M x 512 output cost more than the GEMM).  Each wave therefore turns its 32 x CG fp32 block through LDS and then works
 // row-contiguously: 8 lanes cover 64 columns of a row, so mask / addend loads and the fp16 stores are 16 bytes per lane.
-template <int BN, int MT>
-__device__ inline bool wide_epilogue(const WideNT& p, f32x16 (&acc)[MT][BN / 32], unsigned char* smem_w, int m0, int n0, int wave, int lane) {
+template <int BN, int MT, bool SUMS = false>
+__device__ inline bool wide_epilogue(const WideNT& p, f32x16 (&acc)[MT][BN / 32], unsigned char* smem_w, int m0, int n0, int wave, int lane,
+                              const float* wrow_lds = nullptr /* SUMS: the wave's MT x 32 row weights, staged in LDS by the kernel's prologue */) {
   constexpr int CG = BN < 64 ? BN : 64, EP = CG + 4;
   const int hf = lane >> 5, c = lane & 31;
   bool bad = false;
@@ -124,6 +128,7 @@ __device__ inline bool wide_epilogue(const WideNT& p, f32x16 (&acc)[MT][BN / 32]
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       constexpr int LPR = CG / 8;          // lanes per row (8 columns each)
+      float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // SUMS: this lane's share of sum_rows w[row] * y[row][col .. col + 7]
 #pragma unroll
       for (int it = 0; it < 32 / (64 / LPR); ++it) {
         const int r = it * (64 / LPR) + lane / LPR, col = (lane % LPR) * 8;
@@ -153,9 +158,26 @@ __device__ inline bool wide_epilogue(const WideNT& p, f32x16 (&acc)[MT][BN / 32]
             if (j < 4 || full) bad |= !(fabsf(v[j]) <= 65504.f);
             o[j] = (h16)v[j];
           }
+          if constexpr (SUMS) {     // (the fp16 values as stored: what a pass over the rows would read)
+            const float w = wrow_lds[t * 32 + r];     // (a global load here sat on the epilogue's critical path eight times per wave: +84 us)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < 4 || full) ps[j] += w * (float)o[j];
+          }
           h16* yp = p.y + (size_t)m * p.ldy + n;
           if (full && (p.ldy & 7) == 0) *(h16x8*)yp = o;               // one 16-byte store per lane
           else { *(h16x4*)yp = (h16x4){o[0], o[1], o[2], o[3]}; if (full) *(h16x4*)(yp + 4) = (h16x4){o[4], o[5], o[6], o[7]}; }
+        }
+      }
+      if constexpr (SUMS) {   // fold the row groups (lanes LPR apart hold the same columns): a fixed tree, then one store per column group
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ps[j] += __shfl_xor(ps[j], off);
+        const int mrow = m0 + (wave * MT + t) * 32, n = n0 + cg * CG + (lane % LPR) * 8;
+        if (lane < LPR && mrow < p.M && n < p.N) {
+          float* dst = p.tsums + (size_t)(mrow / 32) * p.N + n;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (n + j < p.N) dst[j] = ps[j];
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -339,7 +361,7 @@ struct WideGen { const h16* geo; int G; const h16* w0; };
 // MT row blocks of 32 samples per wave (block = 128 MT rows): with MT = 2 a k-step reads four weight fragments for eight matrix
 // instructions -- half the LDS bytes per instruction of the 32-row wave tile, which sits at the LDS bandwidth (4 x 1 KB per 128 clk and
 // SIMD) -- and there is no sample tile whose staging registers would push the 64-row tile past 256 VGPRs (k_wide_nt).
-template <int BN, int MT>
+template <int BN, int MT, bool SUMS>
 __global__ __launch_bounds__(256) void k_wide_nt_gen(WideNT p, WideGen g) {
   constexpr int BM = 128 * MT, NB = BN / 32, BK = 64, CG = BN < 64 ? BN : 64, EP = CG + 4;
   constexpr int OPER = 2 * BN * BK * 2, EPIL = 4 * 32 * EP * 4;
@@ -368,6 +390,13 @@ __global__ __launch_bounds__(256) void k_wide_nt_gen(WideNT p, WideGen g) {
   h16x8 gb[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) gb[t] = wide_geo_chunk(g.geo, g.G, (size_t)min(m0 + (wave * MT + t) * 32 + c, p.M - 1), hf);
+  __shared__ float wrow_s[SUMS ? 4 * MT * 32 : 1];
+  if constexpr (SUMS) {   // the wave's row weights: read by its own epilogue only (the barriers of the main loop lie in between)
+    if (hf == 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) { const int m = m0 + (wave * MT + t) * 32 + c; wrow_s[(wave * MT + t) * 32 + c] = m < p.M ? p.w_row[m] : 0.f; }
+    }
+  }
   const int nkt = p.K / BK;
   // the generated operands run one 32-feature block ahead of the matrix instructions that consume them
   h16x8 xb[2][MT][2];
@@ -417,7 +446,7 @@ __global__ __launch_bounds__(256) void k_wide_nt_gen(WideNT p, WideGen g) {
     tile(kt, std::integral_constant<int, 0>{});
     if (kt + 1 < nkt) tile(kt + 1, std::integral_constant<int, 1>{});
   }
-  const bool bad = wide_epilogue<BN, MT>(p, acc, smem_w, m0, n0, wave, lane);
+  const bool bad = wide_epilogue<BN, MT, SUMS>(p, acc, smem_w, m0, n0, wave, lane, &wrow_s[wave * MT * 32]);
   if (bad && p.found_inf) *p.found_inf = 1;
 }
 
@@ -433,7 +462,7 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
   p.M = M; p.N = N; p.K = p.a.K1 + (geo ? 16 : 0);
   p.w = (const h16*)w; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = relu;
   p.mask = (const h16*)mask; p.ldm = ldm; p.add = (const h16*)add; p.lda = lda; p.found_inf = found_inf;
-  p.mgeo = nullptr; p.mw0 = nullptr; p.mG = 0;
+  p.mgeo = nullptr; p.mw0 = nullptr; p.mG = 0; p.w_row = nullptr; p.tsums = nullptr;
   ALN_REQUIRE(ldw >= p.K, "wide_nt: weight rows shorter than K");
   hipStream_t s = (hipStream_t)stream;
   // (measured on the 1M x 512 x 512 layers: wave tile 32 x 128 at 2 waves/SIMD 1.3 ms; 64 x 128 needs > 256 VGPRs, one wave per
@@ -456,8 +485,10 @@ extern "C" int aln_wide_nt(const void* a1, int32_t lda1, int32_t K1, int32_t rel
 
 // Y[M, N] = epi(relu([geo_feat, 1] W0[K, 16]^T) W[N, K]^T): semantic_features' first two layers in one launch, the first one generated
 // (k_wide_nt_gen).  `w_perm`: W with the columns of every group of 16 in wide_kperm order (0-3, 8-11, 4-7, 12-15).
+// `tile_sums` (optional, with `w_row`): fp32 [ceil(M / 32)][N], tile t = sum over rows 32 t .. 32 t + 31 of w_row[row] * Y[row][:].
 extern "C" int aln_wide_nt_gen(const void* geo, int32_t G, const void* w0, int32_t M, int32_t N, int32_t K, const void* w_perm, int32_t ldw,
-                               void* y, int32_t ldy, int32_t relu, int32_t* found_inf, void* stream) {
+                               void* y, int32_t ldy, int32_t relu, const float* w_row, float* tile_sums, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(!tile_sums || w_row, "wide_nt_gen: tile sums need the row weights");
   ALN_REQUIRE(geo && w0 && w_perm && y && M >= 0 && N > 0, "wide_nt_gen: bad arguments");
   ALN_REQUIRE(K > 0 && K % 64 == 0 && N % 4 == 0 && ldw % 8 == 0 && ldw >= K && ldy % 4 == 0, "wide_nt_gen: K must be a multiple of 64, N / leading dimensions of 4 / 8");
   ALN_REQUIRE(((uintptr_t)w_perm & 15) == 0 && ((uintptr_t)w0 & 15) == 0 && ((uintptr_t)geo & 15) == 0, "wide_nt_gen: operands must be 16-byte aligned");
@@ -466,12 +497,16 @@ extern "C" int aln_wide_nt_gen(const void* geo, int32_t G, const void* w0, int32
   p.a = WideSrc{nullptr, 0, 0, 0, nullptr, 0};
   p.M = M; p.N = N; p.K = K; p.w = (const h16*)w_perm; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = relu;
   p.mask = nullptr; p.ldm = 0; p.add = nullptr; p.lda = 0; p.found_inf = found_inf; p.mgeo = nullptr; p.mw0 = nullptr; p.mG = 0;
+  p.w_row = w_row; p.tsums = tile_sums;
   const WideGen g{(const h16*)geo, G, (const h16*)w0};
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm + 7) / 8 * 8 * ((N + bn - 1) / bn))); };
   // (MT = 2, a 64-row wave tile at two waves per SIMD, measured slower in the step: 711 vs 669 us at 2^20 rows)
-  if (N > 64) hipLaunchKernelGGL((k_wide_nt_gen<128, 1>), grid(128, 128), dim3(256), 0, (hipStream_t)stream, p, g);
-  else if (N > 32) hipLaunchKernelGGL((k_wide_nt_gen<64, 1>), grid(128, 64), dim3(256), 0, (hipStream_t)stream, p, g);
-  else hipLaunchKernelGGL((k_wide_nt_gen<32, 1>), grid(128, 32), dim3(256), 0, (hipStream_t)stream, p, g);
+  if (tile_sums) {
+    ALN_REQUIRE(N > 64, "wide_nt_gen: tile sums are instantiated for the 128-column tile only");
+    hipLaunchKernelGGL((k_wide_nt_gen<128, 1, true>), grid(128, 128), dim3(256), 0, (hipStream_t)stream, p, g);
+  } else if (N > 64) hipLaunchKernelGGL((k_wide_nt_gen<128, 1, false>), grid(128, 128), dim3(256), 0, (hipStream_t)stream, p, g);
+  else if (N > 32) hipLaunchKernelGGL((k_wide_nt_gen<64, 1, false>), grid(128, 64), dim3(256), 0, (hipStream_t)stream, p, g);
+  else hipLaunchKernelGGL((k_wide_nt_gen<32, 1, false>), grid(128, 32), dim3(256), 0, (hipStream_t)stream, p, g);
   ALN_CHECK_LAUNCH("wide_nt_gen");
   return 0;
 }
@@ -487,7 +522,7 @@ extern "C" int aln_wide_nt_maskgen(const void* a1, int32_t lda1, int32_t M, int3
   p.a = WideSrc{(const h16*)a1, lda1, K, 0, nullptr, 0};
   p.M = M; p.N = N; p.K = K; p.w = (const h16*)w; p.ldw = ldw; p.y = (h16*)y; p.ldy = ldy; p.relu = 0;
   p.mask = nullptr; p.ldm = 0; p.add = nullptr; p.lda = 0; p.found_inf = found_inf;
-  p.mgeo = (const h16*)geo; p.mw0 = (const h16*)w0; p.mG = G;
+  p.mgeo = (const h16*)geo; p.mw0 = (const h16*)w0; p.mG = G; p.w_row = nullptr; p.tsums = nullptr;
   auto grid = [&](int bm, int bn) { return dim3((unsigned)(((M + bm - 1) / bm + 7) / 8 * 8 * ((N + bn - 1) / bn))); };
   if (N > 64) hipLaunchKernelGGL((k_wide_nt_dma<128, true>), grid(128, 128), dim3(256), 0, (hipStream_t)stream, p);
   else if (N > 32) hipLaunchKernelGGL((k_wide_nt_dma<64, true>), grid(128, 64), dim3(256), 0, (hipStream_t)stream, p);

@@ -342,10 +342,10 @@ class HipPipeline:
     def _gen(self):
         return self.P.wide_wp is not None
 
-    def _nt_gen(self, M, y, sout, relu=1, tag=None):
+    def _nt_gen(self, M, y, sout, relu=1, w_row=None, tile_sums=None, tag=None):
         fs, W = self.L.nets['semf'], self.P.wide_w['semf']
         self._k('aln_wide_nt_gen', H.ptr(sout), self.L.G, H.ptr(W[0]), M, fs.hidden, fs.hidden, H.ptr(self.P.wide_wp), fs.hidden, H.ptr(y), y.shape[1], relu,
-                None, H.stream(), tag=('wide', M, fs.hidden * (fs.hidden + 16)))
+                H.ptr(w_row), H.ptr(tile_sums), None, H.stream(), tag=('wide', M, fs.hidden * (fs.hidden + 16)))
 
     def _nt_maskgen(self, M, wt, y, a1, sout, tag=None):
         fs = self.L.nets['semf']
@@ -515,7 +515,10 @@ class HipPipeline:
                 h2 = g('wide_h2', (M, fs.hidden), f16)
                 if self._gen():
                     h1 = None
-                    self._nt_gen(M, h2, sout, tag=('sem', M))
+                    # the composited hidden activation comes out of the GEMM's epilogue as per-tile weighted sums: no second pass over h2
+                    if S1 % 32 == 0 and S2 % 32 == 0:
+                        c['h2_tile_sums'] = g('wide_h2_tile_sums', (M // 32, fs.hidden), f32_)
+                    self._nt_gen(M, h2, sout, w_row=w_row if 'h2_tile_sums' in c else None, tile_sums=c.get('h2_tile_sums'), tag=('sem', M))
                 else:
                     h1 = g('wide_h1', (M, fs.hidden), f16)
                     self._nt(M, fs.hidden, Wf[0], h1, geo=sout, relu=1, tag=('sem', M))
@@ -562,8 +565,12 @@ class HipPipeline:
             h2r = c['h2_ray32'] = g('h2_ray32', (N, fs.hidden), f32_)
             h2r16 = c['h2_ray16'] = g('h2_ray16', (N, fs.hidden), f16)
             f16r = g('feat_ray16', (N, fs.out_pad), f16)
-            H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), None, H.ptr(c['feat']), H.ptr(out['weights_sum']),
-                   N, S1, S2, L.C, L.Cpad, fs.hidden, float(bg), H.ptr(out['image']), None, H.ptr(h2r), None, H.stream())
+            if 'h2_tile_sums' in c:
+                H.call('aln_composite_out_featsums', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), H.ptr(out['weights_sum']), N, S1, S2, fs.hidden, float(bg),
+                       H.ptr(out['image']), H.ptr(h2r), H.ptr(c['h2_tile_sums']), H.stream())
+            else:
+                H.call('aln_composite_out', H.ptr(w_row), H.ptr(cidx), H.ptr(cout), None, H.ptr(c['feat']), H.ptr(out['weights_sum']),
+                       N, S1, S2, L.C, L.Cpad, fs.hidden, float(bg), H.ptr(out['image']), None, H.ptr(h2r), None, H.stream())
             H.call('aln_cast_f16', H.ptr(h2r), H.ptr(h2r16), h2r.numel(), H.stream())
             self._nt(N, fs.out_pad, P.wide_w['semf'][2], f16r, a1=h2r16, K1=fs.hidden, tag=('sem', N))
             H.call('aln_cast_f32', H.ptr(f16r), H.ptr(out['semantic_features']), f16r.numel(), H.stream())

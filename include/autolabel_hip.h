@@ -275,7 +275,13 @@ int aln_transpose_f16(const void* src /*[R,C]*/, int32_t R, int32_t C, void* dst
  *   aln_wide_nt_maskgen  Y[M,N] = (A[M,K] W[N,K]^T) * (h1 > 0): the data gradient flowing into the generated layer (h1: [M,N], W0: [N,16])
  *   aln_wide_tn_gen      dW[N,K] += G[M,N]^T h1[M,K]: the weight gradient of the layer behind it (ws: aln_wide_tn_ws_bytes(M, N, K)) */
 int aln_wide_nt_gen(const void* geo /*sigma_out [M,16]*/, int32_t G, const void* w0 /*[K,16] f16*/, int32_t M, int32_t N, int32_t K,
-                    const void* w_perm, int32_t ldw, void* y, int32_t ldy, int32_t relu, int32_t* found_inf, void* stream);
+                    const void* w_perm, int32_t ldw, void* y, int32_t ldy, int32_t relu, const float* w_row /*[M] or NULL*/,
+                    float* tile_sums /*[ceil(M/32), N] or NULL: sum over each 32-row tile of w_row[row] * Y[row][:]*/, int32_t* found_inf,
+                    void* stream);
+/* aln_composite_out for a per-sample activation whose producer left its per-tile weighted sums (aln_wide_nt_gen(tile_sums)): the image
+ * as usual, features[ray] = the ray's tiles added up in a fixed order; no [M, D] rows are read */
+int aln_composite_out_featsums(const float* w_row, const int32_t* cidx_row, const void* color_out, const float* wsum, int32_t N, int32_t S1,
+                               int32_t S2, int32_t D, float bg, float* image, float* features, const float* feat_sums, void* stream);
 int aln_wide_nt_maskgen(const void* a1, int32_t lda1, int32_t M, int32_t N, int32_t K, const void* w, int32_t ldw, void* y, int32_t ldy,
                         const void* geo, int32_t G, const void* w0 /*[N,16]*/, int32_t* found_inf, void* stream);
 int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int32_t G, const void* w0 /*[K,16]*/, int32_t M, int32_t N, int32_t K,

@@ -39,7 +39,7 @@ for (N, K1, geo, name) in [(512, 512, False, 'dW 512x512'), (64, 512, True, 'dW 
 # ---- round 5: generated first layer (h1 never stored)
 w0 = (torch.randn(512, 16, device=dev) / 4).half()
 w1 = (torch.randn(512, 512, device=dev) / 22).half()
-t = timeit(lambda: H.call('aln_wide_nt_gen', H.ptr(sout), 15, H.ptr(w0), M, 512, 512, H.ptr(w1), 512, H.ptr(y), 512, 1, None, H.stream()))
+t = timeit(lambda: H.call('aln_wide_nt_gen', H.ptr(sout), 15, H.ptr(w0), M, 512, 512, H.ptr(w1), 512, H.ptr(y), 512, 1, None, None, None, H.stream()))
 print(f'nt_gen (layers 1+2)       : {t * 1e6:8.0f} us  {2.0 * M * 512 * 528 / t / 1e12:7.1f} TFLOP/s')
 y2 = torch.empty_like(y)
 t = timeit(lambda: H.call('aln_wide_nt_maskgen', H.ptr(x), 512, M, 512, 512, H.ptr(w1), 512, H.ptr(y2), 512, H.ptr(sout), 15, H.ptr(w0), None, H.stream()))

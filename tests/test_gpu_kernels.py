@@ -960,7 +960,18 @@ def test_wide_generated_first_layer_kernels(H, M):
     H.call('aln_wide_nt', None, 0, 0, 0, H.ptr(sout), G, M, Hd, H.ptr(w0), 16, H.ptr(h1), Hd, 1, None, 0, None, 0, H.ptr(flag), H.stream())
     H.call('aln_wide_nt', H.ptr(h1), Hd, Hd, 0, None, G, M, Hd, H.ptr(w1), Hd, H.ptr(h2), Hd, 1, None, 0, None, 0, H.ptr(flag), H.stream())
     h2g = nan(M, Hd)
-    H.call('aln_wide_nt_gen', H.ptr(sout), G, H.ptr(w0), M, Hd, Hd, H.ptr(w1p), Hd, H.ptr(h2g), Hd, 1, H.ptr(flag), H.stream())
+    H.call('aln_wide_nt_gen', H.ptr(sout), G, H.ptr(w0), M, Hd, Hd, H.ptr(w1p), Hd, H.ptr(h2g), Hd, 1, None, None, H.ptr(flag), H.stream())
+    # ... and with the compositing weights: the same rows plus, per 32-row tile, sum_rows w[row] * h2[row][:] (the epilogue's by-product
+    # that replaces a second pass over the [M, 512] activation: aln_composite_out_featsums)
+    w_row = torch.rand(M, generator=g).cuda()
+    nt = (M + 31) // 32
+    tsums, h2s = torch.full((nt, Hd), float('nan'), device='cuda'), nan(M, Hd)
+    H.call('aln_wide_nt_gen', H.ptr(sout), G, H.ptr(w0), M, Hd, Hd, H.ptr(w1p), Hd, H.ptr(h2s), Hd, 1, H.ptr(w_row), H.ptr(tsums), H.ptr(flag), H.stream())
+    assert torch.equal(h2s, h2g)
+    pad = torch.zeros(nt * 32, Hd, device='cuda')
+    pad[:M] = w_row[:, None] * h2g.float()
+    want_ts = pad.view(nt, 32, Hd).sum(1)
+    assert torch.isfinite(tsums).all() and (tsums - want_ts).abs().max().item() <= 1e-4 * max(1.0, want_ts.abs().max().item())
     A = _geo_block(sout.cpu(), G)
     want_h1 = torch.relu(A @ w0.cpu().float().t()).half().float()
     want_h2 = torch.relu(want_h1 @ w1.cpu().float().t())
