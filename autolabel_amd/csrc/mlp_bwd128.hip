@@ -81,6 +81,23 @@ __device__ inline void write_slice(lds_h16* T, int wave, int rb, const Pk& p, in
   for (int q = 0; q < 4; ++q) *(LDS_VEC(u32x2)*)(row + 8 * q) = (u32x2){p.q[q >> 1][2 * (q & 1)], p.q[q >> 1][2 * (q & 1) + 1]};
 }
 
+// Physical row of sample s in the row-major x tiles: inside every group of 16 the rows are rotated so that four CONSECUTIVE samples
+// sit four rows apart.  The transposed reads for dW_first fetch four consecutive samples per 16-lane group, 16 columns of each: at
+// the 28- / 20-dword pitches consecutive rows overlap two ways (profiles/r05_probe_lds_patterns.txt: half of those reads' cycles were
+// conflicts), rows four apart start 48 / 16 banks apart and tile the 64 banks exactly.  Row-per-lane accesses see the same rows.
+__device__ inline int xrow(int s_) { return (s_ & ~15) | ((s_ & 3) << 2) | ((s_ >> 2) & 3); }
+// tr_frag_chained (mlp_shared.h) over such a tile
+__device__ inline h16x8 tr_frag_x(const lds_h16* T, int pitch, int col0, int ks, int lane) {
+  const int hf = lane >> 5;
+  const int row = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * hf + ((lane & 15) >> 2);
+  const int col = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(T + xrow(row) * pitch + col));
+  s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(T + xrow(row + 8) * pitch + col));
+  union { struct { s16x4v l, h; } s; h16x8 v; } u;
+  u.s.l = lo; u.s.h = hi;
+  return u.v;
+}
+
 }  // namespace bwd128
 using namespace bwd128;
 
@@ -150,7 +167,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
       const int i = threadIdx.x + 256 * q, r = i / XCH, k = i % XCH;
-      if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX + r * PX + 8 * k) = (r0 + r < rows) ? px[q] : z;
+      if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX + xrow(r) * PX + 8 * k) = (r0 + r < rows) ? px[q] : z;
     }
   };
   auto stash_o = [&](int r0) __attribute__((always_inline)) {
@@ -191,7 +208,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
       for (int ks = 0; ks < KS0; ++ks)
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
-          acc[rb] = mfma16(*(const LDS_VEC(h16x8)*)(tXb + (32 * rb + c) * PX + 16 * ks + 8 * hf), B0[ks], ks == 0 ? zero16 : acc[rb]);
+          acc[rb] = mfma16(*(const LDS_VEC(h16x8)*)(tXb + xrow(32 * rb + c) * PX + 16 * ks + 8 * hf), B0[ks], ks == 0 ? zero16 : acc[rb]);
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) { Pk hp; relu_pack(acc[rb], hp); write_slice(t1, wave, rb, hp, lane); }
     }
@@ -349,10 +366,10 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
     // phase D's LDS operands that do not depend on t3: x^T fragments of the first two k steps, the next tile's first x fragments
     h16x8 bx[3][IB];
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) { bx[0][ib] = tr_frag_chained(PlainV<const lds_h16*>{tX, PX}, 32 * ib, 0, lane); bx[1][ib] = tr_frag_chained(PlainV<const lds_h16*>{tX, PX}, 32 * ib, 1, lane); }
+    for (int ib = 0; ib < IB; ++ib) { bx[0][ib] = tr_frag_x(tX, PX, 32 * ib, 0, lane); bx[1][ib] = tr_frag_x(tX, PX, 32 * ib, 1, lane); }
     if (more) {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) l0a[rb] = *(const LDS_VEC(h16x8)*)(tXn + (32 * rb + c) * PX + 8 * hf);
+      for (int rb = 0; rb < 4; ++rb) l0a[rb] = *(const LDS_VEC(h16x8)*)(tXn + xrow(32 * rb + c) * PX + 8 * hf);
     }
     PT_STAMP(3) __syncthreads(); PT_STAMP(4)   // B_c: t3 complete, t1 / t2 free
 
@@ -373,7 +390,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
       };
       auto req_bx = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ib = 0; ib < IB; ++ib) bx[ks % 3][ib] = tr_frag_chained(PlainV<const lds_h16*>{tX, PX}, 32 * ib, ks, lane);
+        for (int ib = 0; ib < IB; ++ib) bx[ks % 3][ib] = tr_frag_x(tX, PX, 32 * ib, ks, lane);
       };
 #pragma unroll
       for (int ks = 0; ks < DEPTH; ++ks) req(ks);
@@ -381,7 +398,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
       if (more) {
         if (KS0 > 1) {
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) la[1][rb] = *(const LDS_VEC(h16x8)*)(tXn + (32 * rb + c) * PX + 16 + 8 * hf);
+          for (int rb = 0; rb < 4; ++rb) la[1][rb] = *(const LDS_VEC(h16x8)*)(tXn + xrow(32 * rb + c) * PX + 16 + 8 * hf);
         }
         SCHED_FENCE;
 #pragma unroll
@@ -395,7 +412,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
         for (int ks = 1; ks < KS0; ++ks) {
           if (ks + 1 < KS0) {
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) la[(ks + 1) & 1][rb] = *(const LDS_VEC(h16x8)*)(tXn + (32 * rb + c) * PX + 16 * (ks + 1) + 8 * hf);
+            for (int rb = 0; rb < 4; ++rb) la[(ks + 1) & 1][rb] = *(const LDS_VEC(h16x8)*)(tXn + xrow(32 * rb + c) * PX + 16 * (ks + 1) + 8 * hf);
           }
           SCHED_FENCE;
 #pragma unroll
@@ -416,7 +433,9 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
       // lane (sample c, half) holds features 32 ib + 8 q + 4 half + 0..3 of its row: through the wave's [32][IN] corner of t2 (free
       // since B_c), so the rows leave as contiguous 16-byte pieces (one row per lane and store touched 64 lines per instruction:
       // 800 ticks per tile); the pieces are read back here and stored early in the next tile's phase B
-      lds_h16* const stage = t2 + wave * (32 * IN);
+      // (pitch IN + 4 halves: at pitch IN the 32 rows of an 8-byte store fall onto 8 bank pairs -- four ways, 64 ticks per store)
+      constexpr int PS = IN + 4;
+      lds_h16* const stage = t2 + wave * (32 * PS);
 #pragma unroll
       for (int ib = 0; ib < IB; ++ib)
 #pragma unroll
@@ -425,12 +444,19 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
           if (f < IN) {
             const u32x2 v = {cvt_pk(o[ib][4 * q], o[ib][4 * q + 1]), cvt_pk(o[ib][4 * q + 2], o[ib][4 * q + 3])};
             nanz = nan_fold(__builtin_bit_cast(h16x2, v.x), nan_fold(__builtin_bit_cast(h16x2, v.y), nanz));
-            *(LDS_VEC(u32x2)*)(stage + c * IN + f) = v;
+            *(LDS_VEC(u32x2)*)(stage + c * PS + f) = v;
           }
         }
       SCHED_FENCE;
 #pragma unroll
-      for (int i = 0; i < NPC; ++i) if (lane + 64 * i < PIECES) dst[i] = *(const LDS_VEC(u32x4)*)(stage + 8 * (lane + 64 * i));
+      for (int i = 0; i < NPC; ++i) {
+        const int pc = lane + 64 * i;
+        if (pc < PIECES) {   // piece pc = 16 bytes of row pc / (IN / 8): two 8-byte reads (the padded rows are 8-byte aligned only)
+          const lds_h16* src = stage + (pc / (IN / 8)) * PS + 8 * (pc % (IN / 8));
+          const u32x2 a = *(const LDS_VEC(u32x2)*)src, b = *(const LDS_VEC(u32x2)*)(src + 4);
+          dst[i] = (u32x4){a.x, a.y, b.x, b.y};
+        }
+      }
       dprev_row0 = r0 + 32 * wave;
     }
     PT_STAMP(5) __syncthreads(); PT_STAMP(6)   // end of tile: t1 holds the next tile's h1; t2 / t3 / this tile's x buffer are free again
