@@ -27,7 +27,11 @@ __device__ inline void addrs(int lane, int wave, uint32_t (&a)[16], int& kind) {
     if (PAT == 6) { kind = 3; const int ib = s & 1, q = (s >> 1) & 3; off = wave * 32 * 48 + c * 48 + 32 * ib + 8 * q + 4 * hf; if (32 * ib + 8 * q + 4 * hf >= 48) off = wave * 32 * 48 + c * 48; }   // d_in stage writes, pitch 48
     if (PAT == 7) { kind = 2; off = (32 * (s & 3) + c) * 16 + 8 * hf; }                                                                                   // ao: dOut rows, pitch 16
     if (PAT == 8) { kind = 1; const int rb = s & 3, q = (s >> 2) & 3; off = prow(32 * wave + c) * PH + 32 * rb + 4 * hf + 8 * q; }                       // req_m (mask reads)
-    if (PAT == 9) { kind = 2; off = ((s * 64) + lane) * 8; }                                                                                              // w0t fragments (linear)
+    if (PAT == 9) { kind = 2; off = ((s * 64) + lane) * 8; }
+    if (PAT == 10) { kind = 3; off = ((s * 64) + lane) * 4; }                                                                                             // ds_write_b64, linear
+    if (PAT == 11) { kind = 4; off = ((s * 64) + lane) * 8; }                                                                                             // ds_write_b128, linear
+    if (PAT == 12) { kind = 4; const int rb = s & 3, q2 = (s >> 2) & 1; off = prow(32 * wave + c) * PH + 32 * rb + 16 * q2 + 8 * hf; }                   // 16-byte slice stores (permuted sample order)
+    if (PAT == 13) { kind = 3; const int rb = s & 3, q = (s >> 2) & 3; off = prow(32 * wave + c) * PH + 32 * rb + 16 * (q >> 1) + 8 * hf + 4 * (q & 1); } // 8-byte stores, halves 8 apart                                                                                              // w0t fragments (linear)
     a[s] = (uint32_t)(off * 2);
   }
 }
@@ -60,9 +64,13 @@ __global__ __launch_bounds__(256) void k_pat(long long* out, int rounds) {
       asm volatile("s_waitcnt lgkmcnt(0)");
 #pragma unroll
       for (int s = 0; s < 16; ++s) acc ^= v[s];
-    } else { const u2 w = {(uint32_t)r, acc[0]};
+    } else if (kind == 3) { const u2 w = {(uint32_t)r, acc[0]};
 #pragma unroll
       for (int s = 0; s < 16; ++s) asm volatile("ds_write_b64 %0, %1" :: "v"(a[s]), "v"(w) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)");
+    } else { const u4 w = {(uint32_t)r, acc[0], acc[1], 7u};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) asm volatile("ds_write_b128 %0, %1" :: "v"(a[s]), "v"(w) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)");
     }
   }
@@ -90,5 +98,9 @@ int main() {
   run<7>("ao: dOut rows (ds_read_b128, pitch 16)", d);
   run<8>("req_m mask reads (ds_read_b64, prow rows)", d);
   run<9>("w0t fragments (ds_read_b128, linear)", d);
+  run<10>("ds_write_b64 linear", d);
+  run<11>("ds_write_b128 linear", d);
+  run<12>("16-byte slice stores, prow rows (sample order permuted)", d);
+  run<13>("8-byte slice stores, halves 8 apart", d);
   return 0;
 }
