@@ -825,6 +825,145 @@ extern "C" int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int3
   return 0;
 }
 
+// The two consumers of the data gradient dh1 [M, N] that flows into the generated layer, in ONE pass over it:
+//   d_fin[M, 16] = dh1 W0            (the gradient of the layer's 16 inputs: geo_feat + the constant one; A = W0^T [16, N])
+//   dW0[N, 16]  += dh1^T [geo_feat, 1]
+// As two launches (k_wide_nt_dma<32>, k_wide_tn<4, 1>) they read the 1 GB of dh1 twice (190 + 270 us in the LSeg step).  Here a block
+// stages a 64-row x N tile once (N <= 512: 67 KB of LDS); every wave multiplies its 128 columns' transposed fragments with the
+// [geo_feat, 1] rows for dW0 (k_wide_tn's scheme), and the tile's row-major fragments with W0^T for d_fin: wave w takes sample block
+// w & 1 and column half w >> 1, the two halves of a sample block meet in LDS in a fixed order.  Slabs of rows, fixed-order reduction
+// of the dW0 partial sums (k_wide_dw_reduce): bit-reproducible.
+struct WideTNDin {
+  const h16* g; int ldg; const h16* geo; int G; const h16* w0t; int ldw0t;   // dh1 [M, N], sigma_out [M, 16], W0^T [16, N]
+  int M, N, slab; float* ws; h16* d_fin; int* found_inf;
+};
+#define WTD_PG (512 + 24)
+__global__ __launch_bounds__(256) void k_wide_tn_din(WideTNDin p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_d[];
+  h16* Gs = (h16*)smem_d;                        // [64][WTD_PG]
+  h16* As = Gs + WTN_BM * WTD_PG;                // [64][24]   [geo_feat, 1] rows
+  float* red = (float*)(As + WTN_BM * 24);       // [2 sample blocks][8 registers][64 lanes]: the upper column half's d_fin partial sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, c = lane & 31;
+  const int slab_i = blockIdx.x;
+  const int mlo = slab_i * p.slab, mhi = min(p.M, mlo + p.slab);
+  if (mlo >= p.M) return;
+  const int wn = wave * 128, sb = wave & 1, kh = wave >> 1, NH = p.N / 2;
+  f32x16 acc[4], dacc, zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = zero;
+  const WTile<WTD_PG> tG{(lds_h16w*)Gs};
+  const WTile<24> tA{(lds_h16w*)As};
+  const int nks = NH / 16;                        // 16-column steps of this wave's column half (16 at N = 512)
+  // W0^T fragments of the column half (A operand: lane = input j, 16 real rows of 32; 8 columns per half-wave): 16 KB in all, re-read
+  // from L1 / L2 for every tile (resident they cost 64 registers and the second block per CU)
+  const h16* const wrow = p.w0t + (size_t)min(c, 15) * p.ldw0t + kh * NH + 8 * hf;
+  h16x8 gr[16], ar;
+  const WideSrc gsrc{nullptr, 0, 0, 0, p.geo, p.G};
+  auto fetch = [&](int mt) {
+    h16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (h16)0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ch = tid + 256 * i, r = ch >> 6, cc = (ch & 63) * 8;
+      gr[i] = z;
+      if (mt + r < mhi && cc < p.N) gr[i] = *(const h16x8*)(p.g + (size_t)(mt + r) * p.ldg + cc);
+    }
+    ar = z;
+    if (tid < 128 && mt + (tid >> 1) < mhi) ar = wide_chunk(gsrc, (size_t)(mt + (tid >> 1)), 8 * (tid & 1), 16);
+  };
+  auto finish = [&](int mt) {   // d_fin rows of tile mt: lower column half (in registers) + upper half (in LDS), lower first
+    if (kh == 0) {
+      const int m = mt + 32 * sb + c;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = dacc[r] + red[(sb * 8 + r) * 64 + lane];
+      if (m < mhi) {   // register r = input j = 8 (r / 4) + 4 hf + r % 4
+        bool bad = false;
+        h16x4 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o0[r] = (h16)v[r]; o1[r] = (h16)v[4 + r]; bad |= !(fabsf(v[r]) <= 65504.f) | !(fabsf(v[4 + r]) <= 65504.f); }
+        *(h16x4*)(p.d_fin + (size_t)m * 16 + 4 * hf) = o0;
+        *(h16x4*)(p.d_fin + (size_t)m * 16 + 8 + 4 * hf) = o1;
+        if (bad && p.found_inf) *p.found_inf = 1;
+      }
+    }
+  };
+  fetch(mlo);
+  bool pending = false;
+  for (int mt = mlo; mt < mhi; mt += WTN_BM) {
+    __syncthreads();                 // the previous tile is consumed; its upper-half partial sums are in `red`
+    if (pending) finish(mt - WTN_BM);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int ch = tid + 256 * i; *(h16x8*)(Gs + (ch >> 6) * WTD_PG + (ch & 63) * 8) = gr[i]; }
+    if (tid < 128) *(h16x8*)(As + (tid >> 1) * 24 + 8 * (tid & 1)) = ar;
+    __syncthreads();
+    if (mt + WTN_BM < mhi) fetch(mt + WTN_BM);
+    // dW0: this wave's 128 columns x 16 inputs, contraction over the tile's 64 samples
+#pragma unroll
+    for (int ks = 0; ks < WTN_BM / 16; ++ks) {
+      const h16x8 ab = wtr_frag(tA, 0, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = wmfma(wtr_frag(tG, wn + 32 * i, ks, lane), ab, acc[i]);
+    }
+    // d_fin: sample block sb, column half kh
+    dacc = zero;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      if (kk < nks) dacc = wmfma(*(const h16x8*)(wrow + 16 * kk), *(const h16x8*)(Gs + (32 * sb + c) * WTD_PG + kh * NH + 16 * kk + 8 * hf), dacc);
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) red[(sb * 8 + r) * 64 + lane] = dacc[r];
+    }
+    pending = true;
+  }
+  __syncthreads();
+  if (pending) finish(mlo + (mhi - mlo - 1) / WTN_BM * WTN_BM);
+  // dW0 partial sums of the slab: lane = input k (16 real), register r of block i = column n = wn + 32 i + 8 (r / 4) + 4 hf + r % 4
+  if (c < 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = wn + 32 * i + 8 * (r >> 2) + 4 * hf + (r & 3);
+        if (n < p.N) p.ws[((size_t)slab_i * p.N + n) * 16 + c] = acc[i][r];
+      }
+  }
+}
+static void wide_tn_din_split(int M, int& slab, int& slabs) {
+  slabs = 512;    // two blocks per CU; the partial sums the reduction reads grow with the slab count (1024 slabs: +26 us)
+  slab = ((M + slabs - 1) / slabs + WTN_BM - 1) / WTN_BM * WTN_BM;
+  if (slab < WTN_BM) slab = WTN_BM;
+  slabs = (M + slab - 1) / slab;
+}
+extern "C" int64_t aln_wide_tn_din_ws_bytes(int32_t M, int32_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  int slab, slabs;
+  wide_tn_din_split(M, slab, slabs);
+  return (int64_t)slabs * N * 16 * (int64_t)sizeof(float);
+}
+extern "C" int aln_wide_tn_din(const void* g, int32_t ldg, const void* geo, int32_t G, const void* w0t, int32_t ldw0t, int32_t M, int32_t N,
+                               float* dw, int32_t lddw, void* ws, void* d_fin, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(g && geo && w0t && dw && ws && d_fin && M >= 0, "wide_tn_din: bad arguments");
+  ALN_REQUIRE(N > 0 && N <= 512 && N % 32 == 0 && ldg % 8 == 0 && ldw0t % 8 == 0 && ldw0t >= N && lddw >= 16, "wide_tn_din: N must be a multiple of 32, at most 512");
+  ALN_REQUIRE(((uintptr_t)g & 15) == 0 && ((uintptr_t)w0t & 15) == 0 && ((uintptr_t)geo & 15) == 0 && ((uintptr_t)d_fin & 7) == 0, "wide_tn_din: operands must be 16-byte aligned");
+  if (M == 0) return 0;
+  WideTNDin p{(const h16*)g, ldg, (const h16*)geo, G, (const h16*)w0t, ldw0t, M, N, 0, (float*)ws, (h16*)d_fin, found_inf};
+  int slabs;
+  wide_tn_din_split(M, p.slab, slabs);
+  const size_t lds = (size_t)WTN_BM * WTD_PG * 2 + (size_t)WTN_BM * 24 * 2 + 2 * 8 * 64 * sizeof(float);
+  static const bool lds_ok = hipFuncSetAttribute((const void*)k_wide_tn_din, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)) == hipSuccess;
+  ALN_REQUIRE(lds_ok, "wide_tn_din: cannot reserve the LDS tile");
+  hipLaunchKernelGGL(k_wide_tn_din, dim3((unsigned)slabs), dim3(256), lds, (hipStream_t)stream, p);
+  ALN_CHECK_LAUNCH("wide_tn_din");
+  const int64_t nk = (int64_t)N * 16;
+  hipLaunchKernelGGL(k_wide_dw_reduce, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, slabs, N, 16, dw, lddw);
+  ALN_CHECK_LAUNCH("wide_dw_reduce");
+  return 0;
+}
+
 // row-major transpose of an fp16 matrix [R, C] -> [C, R] (W^T copies for the data gradients; weights only: tiny)
 __global__ void k_transpose_h16(const h16* __restrict__ src, int R, int C, h16* __restrict__ dst) {
   __shared__ h16 t[32][33];

@@ -74,6 +74,8 @@ _SIGS = {
     'aln_composite_out_featsums': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     'aln_wide_nt_maskgen': (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]),
     'aln_wide_tn_gen': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp]),
+    'aln_wide_tn_din_ws_bytes': (i64, [i32, i32]),
+    'aln_wide_tn_din': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp]),
     'aln_mlp_repack': (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),
     'aln_mlp_repack_all': (i32, [i32, vp, vp, vp]),

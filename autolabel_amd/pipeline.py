@@ -358,6 +358,19 @@ class HipPipeline:
         self._k('aln_wide_tn_gen', H.ptr(g), g.shape[1], H.ptr(sout), self.L.G, H.ptr(self.P.wide_w['semf'][0]), M, fs.hidden, fs.hidden,
                 C.c_void_p(self.P.grad.data_ptr() + 4 * dw_off), fs.hidden, H.ptr(scratch), H.stream(), tag=('wide', M, fs.hidden * (fs.hidden + 16)))
 
+    def _tn_din(self, M, dh1, d_fin, sout, dw_off, tag=None):
+        """d_fin = dh1 W0 and dW0 += dh1^T [geo_feat, 1] in one pass over dh1 (aln_wide_tn_din)."""
+        fs = self.L.nets['semf']
+        scratch = self._tn_ws.scratch('wide_tn_slabs', int(H.lib().aln_wide_tn_din_ws_bytes(M, fs.hidden)))
+        wt = self.P.wide_wt['semf'][0]
+        self._k('aln_wide_tn_din', H.ptr(dh1), dh1.shape[1], H.ptr(sout), self.L.G, H.ptr(wt), wt.shape[1], M, fs.hidden,
+                C.c_void_p(self.P.grad.data_ptr() + 4 * dw_off), fs.in_pad, H.ptr(scratch), H.ptr(d_fin), H.ptr(self.found_inf), H.stream(),
+                tag=('wide', M, fs.hidden * 32))
+
+    def _din_fused(self):
+        fs = self.L.nets['semf']
+        return fs.in_pad == 16 and fs.hidden <= 512 and fs.hidden % 32 == 0
+
     def wide_sem_fwd(self, sout, M, bufs):
         """f = semantic_features([geo, 1]); logits = semantic_out([relu(f), geo, 1]) for M rows of the density head's output.
         bufs: callable name, shape -> fp16 buffer.  Returns (logits [M, Cpad], f [M, D], saved activations)."""
@@ -410,8 +423,11 @@ class HipPipeline:
             self._nt(M, fs.hidden, Wft[1], dh1, a1=dh2, K1=fs.hidden, mask=h1, watch=True, tag=bl)
             self._tn(M, fs.hidden, dh2, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=bl)
         d_fin = bufs('d_semf_in', (M, fs.in_pad))
-        self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=bl)
-        self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=sout, tag=bl)
+        if self._din_fused():
+            self._tn_din(M, dh1, d_fin, sout, of, tag=bl)
+        else:
+            self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=bl)
+            self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=sout, tag=bl)
         return d_fin, d_ogeo
 
     # ---- point queries (models.py:175-188, 190-220, 248-256)
@@ -682,8 +698,11 @@ class HipPipeline:
                 self._nt(M, fs.hidden, Wft[1], dh1, a1=d_feat, K1=fs.hidden, mask=h1, watch=True, tag=('sem', M))
                 self._tn(M, fs.hidden, d_feat, of + n0, fs.hidden, a1=h1, K1=fs.hidden, tag=('sem', M))
             d_fin = g('d_semf_in', (M, fs.in_pad), f16)
-            self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=('sem', M))
-            self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=c['sigma_out'], tag=('sem', M))
+            if self._din_fused():
+                self._tn_din(M, dh1, d_fin, c['sigma_out'], of, tag=('sem', M))
+            else:
+                self._nt(M, fs.in_pad, Wft[0], d_fin, a1=dh1, K1=fs.hidden, watch=True, tag=('sem', M))
+                self._tn(M, fs.hidden, dh1, of, fs.in_pad, geo=c['sigma_out'], tag=('sem', M))
             d_oin = None
         elif sem and c.get('sem_wide'):
             d_fin, d_oin = self.wide_sem_bwd(c['sigma_out'], M, c['feat'], c['wide_saved'], d_logits, d_feat, lambda n, shp: g(n, shp, f16))

@@ -286,6 +286,11 @@ int aln_wide_nt_maskgen(const void* a1, int32_t lda1, int32_t M, int32_t N, int3
                         const void* geo, int32_t G, const void* w0 /*[N,16]*/, int32_t* found_inf, void* stream);
 int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int32_t G, const void* w0 /*[K,16]*/, int32_t M, int32_t N, int32_t K,
                     float* dw, int32_t lddw, void* ws, void* stream);
+/* both consumers of the data gradient g = dL/dh1 [M,N] (N <= 512) that flows into the generated layer, in ONE pass over it:
+ * d_fin[M,16] (fp16) = g W0 with w0t = W0^T [16,N], and dW0[N,16] += g^T [geo_feat, 1] (ws: aln_wide_tn_din_ws_bytes(M, N)) */
+int64_t aln_wide_tn_din_ws_bytes(int32_t M, int32_t N);
+int aln_wide_tn_din(const void* g, int32_t ldg, const void* geo, int32_t G, const void* w0t, int32_t ldw0t, int32_t M, int32_t N, float* dw,
+                    int32_t lddw, void* ws, void* d_fin, int32_t* found_inf, void* stream);
 
 /* ---- occupancy-grid marching (march.hip): the cuda_ray hooks of autolabel/trainer.py:21-23,34-36,176 and
  * NeRFRenderer.mark_untrained_grid / update_extra_state of the torch-ngp fork (dead in the reference: model_utils.py:72).

@@ -1001,6 +1001,25 @@ def test_wide_generated_first_layer_kernels(H, M):
     assert (dw_b.cpu() - 1.0 - want_dw).abs().max().item() <= 2e-3 * scale
     assert (dw_b - dw_a).abs().max().item() <= 1e-3 * scale
     assert torch.equal(dw_b, dw_c), 'fixed-order slab reduction: bit-reproducible'
+    # both consumers of the data gradient dh1 in one pass (aln_wide_tn_din) against the two launches they replace
+    dh1 = d_b
+    w0t = w0.t().contiguous()                                   # [16, Hd]
+    dfin_a, dfin_b = nan(M, 16), nan(M, 16)
+    dw0_a, dw0_b, dw0_c = (torch.ones(Hd, 16, device='cuda') for _ in range(3))
+    H.call('aln_wide_nt', H.ptr(dh1), Hd, Hd, 0, None, G, M, 16, H.ptr(w0t), Hd, H.ptr(dfin_a), 16, 0, None, 0, None, 0, H.ptr(flag), H.stream())
+    ws0 = torch.empty(int(H.lib().aln_wide_tn_ws_bytes(M, Hd, 16)), dtype=torch.uint8, device='cuda')
+    H.call('aln_wide_tn', H.ptr(dh1), Hd, None, 0, 0, 0, H.ptr(sout), G, M, Hd, H.ptr(dw0_a), 16, H.ptr(ws0), H.stream())
+    ws1 = torch.empty(int(H.lib().aln_wide_tn_din_ws_bytes(M, Hd)), dtype=torch.uint8, device='cuda')
+    for dfin, dw0 in ((dfin_b, dw0_b), (nan(M, 16), dw0_c)):
+        H.call('aln_wide_tn_din', H.ptr(dh1), Hd, H.ptr(sout), G, H.ptr(w0t), Hd, M, Hd, H.ptr(dw0), 16, H.ptr(ws1), H.ptr(dfin), H.ptr(flag), H.stream())
+    want_fin = dh1.cpu().float() @ w0.cpu().float()
+    want_dw0 = dh1.cpu().float().t() @ A
+    assert flag.item() == 0 and torch.isfinite(dfin_b).all(), 'every row written'
+    assert (dfin_b.cpu().float() - want_fin).abs().max().item() <= 2e-3 * max(1.0, want_fin.abs().max().item())
+    assert (dfin_b.float() - dfin_a.float()).abs().max().item() <= 2e-3 * max(1.0, want_fin.abs().max().item())
+    sc0 = max(1.0, want_dw0.abs().max().item())
+    assert (dw0_b.cpu() - 1.0 - want_dw0).abs().max().item() <= 2e-3 * sc0 and (dw0_b - dw0_a).abs().max().item() <= 1e-3 * sc0
+    assert torch.equal(dw0_b, dw0_c)
 
 
 def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
