@@ -383,7 +383,7 @@ def timed_leg(wl, args, eng, B, dseed, mseed, frange, use_graph, world, sync):
     return dt, terms, events, step, done
 
 
-def dp_world1_leg(wl, args, B):
+def dp_world1_leg(wl, args, B, teardown=True):
     """The data-parallel forms of the step on ONE GPU: a one-rank `nccl` (= RCCL) process group, every collective really issued
     (TrainEngine(exchange_at_world_1=True)).  What this measures is what a rank's step costs once the gradient takes the data-parallel
     route -- table gradient through HBM instead of the optimizer inside the scatter, wire-format kernels, collectives, the communication
@@ -412,10 +412,11 @@ def dp_world1_leg(wl, args, B):
                 out[name] = {'error': f'{type(ex).__name__}: {ex}'[:300]}
             torch.cuda.empty_cache()
     finally:
-        import gc
-        gc.collect()
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+        if teardown:
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
     return out
 
 
@@ -444,7 +445,7 @@ def dp1_child(args):
     device = torch.device('cuda', 0)
     torch.cuda.set_device(device)
     wl = Workload(args, device)
-    print(json.dumps(dp_world1_leg(wl, args, args.batch)), flush=True)
+    print(json.dumps(dp_world1_leg(wl, args, args.batch, teardown=False)), flush=True)
     # captured graphs that hold RCCL kernels and a destroyed communicator do not always unwind in a safe order at interpreter exit (one
     # abort in three in-bench runs, after the line above): leave without running destructors
     sys.stdout.flush()
