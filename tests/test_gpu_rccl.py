@@ -74,8 +74,17 @@ def _worker(rank, port, ret):
     run('graph_f16', W, 'f16', overlap=True, graph=True)
     run('sharded_graph_f16', W, 'f16', overlap=True, shard=True, graph=True)
     dist.barrier()
-    dist.destroy_process_group()
-    ret[0] = out
+    torch.cuda.synchronize()
+    ret[0] = out            # (a synchronous call into the manager process: delivered before anything below)
+    # Captured graphs that hold RCCL kernels and a destroyed communicator do not always unwind in a safe order at interpreter exit
+    # (bench.py's dp_world1 child aborted once in three in-bench runs AFTER its legs had finished): nothing is left to verify here, so
+    # the process ends without running destructors.
+    import gc
+    gc.collect()
+    try:
+        dist.destroy_process_group()
+    finally:
+        os._exit(0)
 
 
 def test_rccl_world_of_one_runs_every_data_parallel_form_of_the_step():
