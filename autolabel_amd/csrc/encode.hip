@@ -215,7 +215,16 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
 // coalesced 256-byte store into a per-level plane, and a second, streaming kernel assembles the row-major [rows, enc_pad]
 // operand (frequency features, planes, ones) the MLP reads.
 #define ENC_LG 1   // levels per phase (measured: 1 -> 135 us, 2 -> 140 us, 4 -> 202 us per 512 K samples)
-__global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg) {
+#ifndef ENC_LG_TILED
+#define ENC_LG_TILED 1   // tiled output (2: one 8-byte store per lane for the two levels of a phase -- measured 299 us against 288 per step)
+#endif
+// `tiled` != NULL (round 5): no planes, no assembly pass -- the wave writes its level's features straight into the MLP's input buffer in
+// the TILED layout the 128-wide kernels' loaders fetch (AlnMlpDesc.x_tiled: 16-byte piece q of row r at 32 pad (r / 32) + 256 q + 8 (r % 32)
+// halves).  A 4-byte store per lane at a 16-byte stride fills a quarter of each line; the other three levels of the piece come from
+// blocks with the same row range a few microseconds later, and those run on the SAME XCD (block ids differ by multiples of nblk, a
+// multiple of 8), so the pieces merge in its L2 before they leave for HBM.  The blocks of the first phase also write the frequency
+// features and the ones padding of their rows.
+__global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg, h16* __restrict__ tiled) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.x / nblk, b = blockIdx.x % nblk;
   const int base_row = (b * 4 + wave) * 64;
@@ -224,11 +233,43 @@ __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* 
   float x[3] = {0, 0, 0}, xn[3];
   if (row < p.rows) row_position(p, row, x);
   normalize_pos(x, p.e.bound, true, xn);
+  const int pad = p.e.enc_pad, fdim = 3 * 2 * p.e.n_freq;
+  h16* const trow = tiled ? tiled + (size_t)(row >> 5) * (32 * pad) + 8 * (row & 31) : nullptr;   // piece q of this row: trow + 256 q
+  if (tiled && lg == 2 && g * 2 + 1 < p.e.grid.n_levels && ((fdim + 4 * g) & 3) == 0) {   // the phase's two levels: ONE 8-byte store
+    const h16x2 o0 = level_features(p, 2 * g, xn, lane, base_row), o1 = level_features(p, 2 * g + 1, xn, lane, base_row);
+    if (row < p.rows) {
+      const int j = fdim + 4 * g;
+      h16x4 o; o[0] = o0[0]; o[1] = o0[1]; o[2] = o1[0]; o[3] = o1[1];
+      *(h16x4*)(trow + 256 * (j >> 3) + (j & 7)) = o;
+    }
+  } else
   for (int i = 0; i < lg; ++i) {
     const int l = g * lg + i;
     if (l < p.e.grid.n_levels) {
       const h16x2 o = level_features(p, l, xn, lane, base_row);
-      if (row < p.rows) planes[(size_t)l * p.rows + row] = o;
+      if (row < p.rows) {
+        if (tiled) { const int j = fdim + 2 * l; *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = o; }
+        else planes[(size_t)l * p.rows + row] = o;
+      }
+    }
+  }
+  if (tiled && row < p.rows) {
+    // frequency features (k_encode_assemble's arithmetic) and the ones behind the last level: one PAIR of columns per phase -- phase g
+    // takes pair g of the fdim / 2 + (pad - enc_dim) / 2 extra pairs (all twelve sines in the first phase made its blocks three times
+    // as long as the others); whatever does not fit the phases falls to the last one
+    const int npf = fdim / 2, npo = (pad - p.e.enc_dim) / 2, ngroups = (p.e.grid.n_levels + lg - 1) / lg;
+    for (int q = g; q < npf + npo; q += ngroups) {
+      if (q < npf) {
+        float xr[3] = {x[0], x[1], x[2]};
+        if (p.e.freq_normalized) { float qn[3]; normalize_pos(xr, p.e.bound, false, qn); xr[0] = qn[0]; xr[1] = qn[1]; xr[2] = qn[2]; }
+        const int j = 2 * q;
+        h16x2 f; f[0] = freq_feature(p.e.n_freq, xr, j); f[1] = freq_feature(p.e.n_freq, xr, j + 1);
+        *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = f;
+      } else {
+        const int j = p.e.enc_dim + 2 * (q - npf);
+        h16x2 one; one[0] = (h16)1.0f; one[1] = (h16)1.0f;
+        *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = one;
+      }
     }
   }
 }
@@ -278,11 +319,19 @@ extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16,
                                      void* enc_out, void* stream) {
   EncParams p;
   if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
-  ALN_REQUIRE(e->use_grid && table_f16 && planes_ws && enc_out, "encode_fwd_phased: needs a grid encoding, its table and the plane workspace");
+  ALN_REQUIRE(e->use_grid && table_f16 && enc_out, "encode_fwd_phased: needs a grid encoding and its table");
+  ALN_REQUIRE(planes_ws || ((e->enc_pad == 32 || e->enc_pad == 48) && e->enc_dim % 2 == 0 && ((uintptr_t)enc_out & 15) == 0),
+              "encode_fwd_phased: the tiled output (planes_ws = NULL) needs enc_pad 32 or 48");
   if (rows == 0) return 0;
-  const int lg = ENC_LG;
+  const int lg = planes_ws ? ENC_LG : ENC_LG_TILED;
   const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
-  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
+  if (!planes_ws) {   // tiled: straight into the MLP's input buffer (nblk rounded up to a multiple of 8 keeps a row range on one XCD)
+    const int nblk8 = (nblk + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk8 * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)nullptr, nblk8, lg, (h16*)enc_out);
+    ALN_CHECK_LAUNCH("encode_grid_phased");
+    return 0;
+  }
+  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg, (h16*)nullptr);
   ALN_CHECK_LAUNCH("encode_grid_phased");
   hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
                      (const h16x2*)planes_ws, (h16*)enc_out);
@@ -334,7 +383,7 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
   if (e->use_grid && planes_ws) {
     const int lg = ENC_LG;
     const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
-    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg);
+    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg, (h16*)nullptr);
     ALN_CHECK_LAUNCH("encode_grid_phased");
     hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
                        (const h16x2*)planes_ws, (h16*)enc_out);

@@ -1801,6 +1801,7 @@ static int mlp_fwd_src(const AlnMlpDesc* m, RowSrc xs, int32_t rows, const int32
     if (rc != -3) { ALN_CHECK_LAUNCH("mlp_fwd128"); return rc; }
   }
 #endif
+  ALN_REQUIRE(!m->x_tiled, "mlp_fwd: tiled input rows (AlnMlpDesc.x_tiled) are read by the 128-wide kernel only");
   size_t halves = (size_t)aln_mlp_frag_halves(m->in_pad, m->hidden, m->out_pad, m->n_hidden, 0);
   size_t lds = halves * 2;
   ALN_REQUIRE(lds <= 160 * 1024, "mlp_fwd: weights (%zu B) exceed LDS", lds);
@@ -1857,6 +1858,10 @@ extern "C" int64_t aln_mlp_dw_ws_bytes(int32_t in_pad, int32_t hidden, int32_t o
   return (int64_t)512 * (int64_t)(L.w_off[L.n - 1] + (size_t)L.in_[L.n - 1] * L.out_[L.n - 1]) * (int64_t)sizeof(float);
 }
 
+// heads whose forward AND backward kernels read tiled input rows (AlnMlpDesc.x_tiled): the 128-wide kernels of mlp_fwd128.hip / mlp_bwd128.hip
+extern "C" int aln_mlp_supports_tiled(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden) {
+  return hidden == 128 && n_hidden == 2 && out_pad == 16 && (in_pad == 32 || in_pad == 48);
+}
 // shapes the recompute backward is instantiated for (the list of TRYR below)
 extern "C" int aln_mlp_has_recompute(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden) {
   static const int shapes[][4] = {{48, 128, 16, 2}, {32, 128, 16, 2}, {64, 128, 16, 2}, {16, 64, 64, 2},
@@ -1880,6 +1885,7 @@ static int mlp_bwd_recomp_src(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int row
                 "mlp_bwd: AlnMlpDesc.dw_ws must hold %d slabs of %d floats (aln_mlp_dw_ws_bytes)", g, n_w);
     float* ws = dW ? (float*)m->dw_ws : nullptr;
     const int rc = aln_launch_bwd128(m, xs.a, ds.a, rows, rows_dev, d_in, ws, g, found_inf, s);
+    ALN_REQUIRE(rc != -3 || !m->x_tiled, "mlp_bwd: tiled input rows need the 128-wide kernel");
     if (rc != -3) {
       ALN_CHECK_LAUNCH("mlp_bwd128");
       if (ws && !m->defer_dw_reduce) {
@@ -1890,6 +1896,7 @@ static int mlp_bwd_recomp_src(const AlnMlpDesc* m, RowSrc xs, RowSrc ds, int row
     }
   }
 #endif
+  ALN_REQUIRE(!m->x_tiled, "mlp_bwd: tiled input rows (AlnMlpDesc.x_tiled) are read by the 128-wide kernel only");
 #define TRYR(I, H, O, N)                                                                                  \
   if (m->in_pad == I && m->hidden == H && m->out_pad == O && m->n_hidden == N)                            \
     return launch_bwd_recomp<I, H, O, N>(m, xs, ds, rows, rows_dev, d_in, dW, found_inf, s);

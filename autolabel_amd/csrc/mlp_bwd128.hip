@@ -117,7 +117,7 @@ template <int IN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, const h16* __restrict__ x_g,
                   const h16* __restrict__ do_g, int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
-                  float* __restrict__ dw_ws, int* __restrict__ found_inf) {
+                  float* __restrict__ dw_ws, int* __restrict__ found_inf, int x_tiled) {
   constexpr int KS0 = IN / 16, IB = (IN + 31) / 32, PX = px_pitch(IN);
   constexpr int XCH = IN / 8, NXS = (TR * XCH + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -155,7 +155,11 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
       const int i = threadIdx.x + 256 * q, r = i / XCH, k = i % XCH;
-      if (i < TR * XCH && r0 + r < rows) px[q] = *(const h16x8*)(x_g + (size_t)(r0 + r) * IN + 8 * k);
+      // (x rows row-major, or in the tiled layout of AlnMlpDesc.x_tiled: chunk k of row m at 32 IN (m / 32) + 256 k + 8 (m % 32))
+      if (i < TR * XCH && r0 + r < rows) {
+        const int m = r0 + r;
+        px[q] = *(const h16x8*)(x_tiled ? x_g + (size_t)(m >> 5) * (32 * IN) + 256 * k + 8 * (m & 31) : x_g + (size_t)m * IN + 8 * k);
+      }
     }
   };
   auto prefetch_o = [&](int r0) __attribute__((always_inline)) {
@@ -500,7 +504,7 @@ static int launch(const AlnMlpDesc* m, const h16* x, const h16* d_out, int rows,
   static_assert(lds <= 160 * 1024, "LDS");
   hipFuncSetAttribute((const void*)k_mlp_bwd128<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((k_mlp_bwd128<IN>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,
-                     (h16*)d_in, ws, found_inf);
+                     (h16*)d_in, ws, found_inf, (int)m->x_tiled);
   return 0;
 }
 

@@ -60,7 +60,7 @@ extern "C" int aln_debug_read_fwd128(long long* host_out, int reset) {
 template <int KS0>   // k-steps of the input rows (in_pad / 16: 2 = colour head, 3 = density head)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int rows, const int* __restrict__ rows_dev, h16* __restrict__ out,
-                  float* __restrict__ sigma) {
+                  float* __restrict__ sigma, int tiled) {
   constexpr int NB = 4, KS = 8, IN = 16 * KS0;
   const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -93,11 +93,16 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
   __shared__ __attribute__((aligned(16))) h16 stage[4][2][2 * KS0][64 * 8];
   auto request = [&](int p, int buf) __attribute__((always_inline)) {
     const int ra = min(p * 64 + c, rows - 1), rb = min(p * 64 + 32 + c, rows - 1);   // clamped: a row beyond the end is never stored
+    // row-major rows, or the tiled layout of AlnMlpDesc.x_tiled (piece 2 ks + hf of row r at 32 IN (r / 32) + 256 piece + 8 (r % 32)): the
+    // pieces the lanes fetch are the same either way, only their addresses differ (tiled: a tile's piece is one contiguous 512 bytes)
+    const h16* const pa = tiled ? x + (size_t)(ra >> 5) * (32 * IN) + 8 * (ra & 31) + 256 * hf : x + (size_t)ra * IN + 8 * hf;
+    const h16* const pb = tiled ? x + (size_t)(rb >> 5) * (32 * IN) + 8 * (rb & 31) + 256 * hf : x + (size_t)rb * IN + 8 * hf;
+    const int kstep = tiled ? 512 : 16;
 #pragma unroll
     for (int ks = 0; ks < KS0; ++ks) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + (size_t)ra * IN + 16 * ks + 8 * hf),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + kstep * ks),
                                        (__attribute__((address_space(3))) void*)&stage[wave][buf][ks][0], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + (size_t)rb * IN + 16 * ks + 8 * hf),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + kstep * ks),
                                        (__attribute__((address_space(3))) void*)&stage[wave][buf][KS0 + ks][0], 16, 0, 0);
     }
   };
@@ -228,8 +233,8 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
 int aln_launch_fwd128(const AlnMlpDesc* m, const void* x, int rows, const int* rows_dev, void* out, float* sigma, hipStream_t s) {
   if (m->hidden != 128 || m->n_hidden != 2 || m->out_pad != 16 || (m->in_pad != 32 && m->in_pad != 48)) return -3;
   const int pairs = (rows + 63) / 64, g = min(256, (pairs + 3) / 4);
-  if (m->in_pad == 32) hipLaunchKernelGGL(k_mlp_fwd128<2>, dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma);
-  else hipLaunchKernelGGL(k_mlp_fwd128<3>, dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma);
+  if (m->in_pad == 32) hipLaunchKernelGGL(k_mlp_fwd128<2>, dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma, (int)m->x_tiled);
+  else hipLaunchKernelGGL(k_mlp_fwd128<3>, dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma, (int)m->x_tiled);
   return 0;
 }
 

@@ -29,7 +29,7 @@ class AlnEncDesc(C.Structure):
 
 class AlnMlpDesc(C.Structure):
     _fields_ = [('in_pad', i32), ('hidden', i32), ('out_pad', i32), ('n_hidden', i32), ('wf', vp), ('wb', vp), ('wr', vp), ('dw_ws', vp),
-                ('dw_ws_bytes', i64), ('defer_dw_reduce', i32), ('reserved_', i32)]
+                ('dw_ws_bytes', i64), ('defer_dw_reduce', i32), ('x_tiled', i32)]
 
 
 class AlnAdamFuse(C.Structure):
@@ -80,6 +80,7 @@ _SIGS = {
     'aln_mlp_rowmajor_halves': (i64, [i32, i32, i32, i32]),
     'aln_mlp_repack_all': (i32, [i32, vp, vp, vp]),
     'aln_mlp_has_recompute': (i32, [i32, i32, i32, i32]),
+    'aln_mlp_supports_tiled': (i32, [i32, i32, i32, i32]),
     'aln_mlp_bwd_blocks': (i32, [vp, i32]),
     'aln_mlp_dw_reduce_all': (i32, [i32, vp, vp, vp, vp]),
     'aln_mlp_dw_reduce_slabs': (i32, [i32, vp, vp, vp, vp, vp]),

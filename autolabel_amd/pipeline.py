@@ -74,6 +74,7 @@ class Params:
         self.grad = torch.zeros(L.n_total + 8, dtype=torch.float32, device=device)  # +8: side channel for DP (found_inf)
         self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
         self.frags, self.descs, self.wide_w, self.wide_wt = {}, {}, {}, {}
+        self.desc_sigma_tiled = None
         self.wide_wp = None    # semantic_features' second matrix with the columns of every group of 16 in the order the generated first
                                # layer leaves them in (aln_wide_nt_gen, wide.hip: wide_gen_pack)
         # sharded table optimizer (engine.TrainEngine(shard_optimizer=True, shard_gather='table')): the fp32 masters of the slices other
@@ -102,6 +103,10 @@ class Params:
             # into the gradient buffer with one aln_mlp_dw_reduce_all launch
             self.descs[k] = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(),
                                          ws.data_ptr(), nws, 1, 0)
+            if k == 'sigma' and H.lib().aln_mlp_supports_tiled(s.in_pad, s.hidden, s.out_pad, s.n_hidden):
+                # the same head reading its input rows in the tiled layout the level-phased gather writes (AlnMlpDesc.x_tiled)
+                self.desc_sigma_tiled = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(),
+                                                     ws.data_ptr(), nws, 1, 1)
 
     def init_(self, seed=0):
         """tcnn default initialisation: grid U(-1e-4,1e-4), MLP weights xavier-uniform per padded [out,in] matrix."""
@@ -248,6 +253,11 @@ class HipPipeline:
         self.density_scale, self.min_near = float(density_scale), float(min_near)
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
         self.phased_min_rows = 1 << 16   # hash-grid forward: level-phased from this many sample rows on
+        self.tiled_enc_enabled = True    # (bench.py --no-tiled-enc: A/B against the plane buffers + assembly pass)
+        # the tiled layout's 4-byte stores rely on the four levels of a 16-byte piece meeting in the XCD's L2: a phase writes rows x 4 B, an
+        # eighth of it per XCD -- at the dense renderer's 8.4 M rows per launch that is more than the 4 MB L2 and the pieces leave for HBM
+        # one level at a time (measured: dense render 4.8 -> 4.65 M rays/s; marching render, 2.1 M rows: 17.5 -> 18.3; training, 0.5 M: even)
+        self.tiled_max_rows = 1 << 22
         # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
         self.recompute = all(k in params.wide_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
@@ -431,9 +441,23 @@ class HipPipeline:
         return d_fin, d_ogeo
 
     # ---- point queries (models.py:175-188, 190-220, 248-256)
-    def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train, ws=None):
+    def tiled_enc(self, rows_per_pass, train):
+        """True when the density head's input rows are written straight in the tiled layout (no plane buffers, no assembly pass): the
+        level-phased gather for every pass of the launch sequence, the 128-wide kernels as the only readers, and pass boundaries on
+        whole 32-row tiles."""
+        save = train and not self.recompute
+        return (self.tiled_enc_enabled and self.P.desc_sigma_tiled is not None and bool(self.L.enc.use_grid) and not save and
+                all(self.phased_min_rows <= r <= self.tiled_max_rows and r % 32 == 0 for r in rows_per_pass))
+
+    def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train, ws=None, tiled=False):
         e, s = self.L.enc, self.L.nets['sigma']
         ws = self.ws if ws is None else ws
+        if tiled:
+            self._k('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz),
+                    rows, stride, None, H.ptr(enc), H.stream(), tag=('enc_fwd', rows))
+            self._k('aln_density_fwd', C.byref(self.P.desc_sigma_tiled), H.ptr(enc), rows, None, None, H.ptr(out), H.ptr(sigma), H.stream(),
+                    tag=('sigma', rows))
+            return
         if e.use_grid and rows >= self.phased_min_rows:
             # large batches: level-phased gathers (tables in flight stay L2-resident) + streaming row assembly
             planes = ws.scratch('enc_planes', int(e.grid.n_levels) * rows * 4)
@@ -485,13 +509,14 @@ class HipPipeline:
         else:
             H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
                    H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.ptr(step_dev), H.stream())
-        self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train, ws=ws)
+        tiled = c['enc_tiled'] = self.tiled_enc([M1] + ([N * S2] if S2 > 0 else []), train)
+        self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train, ws=ws, tiled=tiled)
         if S2 > 0:
             zf = z[M1:]
             H.call('aln_sample_fine', H.ptr(z), H.ptr(sigma), H.ptr(c['nears']), H.ptr(c['fars']), N, S1, S2,
                    self.density_scale, int(perturb), seed, step, H.ptr(u), H.ptr(zf), H.ptr(step_dev), H.stream())
             self.density_rows(N * S2, rays_o, rays_d, zf, None, S2, enc[M1:], h1[M1:] if save else h1,
-                              h2[M1:] if save else h2, sout[M1:], sigma[M1:], train, ws=ws)
+                              h2[M1:] if save else h2, sout[M1:], sigma[M1:], train, ws=ws, tiled=tiled)
         perm = c['perm'] = g('perm', (N, S), torch.int16)
         w_row, T_row, d_row = g('w_row', (M,), f32_), g('T_row', (M,), f32_), g('delta_row', (M,), f32_)
         c.update(w_row=w_row, T_row=T_row, delta_row=d_row)
@@ -720,7 +745,7 @@ class HipPipeline:
         H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), 16 if wide else nets['semo'].in_pad,
                0 if wide else L.D, H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
         d_enc = g('d_enc', (M, e.enc_pad), f16)
-        self._k('aln_mlp_bwd', C.byref(P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
+        self._k('aln_mlp_bwd', C.byref(P.desc_sigma_tiled if c.get('enc_tiled') else P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
                 H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
         if rc:   # all fused heads' weight-gradient slabs -> P.grad, one launch (fixed summation order: bit-reproducible)

@@ -62,7 +62,11 @@ typedef struct {
   int64_t dw_ws_bytes;
   int32_t defer_dw_reduce; /* 1: the recompute backward leaves its slabs in dw_ws; the caller folds them into dW later with
                               aln_mlp_dw_reduce_all (all heads of a training step in one launch) */
-  int32_t reserved_;
+  int32_t x_tiled;  /* 1: the input rows of aln_density_fwd / aln_mlp_fwd / aln_mlp_bwd are in the 32-row TILED layout that
+                       aln_encode_fwd_phased(planes_ws = NULL) writes -- tile t = rows [32 t, 32 t + 32), inside it the in_pad / 8
+                       16-byte pieces of a row piece-major: piece p of row r at halves 32 in_pad t + 256 p + 8 (r % 32) -- i.e. exactly the
+                       per-lane pieces the 128-wide kernels fetch (mlp_fwd128.hip, mlp_bwd128.hip).  Only those kernels read it
+                       (aln_mlp_supports_tiled); the buffer must hold whole tiles. */
 } AlnMlpDesc;
 
 const char* aln_last_error(void);
@@ -133,7 +137,10 @@ int aln_encode_fwd(const AlnEncDesc* e, const void* table_f16, const float* rays
                    int32_t rays_stride /*samples per ray for this pass*/, void* enc_out /*[rows,enc_pad] f16*/,
                    void* stream);
 /* the same result for large row counts, level-phased so that the tables in flight stay L2-resident (encode.hip); planes_ws is
- * caller-owned scratch of aln_encode_fwd_ws_bytes(e, rows) bytes */
+ * caller-owned scratch of aln_encode_fwd_ws_bytes(e, rows) bytes.  planes_ws = NULL (round 5): no planes and no assembly pass -- every
+ * level's wave writes its features straight into enc_out in the TILED layout of AlnMlpDesc.x_tiled (the four levels of a 16-byte
+ * piece are written by blocks of the same XCD a few microseconds apart and merge in its L2); enc_out must hold ceil(rows / 32) whole
+ * tiles and enc_pad must be 32 or 48 */
 int64_t aln_encode_fwd_ws_bytes(const AlnEncDesc* e, int32_t rows);
 int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
                           const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* planes_ws, void* enc_out,
@@ -186,6 +193,9 @@ int aln_density_fwd(const AlnMlpDesc* m, const void* x, int32_t rows, void* h1, 
  * d_in (optional) [rows,in_pad] f16; dW (optional) += weight gradients in the fp32 master layout; dA1/dA2 are scratch
  * [rows,hidden] f16 (only touched by the unfused fallback); found_inf is OR-ed when an fp16 gradient overflows. */
 /* 1 if the recompute backward exists for this shape (otherwise pass saved activations to aln_mlp_bwd) */
+/* 1 when this head's forward / backward kernels can read AlnMlpDesc.x_tiled input rows (128 wide, two hidden layers, 16 outputs, 32 or
+ * 48 inputs) */
+int aln_mlp_supports_tiled(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden);
 int aln_mlp_has_recompute(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden);
 int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
                 const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW, int32_t* found_inf, void* stream);

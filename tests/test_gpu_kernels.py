@@ -1022,6 +1022,56 @@ def test_wide_generated_first_layer_kernels(H, M):
     assert torch.equal(dw0_b, dw0_c)
 
 
+@pytest.mark.parametrize('encoding,rows', [('hg+freq', 70000), ('hg', 65536 + 32 * 7)])
+def test_tiled_encoding_equals_the_row_major_encoding_bit_for_bit(H, encoding, rows):
+    """aln_encode_fwd_phased(planes_ws = NULL) writes the encoded rows straight in the 32-row tiled layout the 128-wide MLP kernels fetch
+    (AlnMlpDesc.x_tiled: piece q of row r at 32 pad (r / 32) + 256 q + 8 (r % 32) halves) -- no plane buffers, no assembly pass.  Same
+    bits as the row-major result, and the density head gives the same output from either layout."""
+    from autolabel_amd.pipeline import ModelLayout, Params
+    layout = ModelLayout(encoding, 15, 128, 128, 64, 5, bound=2.0)
+    P = Params(layout, 'cuda'); P.init_(seed=0)
+    with torch.no_grad():
+        P.flat[:layout.n_grid].mul_(3e3)
+    P.refresh_shadows()
+    e = layout.enc
+    pad = int(e.enc_pad)
+    g = torch.Generator().manual_seed(0)
+    n_rays, S = rows // 32, 32
+    rows = n_rays * S
+    ro = ((torch.rand(n_rays, 3, generator=g) - 0.5) * 1.5).cuda()
+    rd = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1).cuda()
+    z = (torch.rand(rows, generator=g) * 2.0 + 0.2).cuda()
+    planes = torch.empty(int(H.lib().aln_encode_fwd_ws_bytes(C.byref(e), rows)), dtype=torch.uint8, device='cuda')
+    want = torch.full((rows, pad), float('nan'), dtype=torch.float16, device='cuda')
+    H.call('aln_encode_fwd_phased', C.byref(e), H.ptr(P.table16), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(planes), H.ptr(want), H.stream())
+    tiled = torch.full((rows, pad), float('nan'), dtype=torch.float16, device='cuda')
+    H.call('aln_encode_fwd_phased', C.byref(e), H.ptr(P.table16), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, None, H.ptr(tiled), H.stream())
+    # [tile][piece][row in tile][8] -> [tile][row in tile][piece][8]
+    back = tiled.view(rows // 32, pad // 8, 32, 8).permute(0, 2, 1, 3).reshape(rows, pad)
+    assert torch.isfinite(back).all() and torch.equal(back, want)
+    if P.desc_sigma_tiled is not None:
+        outs = []
+        for desc, x in ((P.descs['sigma'], want), (P.desc_sigma_tiled, tiled)):
+            out = torch.full((rows, 16), float('nan'), dtype=torch.float16, device='cuda')
+            sig = torch.full((rows,), float('nan'), device='cuda')
+            H.call('aln_density_fwd', C.byref(desc), H.ptr(x), rows, None, None, H.ptr(out), H.ptr(sig), H.stream())
+            outs.append((out, sig))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        # backward from either layout: same input gradients, same weight-gradient slabs
+        d_out = (torch.randn(rows, 16, generator=g) * 0.01).half().cuda()
+        res = []
+        for desc, x in ((P.descs['sigma'], want), (P.desc_sigma_tiled, tiled)):
+            P.grad.zero_()
+            d_in = torch.full((rows, pad), float('nan'), dtype=torch.float16, device='cuda')
+            flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+            H.call('aln_mlp_bwd', C.byref(desc), H.ptr(x), None, None, H.ptr(d_out), rows, None, None, None, H.ptr(d_in),
+                   C.c_void_p(P.grad.data_ptr() + 4 * layout.offsets['sigma']), H.ptr(flag), H.stream())
+            ds = (C.c_void_p * 1)(C.addressof(desc)); dws = (C.c_void_p * 1)(P.grad.data_ptr() + 4 * layout.offsets['sigma'])
+            H.call('aln_mlp_dw_reduce_all', 1, ds, dws, (C.c_int32 * 1)(rows), H.stream())
+            res.append((d_in.clone(), P.net_view('sigma', P.grad).clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
     """aln_encode_fwd_cells generates the jittered cell points inside the kernel: same bits as encoding aln_grid_points' output,
     for both the tile kernel and the level-phased kernels, at a cell offset."""
