@@ -254,10 +254,14 @@ class HipPipeline:
         self.found_inf = torch.zeros(1, dtype=i32_, device=params.device)
         self.phased_min_rows = 1 << 16   # hash-grid forward: level-phased from this many sample rows on
         self.tiled_enc_enabled = True    # (bench.py --no-tiled-enc: A/B against the plane buffers + assembly pass)
+        # Rendering only.  Same-box A/B of the replayed training step (bench.py, two runs each): 2.245 / 2.241 M rays/s through planes +
+        # assembly, 2.232 / 2.225 tiled (-0.6 %); marching step 5.68 / 5.70 vs 5.54 / 5.55 (-2.5 %); render through the grid 16.8 / 16.9 vs
+        # 17.0 / 17.5 M rays/s (+1-4 %), dense render even.  The quarter-line stores cost the gather about what the assembly pass cost.
+        self.tiled_enc_train = False
         # the tiled layout's 4-byte stores rely on the four levels of a 16-byte piece meeting in the XCD's L2: a phase writes rows x 4 B, an
         # eighth of it per XCD -- at the dense renderer's 8.4 M rows per launch that is more than the 4 MB L2 and the pieces leave for HBM
         # one level at a time (measured: dense render 4.8 -> 4.65 M rays/s; marching render, 2.1 M rows: 17.5 -> 18.3; training, 0.5 M: even)
-        self.tiled_max_rows = 1 << 22
+        self.tiled_max_rows = 1 << 21     # rows per gather launch in tiled mode (density_rows splits larger passes into whole-ray pieces)
         # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
         self.recompute = all(k in params.wide_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
@@ -445,16 +449,24 @@ class HipPipeline:
         """True when the density head's input rows are written straight in the tiled layout (no plane buffers, no assembly pass): the
         level-phased gather for every pass of the launch sequence, the 128-wide kernels as the only readers, and pass boundaries on
         whole 32-row tiles."""
+        if train and not self.tiled_enc_train:
+            return False
         save = train and not self.recompute
         return (self.tiled_enc_enabled and self.P.desc_sigma_tiled is not None and bool(self.L.enc.use_grid) and not save and
-                all(self.phased_min_rows <= r <= self.tiled_max_rows and r % 32 == 0 for r in rows_per_pass))
+                all(self.phased_min_rows <= r and r % 32 == 0 for r in rows_per_pass))
 
     def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train, ws=None, tiled=False):
         e, s = self.L.enc, self.L.nets['sigma']
         ws = self.ws if ws is None else ws
         if tiled:
-            self._k('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz),
-                    rows, stride, None, H.ptr(enc), H.stream(), tag=('enc_fwd', rows))
+            # (launches of at most tiled_max_rows rows, whole rays each: see tiled_max_rows)
+            per = max(stride, self.tiled_max_rows // (32 * stride) * (32 * stride)) if xyz is None else self.tiled_max_rows // 32 * 32
+            for a in range(0, rows, per):
+                n = min(per, rows - a)
+                ra = a // stride if xyz is None else 0
+                self._k('aln_encode_fwd_phased', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o[ra:]) if xyz is None else None,
+                        H.ptr(rays_d[ra:]) if xyz is None else None, H.ptr(z[a:]) if xyz is None else None, H.ptr(xyz[a:]) if xyz is not None else None,
+                        n, stride, None, H.ptr(enc[a:]), H.stream(), tag=('enc_fwd', n))
             self._k('aln_density_fwd', C.byref(self.P.desc_sigma_tiled), H.ptr(enc), rows, None, None, H.ptr(out), H.ptr(sigma), H.stream(),
                     tag=('sigma', rows))
             return

@@ -40,6 +40,8 @@ def _run(kind, guard):
     Workspace.guard_bytes = 4096 if guard else 0
     try:
         frames, layout, P, pipe = _setup(D=512 if kind == 'lseg' else 64, cuda_ray=kind == 'march')
+        pipe.tiled_enc_train = kind == 'groups'      # (one of the four kinds trains through the tiled hash-grid output as well)
+        pipe.phased_min_rows = 1 << 15               # (... at this test's 32 K rows per pass)
         kw = dict(feature_loss=True, semantic_weight=0.0) if kind == 'lseg' else {}
         eng = TrainEngine(pipe, num_steps=32, upsample_steps=32, **kw)
         batch = frames.alloc_batch(512 if kind == 'lseg' else 1024)
