@@ -113,11 +113,11 @@ __device__ long long g_ph128[32];
 #define PT_FLUSH
 #endif
 
-template <int IN>
+template <int IN, bool XT>   // XT: x rows in the tiled layout of AlnMlpDesc.x_tiled (compile-time: see mlp_fwd128.hip)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, const h16* __restrict__ x_g,
                   const h16* __restrict__ do_g, int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
-                  float* __restrict__ dw_ws, int* __restrict__ found_inf, int x_tiled) {
+                  float* __restrict__ dw_ws, int* __restrict__ found_inf) {
   constexpr int KS0 = IN / 16, IB = (IN + 31) / 32, PX = px_pitch(IN);
   constexpr int XCH = IN / 8, NXS = (TR * XCH + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -158,7 +158,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
       // (x rows row-major, or in the tiled layout of AlnMlpDesc.x_tiled: chunk k of row m at 32 IN (m / 32) + 256 k + 8 (m % 32))
       if (i < TR * XCH && r0 + r < rows) {
         const int m = r0 + r;
-        px[q] = *(const h16x8*)(x_tiled ? x_g + (size_t)(m >> 5) * (32 * IN) + 256 * k + 8 * (m & 31) : x_g + (size_t)m * IN + 8 * k);
+        px[q] = *(const h16x8*)(XT ? x_g + (size_t)(m >> 5) * (32 * IN) + 256 * k + 8 * (m & 31) : x_g + (size_t)m * IN + 8 * k);
       }
     }
   };
@@ -502,9 +502,15 @@ static int launch(const AlnMlpDesc* m, const h16* x, const h16* d_out, int rows,
   constexpr int IB = (IN + 31) / 32;
   constexpr size_t lds = (2 * (size_t)TR * PX + (size_t)TR * PO + 64 + 3 * (size_t)HID * PH + (size_t)IB * KS * 512) * 2;   // + 64 halves: the transposed reads of the last row run past it
   static_assert(lds <= 160 * 1024, "LDS");
-  hipFuncSetAttribute((const void*)k_mlp_bwd128<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_mlp_bwd128<IN>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,
-                     (h16*)d_in, ws, found_inf, (int)m->x_tiled);
+  if (m->x_tiled) {
+    hipFuncSetAttribute((const void*)k_mlp_bwd128<IN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_mlp_bwd128<IN, true>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,
+                       (h16*)d_in, ws, found_inf);
+  } else {
+    hipFuncSetAttribute((const void*)k_mlp_bwd128<IN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_mlp_bwd128<IN, false>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,
+                       (h16*)d_in, ws, found_inf);
+  }
   return 0;
 }
 

@@ -57,10 +57,12 @@ extern "C" int aln_debug_read_fwd128(long long* host_out, int reset) {
 #define F_STAMP(i)
 #define F_FLUSH
 #endif
-template <int KS0>   // k-steps of the input rows (in_pad / 16: 2 = colour head, 3 = density head)
+// TILED: the input rows are in the tiled layout of AlnMlpDesc.x_tiled.  A COMPILE-TIME switch: as a run-time argument the address
+// selects cost the row-major instantiations 60 us per training step (same-box A/B of the replayed step: 1.74 -> 1.80 ms).
+template <int KS0, bool TILED>   // k-steps of the input rows (in_pad / 16: 2 = colour head, 3 = density head)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int rows, const int* __restrict__ rows_dev, h16* __restrict__ out,
-                  float* __restrict__ sigma, int tiled) {
+                  float* __restrict__ sigma) {
   constexpr int NB = 4, KS = 8, IN = 16 * KS0;
   const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -95,9 +97,9 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
     const int ra = min(p * 64 + c, rows - 1), rb = min(p * 64 + 32 + c, rows - 1);   // clamped: a row beyond the end is never stored
     // row-major rows, or the tiled layout of AlnMlpDesc.x_tiled (piece 2 ks + hf of row r at 32 IN (r / 32) + 256 piece + 8 (r % 32)): the
     // pieces the lanes fetch are the same either way, only their addresses differ (tiled: a tile's piece is one contiguous 512 bytes)
-    const h16* const pa = tiled ? x + (size_t)(ra >> 5) * (32 * IN) + 8 * (ra & 31) + 256 * hf : x + (size_t)ra * IN + 8 * hf;
-    const h16* const pb = tiled ? x + (size_t)(rb >> 5) * (32 * IN) + 8 * (rb & 31) + 256 * hf : x + (size_t)rb * IN + 8 * hf;
-    const int kstep = tiled ? 512 : 16;
+    const h16* const pa = TILED ? x + (size_t)(ra >> 5) * (32 * IN) + 8 * (ra & 31) + 256 * hf : x + (size_t)ra * IN + 8 * hf;
+    const h16* const pb = TILED ? x + (size_t)(rb >> 5) * (32 * IN) + 8 * (rb & 31) + 256 * hf : x + (size_t)rb * IN + 8 * hf;
+    constexpr int kstep = TILED ? 512 : 16;
 #pragma unroll
     for (int ks = 0; ks < KS0; ++ks) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + kstep * ks),
@@ -233,8 +235,10 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
 int aln_launch_fwd128(const AlnMlpDesc* m, const void* x, int rows, const int* rows_dev, void* out, float* sigma, hipStream_t s) {
   if (m->hidden != 128 || m->n_hidden != 2 || m->out_pad != 16 || (m->in_pad != 32 && m->in_pad != 48)) return -3;
   const int pairs = (rows + 63) / 64, g = min(256, (pairs + 3) / 4);
-  if (m->in_pad == 32) hipLaunchKernelGGL(k_mlp_fwd128<2>, dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma, (int)m->x_tiled);
-  else hipLaunchKernelGGL(k_mlp_fwd128<3>, dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma, (int)m->x_tiled);
+#define ALN_F128(KS0, T) hipLaunchKernelGGL((k_mlp_fwd128<KS0, T>), dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma)
+  if (m->in_pad == 32) { if (m->x_tiled) ALN_F128(2, true); else ALN_F128(2, false); }
+  else { if (m->x_tiled) ALN_F128(3, true); else ALN_F128(3, false); }
+#undef ALN_F128
   return 0;
 }
 
