@@ -461,6 +461,18 @@ __device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
   aln_sample_xyz(p.rays_o + 3 * (size_t)ray, p.rays_d + 3 * (size_t)ray, p.z[row], p.e.bound, x);
 }
 
+#ifdef BIN_DEBUG
+// Development taps of phase 1 for scripts/dev/stress_scatter.py (a library built with -DBIN_DEBUG=5 or 6; never the shipped one):
+//   5: [level][tile position][16] the eight record values of every row + scale, slots, row -- the map that traces a wrong record of a
+//      failing replay back to its (tile, wave, lane, corner);   6: one 100 MHz timestamp per (level, tile, wave).
+// They are how the run-to-run differences under a second process were pinned on packed fp32 instructions (build.py).
+__device__ uint32_t* g_bin_dbg = nullptr;
+extern "C" int aln_debug_set_bin_dbg(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bin_dbg), &ptr, sizeof(ptr)); }
+#endif
+__device__ inline uint32_t bin_pack_h2(float a, float b) {
+  h16x2 h; h[0] = (h16)a; h[1] = (h16)b;
+  return *(const uint32_t*)&h;
+}
 typedef uint32_t rec_pair __attribute__((ext_vector_type(4), aligned(8)));   // two 8-byte records at an 8-byte aligned LDS address
 __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   __shared__ uint2 sorted[BIN_CHUNK];                        // 32 KB
@@ -559,6 +571,15 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     // optimizer to its slice (no partly stepped table), whoever produced d_enc.
     if (head && umax >= 0x7f800000u && b.found_inf) *b.found_inf = 1;
     const bool emit = head && umax != 0u && umax <= 0x7f800000u;     // (a NaN run is dropped; the step is skipped anyway)
+#ifdef BIN_DEBUG
+#if BIN_DEBUG == 6
+    if (g_bin_dbg && lane == 0) {   // one 100 MHz timestamp per (level, tile, wave): a wave that was switched out shows a gap
+      const unsigned long long t = wall_clock64();
+      uint32_t* o = g_bin_dbg + (((size_t)l * b.ntiles + tile) * 8 + (tid >> 6)) * 2;
+      o[0] = (uint32_t)t; o[1] = (uint32_t)(t >> 32);
+    }
+#endif
+#endif
     // Ranks within the slices.  The two x-neighbour corners of a cell (c, c + 1) almost always fall into the same slice (their
     // indices differ in the lowest bits: +1 in a dense level, ^1 for even x in a hashed one), so a PAIR takes one returning
     // atomic (+2) and, below, one 16-byte store.  (Measured: 325 -> 321 us only.  Stubbing out the atomics, the sorted stores or
@@ -603,10 +624,17 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
       const float sc = __uint_as_float((uint32_t)(127 - BIN_SHIFT_BIAS + shift_s) << 23);   // 2^shift
 #pragma unroll
       for (int c = 0; c < 8; c += 2) {
-        h16x2 h0, h1;
-        h0[0] = (h16)(v[2 * c] * sc); h0[1] = (h16)(v[2 * c + 1] * sc); h1[0] = (h16)(v[2 * c + 2] * sc); h1[1] = (h16)(v[2 * c + 3] * sc);
+        const uint32_t hw0 = bin_pack_h2(v[2 * c] * sc, v[2 * c + 1] * sc), hw1 = bin_pack_h2(v[2 * c + 2] * sc, v[2 * c + 3] * sc);
         const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
-        const uint2 r0 = make_uint2(idx[c] & slot_mask, *(const uint32_t*)&h0), r1 = make_uint2(idx[c + 1] & slot_mask, *(const uint32_t*)&h1);
+        const uint2 r0 = make_uint2(idx[c] & slot_mask, hw0), r1 = make_uint2(idx[c + 1] & slot_mask, hw1);
+#if defined(BIN_DEBUG) && BIN_DEBUG == 5
+        if (g_bin_dbg) {
+          uint32_t* o = g_bin_dbg + ((size_t)l * p.rows + row0 + tid) * 16;
+          o[c] = r0.y; o[c + 1] = r1.y;
+          if (c == 0) { o[8] = __float_as_uint(sc); o[9] = shift_s; o[10] = __float_as_uint(v[1]); o[11] = __float_as_uint(v[3]); o[12] = r0.x; o[13] = r1.x;
+                        o[14] = base[s0] + rk[0]; o[15] = (uint32_t)row; }
+        }
+#endif
         uint2* const d0 = sorted + base[s0] + rk[c];
         if (s0 == s1) *(rec_pair*)d0 = rec_pair{r0.x, r0.y, r1.x, r1.y};      // adjacent slots: one two-record store (ds_write2_b64)
         else { d0[0] = r0; sorted[base[s1] + rk[c + 1]] = r1; }

@@ -140,11 +140,15 @@ def main():
         if a.groups and it % 2 == 1:
             # what TrainEngine.forward_backward does under data parallelism with overlap, minus the collectives
             eng.world, eng.overlap_comm = 2, True
+            if hasattr(eng, 'dp'):
+                eng.dp = True
             saved = eng._bucket_ready
             eng._bucket_ready = lambda kind, x, y: None
             out = eng.forward_backward(batch, seed=7, step=0)
             eng._bucket_ready = saved
             eng.world, eng.overlap_comm = 1, False
+            if hasattr(eng, 'dp'):
+                eng.dp = False
         else:
             out = eng.forward_backward(batch, seed=7, step=0)
         torch.cuda.synchronize()
