@@ -596,13 +596,18 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
       if (lane == 0 && wm) atomicMax(&vmax_s[par], wm);
     }
     if (emit) {
+      // the four pair atomics go out back to back (no branch between them: one LDS round trip for all four instead of one each);
+      // the rare second atomic of a pair that straddles two slices follows in its own pass
 #pragma unroll
       for (int c = 0; c < 8; c += 2) {
         const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
-        const bool same = s0 == s1;
-        rk[c] = atomicAdd(&cnt[par][s0], same ? 2u : 1u);
+        rk[c] = atomicAdd(&cnt[par][s0], s0 == s1 ? 2u : 1u);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) {
+        const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
         rk[c + 1] = rk[c] + 1u;
-        if (!same) rk[c + 1] = atomicAdd(&cnt[par][s1], 1u);
+        if (s0 != s1) rk[c + 1] = atomicAdd(&cnt[par][s1], 1u);
       }
     }
     __syncthreads();
@@ -622,6 +627,9 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     if (tid == 0) vmax_s[par] = 0u;    // next use: level l + 2, two barriers away from any reader
     if (emit) {
       const float sc = __uint_as_float((uint32_t)(127 - BIN_SHIFT_BIAS + shift_s) << 23);   // 2^shift
+      uint32_t b0[4];
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) b0[c >> 1] = base[idx[c] >> sl];     // (all four slice bases requested before the first store)
 #pragma unroll
       for (int c = 0; c < 8; c += 2) {
         const uint32_t hw0 = bin_pack_h2(v[2 * c] * sc, v[2 * c + 1] * sc), hw1 = bin_pack_h2(v[2 * c + 2] * sc, v[2 * c + 3] * sc);
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
                         o[14] = base[s0] + rk[0]; o[15] = (uint32_t)row; }
         }
 #endif
-        uint2* const d0 = sorted + base[s0] + rk[c];
+        uint2* const d0 = sorted + b0[c >> 1] + rk[c];
         if (s0 == s1) *(rec_pair*)d0 = rec_pair{r0.x, r0.y, r1.x, r1.y};      // adjacent slots: one two-record store (ds_write2_b64)
         else { d0[0] = r0; sorted[base[s1] + rk[c + 1]] = r1; }
       }
