@@ -668,6 +668,7 @@ struct AccAdam {
 };
 struct AccParams {
   const uint2* pool; const uint32_t* desc; float* grad; int32_t* found_inf; AccAdam ad;
+  h16* wire; float wire_mul;   // data parallelism with fp16 on the wire: the slice leaves as fp16(sum * wire_mul) -- no fp32 gradient
   int ntiles, level_lo, n_levels_here;
   uint32_t blk_start[ALN_MAX_LEVELS + 1];   // first block of each launched level (levels enumerated from level_lo)
   uint32_t size[ALN_MAX_LEVELS], offset[ALN_MAX_LEVELS];
@@ -823,6 +824,20 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     if (bad && a.found_inf) *a.found_inf = 1;   // (already set by the producer of d_enc; kept for a caller that feeds records of its own)
     return;
   }
+  if (a.wire) {
+    // The payload of the gradient exchange written here: exactly what aln_grad_pack_f16 makes of the fp32 gradient this block would
+    // have added to a zeroed table -- fp16(float(sum) * 1 / world), zeros included (the wire buffer is not cleared between steps) --
+    // without the fp32 table's read-modify-write and without the packing pass (57 + 57 + 57 + 28 MB of HBM traffic per step).
+    h16x2* const w2 = (h16x2*)(a.wire + g0);
+    for (uint32_t e = tid; e < ne; e += ACC_THREADS) {
+      const long long q0 = acc[e], q1 = acc[plane + e];
+      const float f0 = q0 != 0ll ? (float)((double)q0 * unit) : 0.f, f1 = q1 != 0ll ? (float)((double)q1 * unit) : 0.f;
+      h16x2 o; o[0] = (h16)(f0 * a.wire_mul); o[1] = (h16)(f1 * a.wire_mul);
+      w2[e] = o;
+    }
+    if (bad && a.found_inf) *a.found_inf = 1;   // (the engine reduces this flag over the ranks: every rank skips the step)
+    return;
+  }
   float* g = a.grad + g0;
   for (uint32_t i = tid; i < 2 * ne; i += ACC_THREADS) {   // g is [entry][feature]
     const long long q = acc[(i & 1u) * plane + (i >> 1)];
@@ -841,19 +856,29 @@ extern "C" int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t r
   return nl * ntiles * BIN_CHUNK * (int64_t)sizeof(uint2) + nl * BIN_MAX_SLICES * ntiles * (int64_t)sizeof(uint32_t);
 }
 
-extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
-                                     const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
-                                     const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
-                                     int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* stream) {
+static int binned_launch(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                         const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
+                         const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
+                         int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* wire_f16, float wire_mul, void* stream) {
   BinParams b;
   if (int rc = fill_params(b.p, e, nullptr, rays_o, rays_d, z, xyz, rows, stride1)) return rc;
   // (with `adam` the caller's aln_adam_step(skip_grid = 1) advances the table's step counter: an empty launch must not pass for a step)
   ALN_REQUIRE(!adam || (rows > 0 && e->use_grid && level_lo < level_hi), "encode_bwd_binned: the fused optimizer step needs rows and levels; "
               "run aln_adam_step without skip_grid for an empty batch");
-  if (rows == 0 || !e->use_grid) return 0;
+  if (!e->use_grid) return 0;
   ALN_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= (int)e->grid.n_levels, "encode_bwd_binned: level range [%d, %d)",
               level_lo, level_hi);
-  ALN_REQUIRE(d_enc && (grad_table || adam) && ws, "encode_bwd_binned: NULL pointer");
+  if (rows == 0) {   // nothing to scatter: an fp32 table keeps its zeros, the wire payload of these levels has to be written as zeros
+    if (wire_f16 && level_lo < level_hi) {
+      const size_t lo = 2 * (size_t)e->grid.offset[level_lo];
+      const size_t hi = level_hi < (int)e->grid.n_levels ? 2 * (size_t)e->grid.offset[level_hi] : 2 * ((size_t)e->grid.offset[level_hi - 1] + e->grid.size[level_hi - 1]);
+      ALN_REQUIRE(hipMemsetAsync((h16*)wire_f16 + lo, 0, (hi - lo) * sizeof(h16), (hipStream_t)stream) == hipSuccess, "encode_bwd_binned: memset of the wire buffer failed");
+    }
+    return 0;
+  }
+  ALN_REQUIRE(d_enc && (grad_table || adam || wire_f16) && ws, "encode_bwd_binned: NULL pointer");
+  ALN_REQUIRE(!wire_f16 || (!adam && ((uintptr_t)wire_f16 & 3) == 0 && e->grid.n_features == 2), "encode_bwd_binned: the fp16 wire output excludes the fused "
+              "optimizer and needs a 4-byte aligned buffer");
   ALN_REQUIRE(!adam || (adam->params && adam->m && adam->v && adam->table_f16 && adam->state_i && adam->state_f && e->grid.n_features == 2),
               "encode_bwd_binned: incomplete optimizer descriptor");
   ALN_REQUIRE(!adam || ((((uintptr_t)adam->params | (uintptr_t)adam->m | (uintptr_t)adam->v) & 7) == 0 && ((uintptr_t)adam->table_f16 & 3) == 0),
@@ -874,6 +899,7 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
   hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
   ALN_CHECK_LAUNCH("encode_bwd_bin");
   a.pool = b.pool; a.desc = b.desc; a.grad = grad_table; a.found_inf = found_inf; a.ntiles = ntiles;
+  a.wire = (h16*)wire_f16; a.wire_mul = wire_mul;
   a.ad = AccAdam{};
   if (adam) a.ad = AccAdam{adam->params, adam->m, adam->v, (h16*)adam->table_f16, adam->state_i, adam->state_f, adam->lr, adam->beta1,
                            adam->beta2, adam->eps, log((double)adam->beta1), log((double)adam->beta2)};
@@ -896,6 +922,25 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
   hipLaunchKernelGGL(k_encode_bwd_accum, dim3(nblk), dim3(ACC_THREADS), 2 * (size_t)max_entries * sizeof(long long), (hipStream_t)stream, a);
   ALN_CHECK_LAUNCH("encode_bwd_accum");
   return 0;
+}
+extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                                     const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
+                                     const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
+                                     int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* stream) {
+  return binned_launch(e, rays_o, rays_d, z, xyz, rows, rows_pass1, stride1, stride2, perm, d_enc, grad_table, ws, level_lo, level_hi, found_inf,
+                       adam, nullptr, 0.f, stream);
+}
+// The same scatter with the gradient of levels [level_lo, level_hi) leaving as the fp16 PAYLOAD of the data-parallel exchange:
+// wire_f16[2 * (offset[l] + entry) + feature] = fp16(float(sum) * wire_mul) for EVERY entry of those levels (zeros included) -- bit for bit
+// what aln_grad_pack_f16(grad_table, mul = wire_mul) produces after aln_encode_bwd_binned into a zeroed grad_table; nothing is read
+// from or written to an fp32 gradient table.  A non-finite record poisons the slice's first element and raises found_inf.
+extern "C" int aln_encode_bwd_binned_wire(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                                          const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
+                                          const uint16_t* perm, const void* d_enc, void* ws, int32_t level_lo, int32_t level_hi,
+                                          int32_t* found_inf, void* wire_f16, float wire_mul, void* stream) {
+  ALN_REQUIRE(wire_f16, "encode_bwd_binned_wire: NULL wire buffer");
+  return binned_launch(e, rays_o, rays_d, z, xyz, rows, rows_pass1, stride1, stride2, perm, d_enc, nullptr, ws, level_lo, level_hi, found_inf,
+                       nullptr, wire_f16, wire_mul, stream);
 }
 
 extern "C" int aln_grid_desc_init(AlnGridDesc* g) {

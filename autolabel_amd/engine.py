@@ -18,7 +18,7 @@ class TrainEngine:
     def __init__(self, pipe, lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6, rgb_weight=1.0, depth_weight=0.1,
                  semantic_weight=1.0, feature_weight=0.5, feature_loss=False, num_steps=128, upsample_steps=128,
                  scaler=None, process_group=None, overlap_comm=True, grad_payload='f16', fuse_grid_adam=True, shard_optimizer=False,
-                 shard_gather='table', exchange_at_world_1=False):
+                 shard_gather='table', exchange_at_world_1=False, direct_wire=True):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
         dv = self.P.device
         # the step's intermediates live in a workspace of the engine's own: a render through the same pipeline (pipe.ws) between
@@ -84,6 +84,7 @@ class TrainEngine:
         # itself (step()); with more ranks the gradient has to be averaged first, so it goes through P.grad and aln_adam_step
         self.fuse_grid_adam = bool(fuse_grid_adam) and not self.dp and L.n_grid > 0 and int(L.enc.grid.n_features) == 2
         self.grad_payload = grad_payload     # 'f16': the hash-grid gradient crosses the wire as fp16 (parallel.allreduce_bucket)
+        self.direct_wire = bool(direct_wire)  # ... written by the scatter itself instead of an fp32 table gradient + a packing pass (_wire_direct)
         self._comm = torch.cuda.Stream(device=dv) if self.dp else None
         self._g = {}
         # occupancy-grid marching (pipe.occ set by enable_marching / ALNetwork(cuda_ray=True)): S1 rows per ray inside occupied
@@ -131,16 +132,31 @@ class TrainEngine:
                H.ptr(out['semantic_features']), H.ptr(batch['pixels']), H.ptr(batch['depth']), H.ptr(batch['semantic']),
                H.ptr(gt_feat), N, L.C, L.D, Cf, w[0], w[1], w[2], w[3] if gt_feat is not None else 0.0, H.ptr(self.state_f),
                H.ptr(self.counts), H.ptr(g_image), H.ptr(g_depth), H.ptr(g_sem), H.ptr(g_feat), H.ptr(self.terms), H.stream())
+        # fp16 on the wire, replicated optimizer: the scatter writes the exchange's payload itself (no fp32 table gradient, no packing pass)
+        wire = self._wire_full() if self._wire_direct() else None
+        kw = dict(grid_wire=wire, wire_mul=1.0 / self.world) if wire is not None else {}
         if self.dp and self.overlap_comm:
             self._reduced = True
             # the scatter raises its own flag word: the MLP bucket's tail overwrites state_i[2] on the communication stream while
             # the scatter is still running on the compute stream, so a flag stored there in between could be lost
             pipe.backward(ctx, g_image, g_depth, g_sem, g_feat, level_groups=self.level_groups(), on_grad_ready=self._bucket_ready,
-                          scatter_flag=self.state_i[3:4])
+                          scatter_flag=self.state_i[3:4], **kw)
         else:
             self._reduced = False
-            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat, grid_adam=self._adam_fuse() if grid_adam else None)
+            pipe.backward(ctx, g_image, g_depth, g_sem, g_feat, grid_adam=self._adam_fuse() if grid_adam else None, **kw)
         return out
+
+    def _wire_direct(self):
+        """True when the hash-grid scatter writes the fp16 payload of the exchange itself (aln_encode_bwd_binned_wire): data parallelism,
+        fp16 on the wire, replicated optimizer.  (The sharded optimizer stages padded shards and clears its source: parallel.reduce_scatter_bucket.)"""
+        return bool(self.dp and self.grad_payload == 'f16' and self.shard is None and self.L.n_grid > 0 and self.direct_wire)
+
+    def _wire_full(self):
+        """fp16 payload of the whole table's gradient (element i = flat gradient element i), written by the scatter, reduced in place."""
+        t = self._g.get('wire_full')
+        if t is None:
+            t = self._g['wire_full'] = torch.zeros(self.L.n_grid, dtype=torch.float16, device=self.P.device)
+        return t
 
     def _adam_fuse(self):
         P, L = self.P, self.L
@@ -184,7 +200,9 @@ class TrainEngine:
         """One hash-grid bucket over the ranks on the current stream: all-reduce, or reduce-scatter under the sharded optimizer."""
         from .parallel import allreduce_bucket, reduce_scatter_bucket, shard_range
         if self.shard is None:
-            allreduce_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire(b - a), flag=self.state_i[3:4], force=True)
+            direct = self._wire_direct()
+            allreduce_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire_full()[a:b] if direct else self._wire(b - a),
+                             flag=self.state_i[3:4], force=True, prepacked=direct)
         else:
             S = shard_range(a, b, self.rank, self.world)[2]
             reduce_scatter_bucket(self.P.grad, a, b, self.pg, payload=self.grad_payload, scratch=self._wire((self.world + 1) * S), flag=self.state_i[3:4])
@@ -216,8 +234,10 @@ class TrainEngine:
                 self.state_i[3:4] = 0
             else:
                 from .parallel import allreduce_gradients
+                direct = self._wire_direct()
                 allreduce_gradients(self.P.grad, self.L.n_total, self.state_i[2:3], self.pg, counts=self.counts, n_grid=self.L.n_grid,
-                                    payload=self.grad_payload, scratch=self._wire(self.L.n_grid), force=True)
+                                    payload=self.grad_payload, scratch=self._wire_full() if direct else self._wire(self.L.n_grid), force=True,
+                                    prepacked=direct)
 
     def optimizer_step(self, step_dev=None, skip_grid=False):
         P, L, sc = self.P, self.L, self.scaler_cfg

@@ -11,7 +11,7 @@ import torch
 from .build import LIB
 
 ALN_MAX_LEVELS = 16
-ABI_VERSION = 6   # include/autolabel_hip.h: ALN_ABI_VERSION
+ABI_VERSION = 7   # include/autolabel_hip.h: ALN_ABI_VERSION
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
 
@@ -66,6 +66,7 @@ _SIGS = {
     'aln_encode_bwd_binned_ws_bytes': (i64, [vp, i32]),
     'aln_encode_bwd_binned_tile_rows': (i32, []),
     'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'aln_encode_bwd_binned_wire': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp, f32, vp]),
     'aln_wide_nt': (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp]),
     'aln_wide_tn_ws_bytes': (i64, [i32, i32, i32]),
     'aln_wide_tn': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]),

@@ -64,8 +64,10 @@ def _avg_inplace(view, group, world):
         view.mul_(1.0 / world)
 
 
-def _avg_f16(grad, a, b, scratch, found_inf, group, world):
+def _avg_f16(grad, a, b, scratch, found_inf, group, world, prepacked=False):
     """grad[a:b] averaged over the ranks with fp16 on the wire: pack (x 1/world) -> SUM all-reduce of the halves -> unpack.
+    `prepacked`: scratch[:b - a] already holds fp16(gradient x 1/world) -- the hash-grid scatter wrote the payload itself
+    (aln_encode_bwd_binned_wire; grad[a:b] holds nothing yet) -- so the packing pass is skipped.
     A non-finite element after the reduction (the same on every rank) raises `found_inf`: the step is skipped like any other
     fp16 overflow.  Device tensors only: the two conversions are HIP kernels (csrc/adam.hip)."""
     from . import hip as H
@@ -75,7 +77,8 @@ def _avg_f16(grad, a, b, scratch, found_inf, group, world):
     assert scratch is not None and scratch.dtype == torch.float16 and scratch.numel() >= n, 'fp16 staging buffer too small'
     assert a % 4 == 0, 'bucket start must keep the fp32 side 16-byte aligned'
     wire = scratch[:n]
-    H.call('aln_grad_pack_f16', H.ptr(grad[a:b]), n, 1.0 / world, H.ptr(wire), H.stream())
+    if not prepacked:
+        H.call('aln_grad_pack_f16', H.ptr(grad[a:b]), n, 1.0 / world, H.ptr(wire), H.stream())
     dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group)
     H.call('aln_grad_unpack_f16', H.ptr(wire), n, H.ptr(grad[a:b]), H.ptr(found_inf) if found_inf is not None else None, H.stream())
 
@@ -85,7 +88,7 @@ def wire_bytes(n_grid, n_total, payload='f16'):
     return n_grid * (2 if payload == 'f16' else 4) + (n_total - n_grid + 2) * 4
 
 
-def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None, n_grid=0, payload='f32', scratch=None, force=False):
+def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None, n_grid=0, payload='f32', scratch=None, force=False, prepacked=False):
     """Average `grad[:n_total]` over the group in place; `found_inf` (int32[1]) becomes the logical OR over ranks, and so does
     "some rank had labelled rays" (`counts[1] > 0`, which decides whether the semantic heads take an optimizer step).  `grad`
     must have at least two spare elements at index n_total.  payload='f32': ONE collective over the flat buffer.
@@ -99,13 +102,14 @@ def allreduce_gradients(grad, n_total, found_inf, group=None, counts=None, n_gri
     if payload == 'f16' and n_grid > 0:
         _avg_inplace(grad[n_grid:n_total + 2], group, world)
         _unpack_tail(grad, n_total, found_inf, counts)
-        _avg_f16(grad, 0, n_grid, scratch, found_inf, group, world)
+        _avg_f16(grad, 0, n_grid, scratch, found_inf, group, world, prepacked)
         return
     _avg_inplace(grad[:n_total + 2], group, world)
     _unpack_tail(grad, n_total, found_inf, counts)
 
 
-def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=None, payload='f32', scratch=None, flag=None, force=False):
+def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=None, payload='f32', scratch=None, flag=None, force=False,
+                     prepacked=False):
     """Average `grad[a:b]` over the group in place (one collective on the current stream).  With `found_inf` the bucket
     must end at `tail` (= n_total): the flags travel in `grad[tail:tail + 2]` and come back as the OR over ranks.
     payload='f16' (hash-grid buckets): fp16 on the wire through `scratch`; `flag` (int32[1]) is raised on a non-finite result."""
@@ -117,7 +121,7 @@ def allreduce_bucket(grad, a, b, group=None, found_inf=None, tail=None, counts=N
         _pack_tail(grad, tail, found_inf, counts)
         b = tail + 2
     elif payload == 'f16':
-        _avg_f16(grad, a, b, scratch, flag, group, world)
+        _avg_f16(grad, a, b, scratch, flag, group, world, prepacked)
         return
     _avg_inplace(grad[a:b], group, world)
     if found_inf is not None:

@@ -634,7 +634,8 @@ class HipPipeline:
                H.ptr(out.get('semantic_features')), H.ptr(tile_sums) if c.get('sem_sums') else None, H.stream())
         return out, c
 
-    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None, scatter_flag=None, grid_adam=None):
+    def backward(self, c, g_image, g_depth, g_sem=None, g_feat=None, level_groups=None, on_grad_ready=None, scatter_flag=None, grid_adam=None,
+                 grid_wire=None, wire_mul=1.0):
         """Accumulate d(loss)/d(params) into P.grad from per-ray output gradients (fp32, already loss-scaled).
 
         Data-parallel callers pass ``level_groups`` = [(lo, hi), ...] and ``on_grad_ready``: the hash-grid scatter then runs
@@ -643,7 +644,9 @@ class HipPipeline:
         its all-reduce overlaps the remaining scatter.  ``scatter_flag`` (int32[1]): the hash-grid scatter raises this word instead
         of ``found_inf`` (a data-parallel caller ships ``found_inf`` with the MLP bucket while the scatter is still running).
         ``grid_adam`` (hip.AlnAdamFuse): the scatter's second phase takes the optimizer step for the table itself instead of adding
-        the table's gradient to P.grad (single-GPU training: TrainEngine.step)."""
+        the table's gradient to P.grad (single-GPU training: TrainEngine.step).
+        ``grid_wire`` (fp16 [n_grid]) with ``wire_mul`` (data parallelism, fp16 on the wire): the table's gradient leaves the scatter as the
+        exchange's payload, fp16(sum * wire_mul) -- nothing of it goes to P.grad (aln_encode_bwd_binned_wire)."""
         L, P, ws = self.L, self.P, c['ws']
         self._tn_ws = ws      # scratch of the wide heads' weight-gradient GEMMs (_tn)
         assert c['train'], 'backward needs a forward(train=True) context'
@@ -780,9 +783,15 @@ class HipPipeline:
         F = int(e.grid.n_features)
         for lo, hi in (level_groups or [(0, nl)]):
             # (two passes: the tiles walk every ray in depth order, so coarse and fine samples of one cell dedupe into one record)
-            self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
-                    H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(P.grad), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi,
-                    C.byref(grid_adam) if grid_adam is not None else None, H.stream(), tag=(M, hi - lo))
+            if grid_wire is not None:
+                assert grid_adam is None and grid_wire.dtype == torch.float16 and grid_wire.numel() >= L.n_grid
+                self._k('aln_encode_bwd_binned_wire', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
+                        H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi,
+                        H.ptr(grid_wire), float(wire_mul), H.stream(), tag=(M, hi - lo))
+            else:
+                self._k('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
+                        H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(P.grad), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi,
+                        C.byref(grid_adam) if grid_adam is not None else None, H.stream(), tag=(M, hi - lo))
             if on_grad_ready is not None and level_groups is not None:
                 a = int(e.grid.offset[lo]) * F
                 b = int(e.grid.offset[hi]) * F if hi < nl else L.n_grid

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 6
+#define ALN_ABI_VERSION 7
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -173,6 +173,15 @@ int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float*
                           const uint16_t* depth_order /* optional [rays, stride1 + stride2] */, const void* d_enc,
                           float* grad_table, void* ws, int32_t level_lo, int32_t level_hi, int32_t* found_inf,
                           const AlnAdamFuse* adam /* NULL: gradients are added to grad_table */, void* stream);
+/* Data parallelism with fp16 on the wire (no counterpart in the reference, which has no multi-GPU path: scripts/train.py:83):
+ * the same scatter, but the gradient of levels [level_lo, level_hi) leaves as the PAYLOAD of the exchange --
+ * wire_f16[2 * (offset[l] + entry) + feature] = fp16(float(sum) * wire_mul) for every entry of those levels, zeros included -- bit for bit what
+ * aln_grad_pack_f16(mul = wire_mul) makes of the table aln_encode_bwd_binned adds into when it starts from zeros.  No fp32 gradient table
+ * is read or written (ABI 7). */
+int aln_encode_bwd_binned_wire(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
+                               int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2,
+                               const uint16_t* depth_order, const void* d_enc, void* ws, int32_t level_lo, int32_t level_hi,
+                               int32_t* found_inf, void* wire_f16 /* fp16 [2 * table entries] */, float wire_mul /* 1 / world */, void* stream);
 
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,

@@ -140,6 +140,7 @@ def main():
         if a.groups and it % 2 == 1:
             # what TrainEngine.forward_backward does under data parallelism with overlap, minus the collectives
             eng.world, eng.overlap_comm = 2, True
+            eng.direct_wire = False      # (keep the table's gradient in P.grad, where this tool compares it)
             if hasattr(eng, 'dp'):
                 eng.dp = True
             saved = eng._bucket_ready

@@ -410,6 +410,64 @@ def test_fused_table_optimizer_steps_nothing_when_phase_1_meets_a_non_finite_gra
                None, H.ptr(ws), 3, 3, H.ptr(si[2:3]), C.byref(ad), H.stream())
 
 
+def test_binned_encode_backward_writes_the_fp16_wire_payload_itself(H):
+    """Data parallelism, fp16 on the wire: `aln_encode_bwd_binned_wire` leaves the table's gradient as the exchange's payload.
+    It must be BIT FOR BIT what the fp32 route produces -- aln_encode_bwd_binned into a zeroed table, then aln_grad_pack_f16(x 1 / world) --
+    for the whole table, level group by level group (stale bytes of the other groups untouched, zeros written where nothing landed),
+    with a non-finite gradient raising the flag, and with no rows at all (zeros, not yesterday's payload)."""
+    bound = 2.0
+    e = H.make_enc_desc('hg+freq', bound)
+    N, S1, S2 = 300, 24, 40
+    M1, M = N * S1, N * (S1 + S2)
+    g = torch.Generator().manual_seed(21)
+    ro = ((torch.rand(N, 3, generator=g) - 0.5) * bound).cuda()
+    rd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()
+    z = torch.cat([(torch.rand(N, S1, generator=g).sort(dim=1)[0] * 4).reshape(-1),
+                   (torch.rand(N, S2, generator=g).sort(dim=1)[0] * 4).reshape(-1)]).cuda().contiguous()
+    d_enc = torch.zeros(M, e.enc_pad, dtype=torch.float16, device='cuda')
+    d_enc[:, 12:44] = (torch.randn(M, 32, generator=g) * 20.0).half().cuda()      # (loss-scaled magnitudes: the halves carry real bits)
+    n, nl = int(e.grid.n_entries) * 2, int(e.grid.n_levels)
+    ws = torch.empty(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M)), dtype=torch.uint8, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for world in (1, 8):
+        mul = 1.0 / world
+        grad = torch.zeros(n, device='cuda')
+        _binned_bwd(H, e, ro, rd, z, M, M1, S1, S2, d_enc, grad)
+        want = torch.empty(n, dtype=torch.float16, device='cuda')
+        H.call('aln_grad_pack_f16', H.ptr(grad), n, mul, H.ptr(want), H.stream())
+        assert (want != 0).sum().item() > 10000
+        wire = torch.full((n,), 7.0, dtype=torch.float16, device='cuda')           # stale payload of an earlier step
+        call = lambda rows, lo, hi: H.call('aln_encode_bwd_binned_wire', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, min(M1, rows), S1, S2, None,
+                                           H.ptr(d_enc), H.ptr(ws), lo, hi, H.ptr(flag), H.ptr(wire), mul, H.stream())
+        call(M, 0, nl)
+        torch.cuda.synchronize()
+        assert flag.item() == 0
+        assert torch.equal(wire.view(torch.int16), want.view(torch.int16)), f'world {world}: {(wire != want).sum().item()} halves differ'
+        # level groups: each launch writes its own levels only
+        wire.fill_(7.0)
+        off = [int(e.grid.offset[l]) * 2 for l in range(nl)] + [n]
+        for lo, hi in ((12, 16), (8, 12), (4, 8)):
+            call(M, lo, hi)
+        torch.cuda.synchronize()
+        assert torch.equal(wire[off[4]:].view(torch.int16), want[off[4]:].view(torch.int16))
+        assert bool((wire[:off[4]] == 7.0).all()), 'levels outside the launched groups were written'
+        call(M, 0, 4)
+        torch.cuda.synchronize()
+        assert torch.equal(wire.view(torch.int16), want.view(torch.int16))
+    # no rows: the payload of the launched levels is zero (an fp32 table would simply have kept its zeros)
+    wire.fill_(7.0)
+    H.call('aln_encode_bwd_binned_wire', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, 0, 0, S1, S2, None, H.ptr(d_enc), H.ptr(ws), 8, 12,
+           H.ptr(flag), H.ptr(wire), 1.0, H.stream())
+    torch.cuda.synchronize()
+    assert bool((wire[off[8]:off[12]] == 0).all()) and bool((wire[:off[8]] == 7.0).all()) and bool((wire[off[12]:] == 7.0).all())
+    # a non-finite upstream gradient raises the flag (the engine reduces it over the ranks; every rank skips the step)
+    d_bad = d_enc.clone(); d_bad[M // 2 + 3, 40] = float('inf')
+    H.call('aln_encode_bwd_binned_wire', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, S2, None, H.ptr(d_bad), H.ptr(ws), 0, nl,
+           H.ptr(flag), H.ptr(wire), 1.0, H.stream())
+    torch.cuda.synchronize()
+    assert flag.item() == 1
+
+
 def test_binned_encode_backward_two_passes_and_level_groups(H):
     """Coarse + fine pass in ONE launch (rows_pass1 / two strides) and the data-parallel level groups give the gradient fp32
     autograd computes for the two passes; a non-finite upstream gradient raises found_inf."""

@@ -88,11 +88,23 @@ def _worker(rank, port, ret):
 
 
 def test_rccl_world_of_one_runs_every_data_parallel_form_of_the_step():
-    port = _free_port()
-    with mp.Manager() as mgr:
-        ret = mgr.dict()
-        mp.spawn(_worker, args=(port, ret), nprocs=1, join=True)
-        res = dict(ret)[0]
+    res, errors = None, []
+    for attempt in range(2):     # RCCL failing to come up (once in ~20 runs on the gpurun boxes: a c10 DistBackendError out of the worker before any
+        port = _free_port()      # step has run) is retried once with a fresh rendezvous; what the worker COMPUTED is never retried
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            try:
+                mp.spawn(_worker, args=(port, ret), nprocs=1, join=True)
+            except Exception as e:   # noqa: BLE001 -- ProcessRaisedException / ProcessExitedException of the spawned rank
+                errors.append(f'{type(e).__name__}: {str(e)[:1500]}')
+            got = dict(ret)
+        if 0 in got:
+            res = got[0]
+            break
+    if errors:
+        import warnings
+        warnings.warn('the RCCL worker failed before delivering results: ' + ' | '.join(errors))
+    assert res is not None, errors
     assert res['backend'] == 'nccl' and res['world'] == 1
     errors = {k: v['error'] for k, v in res.items() if isinstance(v, dict) and 'error' in v}
     assert not errors, errors
