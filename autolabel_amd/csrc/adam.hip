@@ -40,7 +40,7 @@ __device__ inline bool adam_block_active(const AdamBlocks& blk, int b, bool has_
 
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        h16* __restrict__ table16, size_t n_grid, size_t n_total, int* si, float* sf, float* c_out, AdamHyper h,
-                       AdamBlocks blk, AdamRanges rg, const int* counts, uint32_t* step_dev) {
+                       AdamBlocks blk, AdamRanges rg, const int* counts, uint32_t* step_dev, const h16* __restrict__ gwire) {
   __shared__ AdamConsts cs;
   const size_t vec_end = (blk.n > 0 && (size_t)blk.end[0] <= n_grid) ? ((size_t)blk.end[0] & ~(size_t)3) : 0;
   // (skip_grid: rg.n = 0 -- nothing of block 0 is touched, not even its zero gradient)
@@ -81,10 +81,14 @@ __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __re
     const long long mq0 = rg.mv[k] / 4 - (long long)q_lo;   // moment index of parameter group q: q + mq0
     for (size_t q = q_lo + blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < q_hi; q += (size_t)gridDim.x * blockDim.x) {
       const size_t mq = (size_t)((long long)q + mq0);
-      const float4 g4 = ((const float4*)g)[q];
+      // gwire (data parallelism, fp16 on the wire): the averaged table gradient is read as the halves the exchange left -- the same
+      // fp32 values aln_grad_unpack_f16 would have written to g -- and there is no fp32 table gradient to read or to clear
+      float4 g4;
+      if (gwire) { if (idle) continue; const h16x4 w4 = *(const h16x4*)(gwire + 4 * q); g4 = make_float4((float)w4[0], (float)w4[1], (float)w4[2], (float)w4[3]); }
+      else g4 = ((const float4*)g)[q];
       float4 p4, m4, v4;
       if (!idle) { p4 = ((const float4*)p)[q]; m4 = ((const float4*)m)[mq]; v4 = ((const float4*)v)[mq]; }
-      ((float4*)g)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!gwire) ((float4*)g)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idle) continue;
       float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
       h16x4 t4;
@@ -160,8 +164,11 @@ static int adam_launch(float* params, float* grads, float* m, float* v, void* ta
                        float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
                        int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
                        int32_t skip_grid, int32_t n_ranges, const int64_t* range_lo, const int64_t* range_hi,
-                       const int32_t* counts, uint32_t* step_dev, void* stream) {
+                       const int32_t* counts, uint32_t* step_dev, const void* grid_wire_f16, void* stream) {
   ALN_REQUIRE(params && grads && m && v && state_i && state_f, "adam: NULL pointer");
+  ALN_REQUIRE(!grid_wire_f16 || (n_ranges < 0 && !skip_grid && n_grid > 0 && n_grid % 4 == 0 && n_blocks > 0 && block_end[0] == n_grid &&
+                                 ((uintptr_t)grid_wire_f16 & 7) == 0),
+              "adam: the fp16 table gradient needs the replicated optimizer with the table as parameter block 0 (a multiple of 4 long)");
   ALN_REQUIRE(n_grid == 0 || table_f16, "adam: fp16 table shadow missing");
   ALN_REQUIRE(n_blocks >= 0 && n_blocks <= ADAM_MAX_BLOCKS && (n_blocks == 0 || (block_end && block_kind)), "adam: bad block table");
   ALN_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)table_f16 & 7) == 0,
@@ -197,7 +204,7 @@ static int adam_launch(float* params, float* grads, float* m, float* v, void* ta
   // blocks' atomics one after the other (~20 ns each) -- 243 blocks for the 62 K MLP parameters of the single-GPU step took 10.7 us,
   // 2048 blocks for the 0.57 M of the LSeg heads 48 us (profiles/r05_lseg_leg_kernel_stats_rocprofv3.csv), for microseconds of work
   hipLaunchKernelGGL(k_adam, dim3(aln_grid_for(n_work > 0 ? (n_work + 3) / 4 : 1, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (h16*)table_f16,
-                     (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, rg, counts, step_dev);
+                     (size_t)n_grid, (size_t)n_total, state_i, state_f, consts, h, blk, rg, counts, step_dev, (const h16*)grid_wire_f16);
   ALN_CHECK_LAUNCH("adam");
   return 0;
 }
@@ -207,7 +214,20 @@ extern "C" int aln_adam_step(float* params, float* grads, float* m, float* v, vo
                              int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
                              int32_t skip_grid, const int32_t* counts, uint32_t* step_dev, void* stream) {
   return adam_launch(params, grads, m, v, table_f16, n_grid, n_total, state_i, state_f, consts, lr, beta1, beta2, eps, wd_net, growth, backoff,
-                     growth_interval, n_blocks, block_end, block_kind, feature_loss, skip_grid, -1, nullptr, nullptr, counts, step_dev, stream);
+                     growth_interval, n_blocks, block_end, block_kind, feature_loss, skip_grid, -1, nullptr, nullptr, counts, step_dev, nullptr, stream);
+}
+// The same step with the TABLE's gradient read from the fp16 payload of the data-parallel exchange (grid_wire_f16[i] = averaged gradient of
+// flat element i < n_grid, as aln_encode_bwd_binned_wire + the SUM all-reduce leave it; watched for non-finite halves by
+// aln_grad_unpack_f16(grad = NULL) beforehand): bit for bit the step aln_grad_unpack_f16 + aln_adam_step take, without the fp32 copy of
+// the table gradient (57 MB written, read and cleared per step).  grads[n_grid, n_total) (the MLP blocks) is read and cleared as usual.
+extern "C" int aln_adam_step_wire(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid,
+                                  int64_t n_total, int32_t* state_i, float* state_f, float* consts, float lr, float beta1,
+                                  float beta2, float eps, float wd_net, float growth, float backoff, int32_t growth_interval,
+                                  int32_t n_blocks, const int64_t* block_end, const int32_t* block_kind, int32_t feature_loss,
+                                  const void* grid_wire_f16, const int32_t* counts, uint32_t* step_dev, void* stream) {
+  ALN_REQUIRE(grid_wire_f16, "adam_step_wire: NULL wire buffer");
+  return adam_launch(params, grads, m, v, table_f16, n_grid, n_total, state_i, state_f, consts, lr, beta1, beta2, eps, wd_net, growth, backoff,
+                     growth_interval, n_blocks, block_end, block_kind, feature_loss, 0, -1, nullptr, nullptr, counts, step_dev, grid_wire_f16, stream);
 }
 // Sharded optimizer of the data-parallel engine (autolabel_amd/engine.py: shard_optimizer): the step touches only the slices
 // [range_lo[k], range_hi[k]) of the hash table (ascending, disjoint, multiples of 4) and the whole MLP block.  `m`, `v` are
@@ -222,7 +242,7 @@ extern "C" int aln_adam_step_ranges(float* params, float* grads, float* m, float
                                     uint32_t* step_dev, void* stream) {
   ALN_REQUIRE(n_ranges >= 0, "adam: negative range count");
   return adam_launch(params, grads, m, v, table_f16, n_grid, n_total, state_i, state_f, consts, lr, beta1, beta2, eps, wd_net, growth, backoff,
-                     growth_interval, n_blocks, block_end, block_kind, feature_loss, 0, n_ranges, range_lo, range_hi, counts, step_dev, stream);
+                     growth_interval, n_blocks, block_end, block_kind, feature_loss, 0, n_ranges, range_lo, range_hi, counts, step_dev, nullptr, stream);
 }
 
 // fp16 shadow of the grid table from the fp32 master (initialisation / checkpoint load)
@@ -277,10 +297,12 @@ __global__ void k_grad_unpack_f16(const h16* __restrict__ in, size_t n, float* _
     float f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { f[j] = (float)v[j]; bad |= !(fabsf(f[j]) <= 65504.f); }
-    *(float4*)(g + 8 * i) = make_float4(f[0], f[1], f[2], f[3]);
-    *(float4*)(g + 8 * i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    if (g) {   // (g == NULL: watch only -- the optimizer reads the halves itself, aln_adam_step_wire)
+      *(float4*)(g + 8 * i) = make_float4(f[0], f[1], f[2], f[3]);
+      *(float4*)(g + 8 * i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
   }
-  if (blockIdx.x == 0) for (size_t i = 8 * n8 + threadIdx.x; i < n; i += blockDim.x) { const float f = (float)in[i]; bad |= !(fabsf(f) <= 65504.f); g[i] = f; }
+  if (blockIdx.x == 0) for (size_t i = 8 * n8 + threadIdx.x; i < n; i += blockDim.x) { const float f = (float)in[i]; bad |= !(fabsf(f) <= 65504.f); if (g) g[i] = f; }
   if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
 }
 extern "C" int aln_grad_pack_f16(const float* grad, int64_t n, float mul, void* out_f16, void* stream) {
@@ -305,7 +327,7 @@ extern "C" int aln_grad_pack_f16_clear(float* grad, int64_t n, int64_t n_pad, fl
   return 0;
 }
 extern "C" int aln_grad_unpack_f16(const void* in_f16, int64_t n, float* grad, int32_t* found_inf, void* stream) {
-  ALN_REQUIRE(grad && in_f16 && n >= 0, "grad_unpack_f16: bad arguments");
+  ALN_REQUIRE(in_f16 && n >= 0 && (grad || found_inf), "grad_unpack_f16: bad arguments");   // grad == NULL: only watch for non-finite halves
   ALN_REQUIRE(((uintptr_t)grad & 15) == 0 && ((uintptr_t)in_f16 & 15) == 0, "grad_unpack_f16: buffers must be 16-byte aligned");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_grad_unpack_f16, dim3(aln_grid_for(n / 8 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const h16*)in_f16, (size_t)n, grad,

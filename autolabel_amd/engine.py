@@ -151,6 +151,14 @@ class TrainEngine:
         fp16 on the wire, replicated optimizer.  (The sharded optimizer stages padded shards and clears its source: parallel.reduce_scatter_bucket.)"""
         return bool(self.dp and self.grad_payload == 'f16' and self.shard is None and self.L.n_grid > 0 and self.direct_wire)
 
+    def averaged_gradient(self):
+        """The flat gradient after all_reduce_grads() as fp32 (a copy): P.grad, with the table's part taken from the fp16 payload when the
+        scatter wrote that itself (then P.grad holds no table gradient at any time)."""
+        g = self.P.grad[:self.L.n_total].clone()
+        if self._wire_direct():
+            g[:self.L.n_grid] = self._wire_full().float()
+        return g
+
     def _wire_full(self):
         """fp16 payload of the whole table's gradient (element i = flat gradient element i), written by the scatter, reduced in place."""
         t = self._g.get('wire_full')
@@ -255,6 +263,13 @@ class TrainEngine:
             for a, b in sh['buckets']:     # the updated fp16 table of every owner (a skipped step gathers the unchanged table)
                 allgather_bucket(P.table16, a, b, self.pg, scratch=self._g.get('wire'))
             P.masters_stale = True         # (until sync_master: state_dict / shadow refreshes refuse to read the masters)
+            P.refresh_shadows(grid=False)
+            return
+        if self._wire_direct() and not skip_grid:   # the table's averaged gradient is the fp16 payload the exchange left (no fp32 copy of it)
+            H.call('aln_adam_step_wire', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,
+                   H.ptr(self.state_i), H.ptr(self.state_f), H.ptr(self.consts), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                   sc['growth_factor'], sc['backoff_factor'], int(sc['growth_interval']), len(self._blk_kind), self._blk_end,
+                   self._blk_kind, int(bool(self.feature_loss)), H.ptr(self._wire_full()), H.ptr(self.counts), H.ptr(step_dev), H.stream())
             P.refresh_shadows(grid=False)
             return
         H.call('aln_adam_step', H.ptr(P.flat), H.ptr(P.grad), H.ptr(self.m), H.ptr(self.v), H.ptr(P.table16), L.n_grid, L.n_total,

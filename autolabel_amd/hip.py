@@ -113,6 +113,7 @@ _SIGS = {
     'aln_loss_terms_floats': (i32, []),
     'aln_loss_fwd_bwd': (i32, [vp] * 8 + [i32] * 4 + [f32] * 4 + [vp] * 8),
     'aln_adam_step': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
+    'aln_adam_step_wire': (i32, [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
     'aln_similarity_argmax': (i32, [vp, i32, i32, vp, i32, vp, vp]),
     'aln_cast_f16': (i32, [vp, vp, i64, vp]),
     'aln_cast_f32': (i32, [vp, vp, i64, vp]),

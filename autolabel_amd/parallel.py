@@ -67,7 +67,8 @@ def _avg_inplace(view, group, world):
 def _avg_f16(grad, a, b, scratch, found_inf, group, world, prepacked=False):
     """grad[a:b] averaged over the ranks with fp16 on the wire: pack (x 1/world) -> SUM all-reduce of the halves -> unpack.
     `prepacked`: scratch[:b - a] already holds fp16(gradient x 1/world) -- the hash-grid scatter wrote the payload itself
-    (aln_encode_bwd_binned_wire; grad[a:b] holds nothing yet) -- so the packing pass is skipped.
+    (aln_encode_bwd_binned_wire; grad[a:b] holds nothing yet) -- so the packing pass is skipped, and the averaged halves STAY in
+    `scratch` for the optimizer (aln_adam_step_wire): they are only watched for a non-finite element, grad[a:b] is not written.
     A non-finite element after the reduction (the same on every rank) raises `found_inf`: the step is skipped like any other
     fp16 overflow.  Device tensors only: the two conversions are HIP kernels (csrc/adam.hip)."""
     from . import hip as H
@@ -80,6 +81,10 @@ def _avg_f16(grad, a, b, scratch, found_inf, group, world, prepacked=False):
     if not prepacked:
         H.call('aln_grad_pack_f16', H.ptr(grad[a:b]), n, 1.0 / world, H.ptr(wire), H.stream())
     dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group)
+    if prepacked:
+        assert found_inf is not None, 'the reduced halves must be watched: pass the flag word'
+        H.call('aln_grad_unpack_f16', H.ptr(wire), n, None, H.ptr(found_inf), H.stream())
+        return
     H.call('aln_grad_unpack_f16', H.ptr(wire), n, H.ptr(grad[a:b]), H.ptr(found_inf) if found_inf is not None else None, H.stream())
 
 

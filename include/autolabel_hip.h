@@ -383,6 +383,16 @@ int aln_adam_step(float* params, float* grads, float* m, float* v, void* table_f
                   int32_t skip_grid /* 1: block 0 (the table) was updated by aln_encode_bwd_binned(adam); only its step counter advances */,
                   const int32_t* counts /*device, optional*/,
                   uint32_t* step_dev /*optional: += 1 once per call (the step counter of aln_raygen_train & co. under graph replay)*/, void* stream);
+/* The same step with the TABLE's gradient taken from the fp16 payload of the data-parallel exchange instead of grads[0, n_grid)
+ * (grid_wire_f16[i] = averaged gradient of flat element i, as aln_encode_bwd_binned_wire and the SUM all-reduce leave it; the caller
+ * has watched it for non-finite halves with aln_grad_unpack_f16(grad = NULL)): bit for bit the step aln_grad_unpack_f16 + aln_adam_step
+ * take, without the fp32 copy of the table gradient.  The MLP blocks' gradients are read from grads and cleared as usual.  Replicated
+ * optimizer only; the table is parameter block 0, n_grid a multiple of 4 (ABI 7). */
+int aln_adam_step_wire(float* params, float* grads, float* m, float* v, void* table_f16, int64_t n_grid, int64_t n_total,
+                       int32_t* state_i, float* state_f, float* consts, float lr, float beta1, float beta2, float eps, float wd_net,
+                       float growth, float backoff, int32_t growth_interval, int32_t n_blocks, const int64_t* block_end /*host*/,
+                       const int32_t* block_kind /*host*/, int32_t feature_loss, const void* grid_wire_f16,
+                       const int32_t* counts /*device, optional*/, uint32_t* step_dev /*optional*/, void* stream);
 /* The same step for a rank that owns only the slices [range_lo[k], range_hi[k]) of the table (n_ranges <= 8, ascending, disjoint,
  * multiples of 4; the table must be parameter block 0 and n_grid a multiple of 4) plus the whole MLP block: the sharded optimizer
  * of the data-parallel engine (no counterpart in the reference, which has no multi-GPU path; the arithmetic per parameter is
@@ -398,7 +408,8 @@ int aln_cast_f16(const float* src, void* dst, int64_t n, void* stream);
 int aln_cast_f32(const void* src_f16, float* dst, int64_t n, void* stream);
 /* fp16 wire format of the data-parallel exchange of the hash-grid gradient block (the reference has no multi-GPU path; the
  * gradient it averages is what scripts/train.py:50-63's optimizer consumes): out = fp16(grad * mul), and back grad = fp32(in)
- * with *found_inf raised on a non-finite element.  Pointers 16-byte aligned. */
+ * with *found_inf raised on a non-finite element (grad == NULL: watch only -- aln_adam_step_wire reads the halves itself).
+ * Pointers 16-byte aligned. */
 int aln_grad_pack_f16(const float* grad, int64_t n, float mul, void* out_f16, void* stream);
 int aln_grad_unpack_f16(const void* in_f16, int64_t n, float* grad, int32_t* found_inf, void* stream);
 /* staging for a reduce-scatter: as aln_grad_pack_f16, plus out[n, n_pad) = 0 and grad[0, n) cleared behind the read */

@@ -169,9 +169,18 @@ def _shard_worker(rank, world, port, ret):
             batch = frames.alloc_batch(1024)
             for i in range(4):
                 frames.next_train(batch, seed=parallel.rank_seed(5, rank), step=i, frame_range=(lo, hi))
-                if i == 2 and rank == 1:
-                    P.grad[5] = float('inf')   # a non-finite table gradient on ONE rank (in rank 0's shard): BOTH ranks must skip the step
+                inner = eng.pipe._k
+                if i == 2 and rank == 1:       # a non-finite table gradient on ONE rank: BOTH ranks must skip the step
+                    if shard:                  # ... as a VALUE in rank 0's shard (the sharded scatter adds into P.grad; the flag is raised on the owner)
+                        P.grad[5] = float('inf')
+                    else:                      # ... upstream of the scatter (replicated, fp16 on the wire: the scatter writes the payload itself and no
+                        def poisoned(name, *a, **kw):    # fp32 table gradient exists to plant a value in): one infinite element of d_enc
+                            if name.startswith('aln_encode_bwd_binned'):
+                                eng.ws.bufs['d_enc'][1][777, 20] = float('inf')
+                            return inner(name, *a, **kw)
+                        eng.pipe._k = poisoned
                 eng.step(batch, seed=parallel.rank_seed(7, rank), step=i)
+                eng.pipe._k = inner
             sd = eng.state_dict()              # (a collective under the sharded optimizer)
             eng.sync_master()
             torch.cuda.synchronize()
@@ -314,7 +323,7 @@ def _equiv_worker(rank, world, port, ret):
         eng.forward_backward(batch, seed=1, step=0, noise=nz.contiguous(), u=uu.contiguous())
         eng.all_reduce_grads()
         torch.cuda.synchronize()
-        return eng.P.grad[:layout.n_total].clone(), int(eng.state_i[2].item())
+        return eng.averaged_gradient(), int(eng.state_i[2].item())    # (fp16 on the wire: the table's part is the exchange's payload itself)
 
     def engine(pg, payload='f16', overlap=True):
         P = Params(layout, dev); P.init_(seed=0)
@@ -338,7 +347,10 @@ def _equiv_worker(rank, world, port, ret):
     eng.P.grad.zero_(); eng.state_i[2:4] = 0
     eng.forward_backward(mine, seed=1, step=0, noise=noise[lo:hi].contiguous(), u=u[lo:hi].contiguous())
     if rank == 1:
-        eng.P.grad[100] = 1e9
+        if eng._wire_direct():     # (the scatter wrote the payload itself: the planted gradient as the half it would have become)
+            eng._wire_full()[100] = float('inf')
+        else:
+            eng.P.grad[100] = 1e9
     eng.all_reduce_grads()
     torch.cuda.synchronize()
     out['overflow_flag'] = int(eng.state_i[2].item())

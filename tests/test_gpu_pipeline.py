@@ -303,6 +303,48 @@ def test_training_converges_like_the_oracle():
     assert abs(ph - po) < 1.0, (ph, po)   # +-1 dB after 50 steps from identical init
 
 
+def test_adam_step_reads_the_fp16_payload_of_the_exchange_bit_for_bit():
+    """Data parallelism, fp16 on the wire: `aln_adam_step_wire` takes the table's averaged gradient from the halves the exchange left
+    (+ a watch-only `aln_grad_unpack_f16`) -- the same step, bit for bit, as unpacking them into the fp32 gradient and running
+    `aln_adam_step`; a non-finite half is seen by the watch and the step skipped; the fp32 table gradient is neither read nor cleared."""
+    from autolabel_amd import hip as H
+    import ctypes
+    n_grid, n = 4096, 4096 + 600
+    g = torch.Generator().manual_seed(4)
+    ends, kinds = (ctypes.c_int64 * 2)(n_grid, n), (ctypes.c_int32 * 2)(0, 0)
+    state = lambda: (torch.zeros(16, dtype=torch.int32, device='cuda'), torch.tensor([128.0, 0, 0, 0], device='cuda'), torch.zeros(24, device='cuda'))
+    p0 = torch.randn(n, generator=g).cuda()
+    A = dict(p=p0.clone(), gr=torch.zeros(n).cuda(), m=torch.zeros(n).cuda(), v=torch.zeros(n).cuda(), t16=torch.zeros(n_grid, dtype=torch.float16, device='cuda'))
+    B = {k: t.clone() for k, t in A.items()}
+    (siA, sfA, cA), (siB, sfB, cB) = state(), state()
+    sentinel = 123.0
+    for it in range(5):
+        wire = (torch.randn(n_grid, generator=g) * (10.0 ** float(torch.randint(-6, 3, (1,), generator=g)))).half().cuda()
+        if it == 3:
+            wire[777] = float('inf')          # an overflow of the fp16 SUM: every rank sees it in the reduced halves
+        mlp = torch.randn(n - n_grid, generator=g).cuda()
+        # reference route: unpack into the fp32 gradient, then the plain step
+        A['gr'][n_grid:] = mlp
+        H.call('aln_grad_unpack_f16', H.ptr(wire), n_grid, H.ptr(A['gr']), H.ptr(siA[2:3]), H.stream())
+        H.call('aln_adam_step', H.ptr(A['p']), H.ptr(A['gr']), H.ptr(A['m']), H.ptr(A['v']), H.ptr(A['t16']), n_grid, n, H.ptr(siA), H.ptr(sfA), H.ptr(cA),
+               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, 0, None, None, H.stream())
+        # wire route: watch only, the optimizer reads the halves; the fp32 table gradient holds a sentinel nobody may touch
+        B['gr'][:n_grid] = sentinel
+        B['gr'][n_grid:] = mlp
+        H.call('aln_grad_unpack_f16', H.ptr(wire), n_grid, None, H.ptr(siB[2:3]), H.stream())
+        H.call('aln_adam_step_wire', H.ptr(B['p']), H.ptr(B['gr']), H.ptr(B['m']), H.ptr(B['v']), H.ptr(B['t16']), n_grid, n, H.ptr(siB), H.ptr(sfB), H.ptr(cB),
+               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, H.ptr(wire), None, None, H.stream())
+        torch.cuda.synchronize()
+        for k in ('p', 'm', 'v', 't16'):
+            assert torch.equal(A[k].view(torch.int32 if k != 't16' else torch.int16), B[k].view(torch.int32 if k != 't16' else torch.int16)), (it, k)
+        assert torch.equal(siA, siB) and torch.equal(sfA, sfB), it
+        assert bool((B['gr'][:n_grid] == sentinel).all()) and float(B['gr'][n_grid:].abs().max()) == 0.0
+    assert int(siA[0]) == 4 and float(sfA[0]) == 128.0 * 2.0 * 0.5      # grew after three clean steps, the overflow step was skipped and backed off
+    with pytest.raises(RuntimeError):       # the halves can only stand in for the whole table under the replicated optimizer
+        H.call('aln_adam_step_wire', H.ptr(B['p']), H.ptr(B['gr']), H.ptr(B['m']), H.ptr(B['v']), H.ptr(B['t16']), n_grid, n, H.ptr(siB), H.ptr(sfB), H.ptr(cB),
+               5e-3, 0.9, 0.99, 1e-15, 1e-6, 2.0, 0.5, 3, 2, ends, kinds, 0, None, None, None, H.stream())
+
+
 def test_adam_step_matches_torch_adam_and_skips_on_inf():
     from autolabel_amd import hip as H
     n_grid, n = 1000, 1600
