@@ -6,6 +6,8 @@ scale, the overflow flag, the optimizer step counter and the loss terms all live
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import hip as H
@@ -18,8 +20,9 @@ class TrainEngine:
     def __init__(self, pipe, lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay_net=1e-6, rgb_weight=1.0, depth_weight=0.1,
                  semantic_weight=1.0, feature_weight=0.5, feature_loss=False, num_steps=128, upsample_steps=128,
                  scaler=None, process_group=None, overlap_comm=True, grad_payload='f16', fuse_grid_adam=True, shard_optimizer=False,
-                 shard_gather='table', exchange_at_world_1=False, direct_wire=True):
+                 shard_gather='table', exchange_at_world_1=False, direct_wire=True, level_group=4):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
+        self.level_group = int(level_group)   # hash-grid levels per scatter launch / gradient bucket of the overlapped exchange (level_groups)
         dv = self.P.device
         # the step's intermediates live in a workspace of the engine's own: a render through the same pipeline (pipe.ws) between
         # two steps cannot move the buffers a captured step points into
@@ -173,12 +176,17 @@ class TrainEngine:
                              self.state_f.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps)
 
     def level_groups(self):
-        """Hash-grid levels in scatter order: the fine (large, 4 MB each) levels first in groups of four -- one level per wave
-        of the scatter kernel -- and the small coarse levels last, so the only all-reduce nothing can hide is the smallest."""
+        """Hash-grid levels in scatter order, the groups whose gradient is exchanged while the next group is scattered: the fine levels
+        first in groups of ``level_group`` (default 4 -- one level per wave of the scatter kernel), the small coarse levels last, so the
+        only all-reduce nothing can hide is the smallest.  Every launch pair beyond the first costs ~30 us of scatter time (world-of-one
+        RCCL legs of bench.py: groups of 4 = five buckets 1.98 ms, groups of 8 = three buckets 1.93, one group 1.90): groups of 4 hide
+        8.4 MB buckets behind ~150 us of scatter each and expose 1.4 MB; groups of 8 expose the 11 MB of levels 0-7.  Which wins depends on
+        what the links deliver, so `bench.py --gpus N` times both (dp_overlap, dp_overlap_g8)."""
         n = int(self.L.enc.grid.n_levels) if self.L.n_grid else 0
+        per = max(1, int(os.environ.get('ALN_LEVEL_GROUP', self.level_group)))
         groups, hi = [], n
         while hi > 0:
-            lo = max(0, hi - 4)
+            lo = max(0, hi - per)
             groups.append((lo, hi))
             hi = lo
         return groups
