@@ -128,7 +128,8 @@ class Workload:
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)
             pipe.mark_untrained_grid(t.world_to_camera(), (t.desc.fx, t.desc.fy, t.desc.cx, t.desc.cy), size=(t.w, t.h))
         return TrainEngine(pipe, feature_loss=True, process_group=pg, semantic_weight=semantic_weight, overlap_comm=overlap_comm,
-                           shard_optimizer=shard_optimizer, exchange_at_world_1=exchange_at_world_1, level_group=level_group)
+                           shard_optimizer=shard_optimizer, exchange_at_world_1=exchange_at_world_1, level_group=level_group,
+                           direct_wire=os.environ.get('ALN_DIRECT_WIRE', '1') != '0')   # (A/B knob: 0 = fp32 table gradient + conversion passes)
 
     def renderer(self, eng, march):
         """render callable for quality.heldout_metrics: 256 rows per ray along the whole ray (dense) / 128 rows inside occupied cells."""
@@ -408,6 +409,8 @@ def dp_world1_leg(wl, args, B, teardown=True):
         for name, overlap, graph, shard, lg in [('dp_simple', False, False, False, 4), ('dp_overlap', True, False, False, 4), ('dp_overlap_g8', True, False, False, 8),
                                                 ('dp_sharded', True, False, True, 4), ('dp_graph', True, True, False, 4), ('dp_graph_g8', True, True, False, 8),
                                                 ('dp_sharded_graph', True, True, True, 4)]:
+            if os.environ.get('ALN_DP1_ONLY') and name not in os.environ['ALN_DP1_ONLY'].split(','):   # (profiling runs: scripts/dev/run_profiles.sh)
+                continue
             try:
                 e = wl.engine(SEEDS[0][0], pg=dist.group.WORLD, overlap_comm=overlap, shard_optimizer=shard, exchange_at_world_1=True, level_group=lg)
                 dt = timed_leg(wl, a2, e, B, SEEDS[0][1], SEEDS[0][2], None, graph, 1, torch.cuda.synchronize)[0]
@@ -450,6 +453,9 @@ def dp1_child(args):
     device = torch.device('cuda', 0)
     torch.cuda.set_device(device)
     wl = Workload(args, device)
+    if os.environ.get('ALN_DP1_ONLY'):   # a profiled run of chosen eager legs: tear down and leave normally, so that rocprofv3 writes its trace
+        print(json.dumps(dp_world1_leg(wl, args, args.batch, teardown=True)), flush=True)
+        return 0
     print(json.dumps(dp_world1_leg(wl, args, args.batch, teardown=False)), flush=True)
     # captured graphs that hold RCCL kernels and a destroyed communicator do not always unwind in a safe order at interpreter exit (one
     # abort in three in-bench runs, after the line above): leave without running destructors
