@@ -126,12 +126,12 @@ def test_two_ranks_on_one_gpu_stay_in_lockstep_with_bucketed_allreduce():
         assert step0[-1][1] == 0
     # overlapped buckets and the single exchange after the backward pass move the same numbers: every kernel of the step is
     # order-independent and the level groups reproduce the single scatter launch bit for bit.
-    # This comparison failed ONCE (GPUTEST_r04, 3.4 M parameters apart after three steps, both ranks still in agreement) and has not
-    # failed again in 50+ runs on fresh boxes; every kernel of the step has since been shown bit-stable under poisoned scratch, guard
-    # bands and a competing process, so what is left is outside those kernels (gloo's host-staged collectives on
-    # device tensors, or two processes time-slicing one GPU) or needs a memory layout nobody has reproduced.  A divergence is therefore
-    # RECORDED with the step and parameter block it started in (gpurun_out/lockstep_divergence.json) and the pair is run once more: two
-    # divergences in a row fail the test, a single one is reported as a warning -- it must not take the 8(a) rows of the suite with it.
+    # This comparison failed in GPUTEST_r04 (3.4 M parameters apart after three steps, both ranks still in agreement) and then about once in
+    # twenty runs.  Round 5 found the cause outside the exchange: packed fp32 instructions of the scatter returning +0 in lanes 48..63
+    # while the OTHER rank's MFMA kernels ran on the same SIMD -- two processes on one GPU (scripts/dev/probe_pk_f32.hip).
+    # The library is now built without them (tests/test_build_hygiene.py) and the test passed 40 of 40 first attempts.  The record-and-repeat
+    # below stays as the instrument it was: a divergence is RECORDED with the step and parameter block it started in
+    # (gpurun_out/lockstep_divergence.json) and the pair is run once more; two divergences in a row fail the test, a single one is a warning.
     div = _lockstep_divergence(res)
     if div is not None:
         import json
