@@ -149,6 +149,8 @@ int main(int argc, char** argv) {
   const bool load = argc > 2 && (!strcmp(argv[2], "load") || !strcmp(argv[2], "mfma") || !strcmp(argv[2], "valu") || !strcmp(argv[2], "mfma16") ||
                                  !strcmp(argv[2], "trload") || !strcmp(argv[2], "gll"));
   const int src = argc > 2 && !load ? atoi(argv[2]) : 0;
+  const bool same_process = argc > 3 && !strcmp(argv[3], "same");   // ./probe_pk_f32 <seconds> <src> same: the v_mfma_f32_32x32x16_f16 neighbour
+                                                                    // runs on a second stream of THIS process instead of in another process
   const auto t0 = std::chrono::steady_clock::now();
   auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   if (load) {
@@ -179,7 +181,10 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(xs, h, n * sizeof(float), hipMemcpyHostToDevice);
   (void)hipMemset(counts, 0, NC * 4);
   long launches = 0;
+  hipStream_t sb = nullptr; float* nbuf = nullptr;
+  if (same_process) { (void)hipStreamCreateWithFlags(&sb, hipStreamNonBlocking); (void)hipMalloc(&nbuf, 1 << 20); }
   while (elapsed() < seconds) {
+    if (same_process) for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(k_mfma16, dim3(4096), dim3(256), 0, sb, nbuf, 2000);
     for (int k = 0; k < 50; ++k) {
       if (src == 0) hipLaunchKernelGGL(k_probe<0>, dim3(nblk), dim3(512), 0, 0, xs, counts, ev, 200);
       else if (src == 1) hipLaunchKernelGGL(k_probe<1>, dim3(nblk), dim3(512), 0, 0, xs, counts, ev, 200);
@@ -191,6 +196,7 @@ int main(int argc, char** argv) {
   }
   uint32_t* hc = (uint32_t*)malloc(NC * 4); Event he[64];
   (void)hipMemcpy(hc, counts, NC * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(he, ev, sizeof(he), hipMemcpyDeviceToHost);
+  if (same_process) printf("(neighbour: v_mfma_f32_32x32x16_f16 kernels on a second stream of this process)\n");
   printf("probe_pk_f32 (factor source %d): %ld launches x %d blocks x 512 lanes x 200 x 8 products: %u packed products differ from the scalar ones (%.3g of all)\n",
          src, launches, nblk, hc[0], hc[0] / (double(launches) * nblk * 512 * 200 * 8));
   if (hc[0]) {
