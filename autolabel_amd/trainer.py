@@ -73,8 +73,9 @@ class Trainer:
                  local_rank=0, world_size=1, device=None, mute=False, fp16=False, eval_interval=1, max_keep_ckpt=2,
                  workspace='workspace', best_mode='min', use_loss_as_metric=True, report_metric_at_train=False,
                  use_checkpoint='latest', use_tensorboardX=False, scheduler_update_every_step=False, fused=None,
-                 process_group=None, use_graph=True, device_data='auto', use_graph_dp=False, shard_optimizer=False):
+                 process_group=None, use_graph=True, device_data='auto', use_graph_dp=False, shard_optimizer=False, dp_level_group=4):
         self.name, self.opt, self.mute, self.metrics = name, opt, mute, metrics
+        self.dp_level_group = int(dp_level_group)   # data parallel: hash-grid levels per scatter launch / gradient bucket (TrainEngine.level_groups)
         self.local_rank, self.world_size, self.workspace = local_rank, world_size, workspace
         self.ema_decay, self.fp16, self.best_mode = ema_decay, fp16, best_mode
         self.use_loss_as_metric, self.report_metric_at_train = use_loss_as_metric, report_metric_at_train
@@ -149,7 +150,7 @@ class Trainer:
                                       feature_loss=getattr(opt, 'feature_loss', False),
                                       num_steps=getattr(opt, 'num_steps', self.model.num_steps_default),
                                       upsample_steps=getattr(opt, 'upsample_steps', self.model.upsample_steps_default),
-                                      process_group=self.process_group, shard_optimizer=self.shard_optimizer,
+                                      process_group=self.process_group, shard_optimizer=self.shard_optimizer, level_group=self.dp_level_group,
                                       shard_gather='master' if self.ema is not None else 'table')   # (the EMA reads the fp32 masters every step)
             if old is not None:   # same parameters on a new buffer: the Adam moments / loss scale / step counters carry over
                 self.engine.load_state_dict(old.state_dict())

@@ -38,6 +38,8 @@ def read_args():
     parser.add_argument('--device-data', action='store_true', help='(default whenever the frames fit in HBM; kept for older command lines)')
     parser.add_argument('--host-data', action='store_true', help="the reference's host DataLoader instead of device-resident frames")
     parser.add_argument('--shard-optimizer', action='store_true', help='data parallel: every rank runs Adam on 1 / world of the hash table (reduce-scatter + all-gather)')
+    parser.add_argument('--dp-level-group', type=int, default=4, help='data parallel: hash-grid levels per gradient bucket of the overlapped exchange '
+                        '(4 = five buckets, 8 = three: less scatter time, a larger last bucket with nothing to hide behind)')
     parser.add_argument('--dp-graph', action='store_true', help='data parallel: capture the step with its RCCL collectives into a hipGraph')
     parser.add_argument('--global-batch', type=int, default=0, help='data parallel: fixed global batch (overrides --batch-size)')
     parser.add_argument('--cuda-ray', action='store_true', help='occupancy-grid marching (the reference hard-codes cuda_ray=False)')
@@ -88,7 +90,7 @@ def main():
                             fp16=True, ema_decay=0.95, lr_scheduler=scheduler, scheduler_update_every_step=False, metrics=[],
                             use_checkpoint='latest', local_rank=rank, world_size=world, process_group=pg,
                             device_data=False if flags.host_data else ('auto' if not flags.device_data else True), use_graph_dp=flags.dp_graph,
-                            shard_optimizer=flags.shard_optimizer)
+                            shard_optimizer=flags.shard_optimizer, dp_level_group=flags.dp_level_group)
     if world > 1:   # replicas start identical (a resumed checkpoint is read by every rank; the broadcast also covers a fresh init)
         parallel.broadcast_parameters(model._ensure_device().P.flat, pg)
         model._shadow_version = None
