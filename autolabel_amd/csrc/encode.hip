@@ -414,8 +414,10 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
 // HBM traffic: 8 B written + 8 B read per record (<= 8 x 16 records per sample) instead of 4 atomic requests per (sample, level).
 #ifndef BIN_TILE
 #define BIN_TILE 512            // sample rows per phase-1 block (= threads: lane = sample, so runs along a ray dedupe in-wave); -DBIN_TILE=1024
-                                // (1 KB runs for phase 2) measured: dense pair 771 -> 806 us, marching 265 -> 260 us: no gain
+                                // (1 KB runs for phase 2) measured: round 3 dense pair 771 -> 806 us, round 5 620 -> 607 us (step -0.3 %): no gain
+                                // worth the format change it needs -- a full 1024-row tile has 8192 records, one more than DESC_START holds
 #endif
+static_assert(BIN_TILE * 8 <= 0x1FFF, "a tile's record count (the start of a trailing empty slice) must fit the 13-bit start field of the descriptors");
 // descriptor word: start (13 bits) | count << 13 (14 bits) | (shift + BIN_SHIFT_BIAS) << 27
 #define DESC_START(q) ((q) & 0x1FFFu)
 #define DESC_COUNT(q) (((q) >> 13) & 0x3FFFu)
