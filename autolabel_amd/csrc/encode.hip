@@ -861,8 +861,9 @@ extern "C" int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t r
 static int binned_launch(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
                          const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
                          const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
-                         int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* wire_f16, float wire_mul, void* stream) {
+                         int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* wire_f16, float wire_mul, int phases, void* stream) {
   BinParams b;
+  ALN_REQUIRE(phases >= 1 && phases <= 3 && (phases == 3 || !adam), "encode_bwd_binned: phases must be 1 (records), 2 (accumulate) or 3 (both)");
   if (int rc = fill_params(b.p, e, nullptr, rays_o, rays_d, z, xyz, rows, stride1)) return rc;
   // (with `adam` the caller's aln_adam_step(skip_grid = 1) advances the table's step counter: an empty launch must not pass for a step)
   ALN_REQUIRE(!adam || (rows > 0 && e->use_grid && level_lo < level_hi), "encode_bwd_binned: the fused optimizer step needs rows and levels; "
@@ -871,14 +872,14 @@ static int binned_launch(const AlnEncDesc* e, const float* rays_o, const float* 
   ALN_REQUIRE(0 <= level_lo && level_lo <= level_hi && level_hi <= (int)e->grid.n_levels, "encode_bwd_binned: level range [%d, %d)",
               level_lo, level_hi);
   if (rows == 0) {   // nothing to scatter: an fp32 table keeps its zeros, the wire payload of these levels has to be written as zeros
-    if (wire_f16 && level_lo < level_hi) {
+    if (wire_f16 && level_lo < level_hi && (phases & 2)) {
       const size_t lo = 2 * (size_t)e->grid.offset[level_lo];
       const size_t hi = level_hi < (int)e->grid.n_levels ? 2 * (size_t)e->grid.offset[level_hi] : 2 * ((size_t)e->grid.offset[level_hi - 1] + e->grid.size[level_hi - 1]);
       ALN_REQUIRE(hipMemsetAsync((h16*)wire_f16 + lo, 0, (hi - lo) * sizeof(h16), (hipStream_t)stream) == hipSuccess, "encode_bwd_binned: memset of the wire buffer failed");
     }
     return 0;
   }
-  ALN_REQUIRE(d_enc && (grad_table || adam || wire_f16) && ws, "encode_bwd_binned: NULL pointer");
+  ALN_REQUIRE(d_enc && (phases == 1 || grad_table || adam || wire_f16) && ws, "encode_bwd_binned: NULL pointer");
   ALN_REQUIRE(!wire_f16 || (!adam && ((uintptr_t)wire_f16 & 3) == 0 && e->grid.n_features == 2), "encode_bwd_binned: the fp16 wire output excludes the fused "
               "optimizer and needs a 4-byte aligned buffer");
   ALN_REQUIRE(!adam || (adam->params && adam->m && adam->v && adam->table_f16 && adam->state_i && adam->state_f && e->grid.n_features == 2),
@@ -898,8 +899,11 @@ static int binned_launch(const AlnEncDesc* e, const float* rays_o, const float* 
   b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * BIN_CHUNK * sizeof(uint2));
   AccParams a;
   for (int l = 0; l < ALN_MAX_LEVELS; ++l) b.slice_log2[l] = a.slice_log2[l] = (uint8_t)(l < nl ? bin_slice_log2(e->grid.size[l]) : 0);
-  hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
-  ALN_CHECK_LAUNCH("encode_bwd_bin");
+  if (phases & 1) {
+    hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
+    ALN_CHECK_LAUNCH("encode_bwd_bin");
+  }
+  if (!(phases & 2)) return 0;
   a.pool = b.pool; a.desc = b.desc; a.grad = grad_table; a.found_inf = found_inf; a.ntiles = ntiles;
   a.wire = (h16*)wire_f16; a.wire_mul = wire_mul;
   a.ad = AccAdam{};
@@ -930,7 +934,7 @@ extern "C" int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, c
                                      const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
                                      int32_t level_hi, int32_t* found_inf, const AlnAdamFuse* adam, void* stream) {
   return binned_launch(e, rays_o, rays_d, z, xyz, rows, rows_pass1, stride1, stride2, perm, d_enc, grad_table, ws, level_lo, level_hi, found_inf,
-                       adam, nullptr, 0.f, stream);
+                       adam, nullptr, 0.f, 3, stream);
 }
 // The same scatter with the gradient of levels [level_lo, level_hi) leaving as the fp16 PAYLOAD of the data-parallel exchange:
 // wire_f16[2 * (offset[l] + entry) + feature] = fp16(float(sum) * wire_mul) for EVERY entry of those levels (zeros included) -- bit for bit
@@ -942,7 +946,19 @@ extern "C" int aln_encode_bwd_binned_wire(const AlnEncDesc* e, const float* rays
                                           int32_t* found_inf, void* wire_f16, float wire_mul, void* stream) {
   ALN_REQUIRE(wire_f16, "encode_bwd_binned_wire: NULL wire buffer");
   return binned_launch(e, rays_o, rays_d, z, xyz, rows, rows_pass1, stride1, stride2, perm, d_enc, nullptr, ws, level_lo, level_hi, found_inf,
-                       nullptr, wire_f16, wire_mul, stream);
+                       nullptr, wire_f16, wire_mul, 3, stream);
+}
+// The two phases on their own (the overlapped data-parallel exchange: phase 1 ONCE for all levels -- one launch instead of one per bucket,
+// 270 instead of 348 us at the bench's batch -- then phase 2 bucket by bucket, each bucket's exchange starting behind its own launch).
+// phases = 1: records of levels [level_lo, level_hi) into ws (grad_table / wire_f16 unused); phases = 2: accumulate those levels from
+// ws into grad_table (added) or, with wire_f16, into the fp16 payload; phases = 3: both, as aln_encode_bwd_binned / _wire.  The same
+// kernels on the same records: results are bit-identical however the levels are grouped.
+extern "C" int aln_encode_bwd_binned_phase(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
+                                           const float* xyz, int32_t rows, int32_t rows_pass1, int32_t stride1, int32_t stride2,
+                                           const uint16_t* perm, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
+                                           int32_t level_hi, int32_t* found_inf, void* wire_f16, float wire_mul, int32_t phases, void* stream) {
+  return binned_launch(e, rays_o, rays_d, z, xyz, rows, rows_pass1, stride1, stride2, perm, d_enc, grad_table, ws, level_lo, level_hi, found_inf,
+                       nullptr, wire_f16, wire_mul, phases, stream);
 }
 
 extern "C" int aln_grid_desc_init(AlnGridDesc* g) {

@@ -178,8 +178,8 @@ class TrainEngine:
     def level_groups(self):
         """Hash-grid levels in scatter order, the groups whose gradient is exchanged while the next group is scattered: the fine levels
         first in groups of ``level_group`` (default 4 -- one level per wave of the scatter kernel), the small coarse levels last, so the
-        only all-reduce nothing can hide is the smallest.  Every launch pair beyond the first costs ~30 us of scatter time (world-of-one
-        RCCL legs of bench.py: groups of 4 = five buckets 1.98 ms, groups of 8 = three buckets 1.93, one group 1.90): groups of 4 hide
+        only all-reduce nothing can hide is the smallest.  Phase 1 of the scatter runs once for all levels; every phase-2 launch beyond the
+        first costs ~15 us (world-of-one RCCL legs of bench.py: groups of 4 = five buckets 1.93 ms, groups of 8 = three buckets 1.90): groups of 4 hide
         8.4 MB buckets behind ~150 us of scatter each and expose 1.4 MB; groups of 8 expose the 11 MB of levels 0-7.  Which wins depends on
         what the links deliver, so `bench.py --gpus N` times both (dp_overlap, dp_overlap_g8)."""
         n = int(self.L.enc.grid.n_levels) if self.L.n_grid else 0

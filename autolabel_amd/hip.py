@@ -67,6 +67,7 @@ _SIGS = {
     'aln_encode_bwd_binned_tile_rows': (i32, []),
     'aln_encode_bwd_binned': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'aln_encode_bwd_binned_wire': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp, f32, vp]),
+    'aln_encode_bwd_binned_phase': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, f32, i32, vp]),
     'aln_wide_nt': (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp]),
     'aln_wide_tn_ws_bytes': (i64, [i32, i32, i32]),
     'aln_wide_tn': (i32, [vp, i32, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]),

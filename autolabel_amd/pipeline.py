@@ -781,9 +781,19 @@ class HipPipeline:
         nl = int(e.grid.n_levels)
         bins = ws.scratch('enc_bwd_bins', H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M))
         F = int(e.grid.n_features)
+        flag = H.ptr(scatter_flag) if scatter_flag is not None else fi
+        split = level_groups is not None and len(level_groups) > 1 and grid_adam is None
+        if split:   # phase 1 ONCE for every level of the groups (one launch instead of one per group), phase 2 group by group below
+            self._k('aln_encode_bwd_binned_phase', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
+                    H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), None, H.ptr(bins), min(lo for lo, _ in level_groups), max(hi for _, hi in level_groups),
+                    flag, None, 0.0, 1, H.stream(), tag=(M, nl))
         for lo, hi in (level_groups or [(0, nl)]):
             # (two passes: the tiles walk every ray in depth order, so coarse and fine samples of one cell dedupe into one record)
-            if grid_wire is not None:
+            if split:
+                self._k('aln_encode_bwd_binned_phase', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
+                        H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(P.grad) if grid_wire is None else None, H.ptr(bins), lo, hi, flag,
+                        H.ptr(grid_wire), float(wire_mul), 2, H.stream(), tag=(M, hi - lo))
+            elif grid_wire is not None:
                 assert grid_adam is None and grid_wire.dtype == torch.float16 and grid_wire.numel() >= L.n_grid
                 self._k('aln_encode_bwd_binned_wire', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, max(S2, 1),
                         H.ptr(c['perm']) if S2 > 0 else None, H.ptr(d_enc), H.ptr(bins), lo, hi, H.ptr(scatter_flag) if scatter_flag is not None else fi,

@@ -182,6 +182,13 @@ int aln_encode_bwd_binned_wire(const AlnEncDesc* e, const float* rays_o, const f
                                int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2,
                                const uint16_t* depth_order, const void* d_enc, void* ws, int32_t level_lo, int32_t level_hi,
                                int32_t* found_inf, void* wire_f16 /* fp16 [2 * table entries] */, float wire_mul /* 1 / world */, void* stream);
+/* The two phases of the scatter on their own, for the overlapped exchange: phases = 1 writes the records of levels [level_lo, level_hi)
+ * into ws (one launch for all levels), phases = 2 accumulates a level range from ws into grad_table (added) or, with wire_f16 != NULL, into
+ * the fp16 payload; phases = 3 = aln_encode_bwd_binned / _wire.  Bit-identical results however the levels are grouped (ABI 7). */
+int aln_encode_bwd_binned_phase(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
+                                int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2,
+                                const uint16_t* depth_order, const void* d_enc, float* grad_table, void* ws, int32_t level_lo,
+                                int32_t level_hi, int32_t* found_inf, void* wire_f16, float wire_mul, int32_t phases, void* stream);
 
 /* ---- MLPs: tcnn Network{FullyFusedMLP,CutlassMLP}, autolabel/models.py:84-136 */
 int aln_mlp_repack(const float* w_master, int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden,

@@ -454,6 +454,18 @@ def test_binned_encode_backward_writes_the_fp16_wire_payload_itself(H):
         call(M, 0, 4)
         torch.cuda.synchronize()
         assert torch.equal(wire.view(torch.int16), want.view(torch.int16))
+    # the phases on their own (overlapped exchange: records of ALL levels in one launch, then the accumulation bucket by bucket), into the
+    # payload and into an fp32 table: the same bits as the single launches
+    phase = lambda lo, hi, ph, table, w: H.call('aln_encode_bwd_binned_phase', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, S2, None,
+                                                H.ptr(d_enc), H.ptr(table), H.ptr(ws), lo, hi, H.ptr(flag), H.ptr(w), mul, ph, H.stream())
+    wire.fill_(7.0)
+    split = torch.zeros(n, device='cuda')
+    phase(0, nl, 1, None, None)
+    for lo, hi in ((8, 16), (0, 8)):
+        phase(lo, hi, 2, None, wire)
+        phase(lo, hi, 2, split, None)
+    torch.cuda.synchronize()
+    assert torch.equal(wire.view(torch.int16), want.view(torch.int16)) and torch.equal(split, grad) and flag.item() == 0
     # no rows: the payload of the launched levels is zero (an fp32 table would simply have kept its zeros)
     wire.fill_(7.0)
     H.call('aln_encode_bwd_binned_wire', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, 0, 0, S1, S2, None, H.ptr(d_enc), H.ptr(ws), 8, 12,
