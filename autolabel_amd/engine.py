@@ -96,6 +96,8 @@ class TrainEngine:
         if self.march:
             self.S1, self.S2 = pipe.occ.samples, 0
         self._calls = 0
+        if self._wire_direct():
+            self._wire_full()      # (allocated here, not inside a step that may be the one a hipGraph capture records)
 
     @property
     def lr(self):
