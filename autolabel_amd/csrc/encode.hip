@@ -463,23 +463,41 @@ __device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
   aln_sample_xyz(p.rays_o + 3 * (size_t)ray, p.rays_d + 3 * (size_t)ray, p.z[row], p.e.bound, x);
 }
 
-#ifdef BIN_DEBUG
-// Development taps of phase 1 for scripts/dev/stress_scatter.py (a library built with -DBIN_DEBUG=5 or 6; never the shipped one):
-//   5: [level][tile position][16] the eight record values of every row + scale, slots, row -- the map that traces a wrong record of a
-//      failing replay back to its (tile, wave, lane, corner);   6: one 100 MHz timestamp per (level, tile, wave).
-// They are how the run-to-run differences under a second process were pinned on packed fp32 instructions (build.py).
-__device__ uint32_t* g_bin_dbg = nullptr;
-extern "C" int aln_debug_set_bin_dbg(void* ptr) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bin_dbg), &ptr, sizeof(ptr)); }
-#endif
+// (round 5's value / timestamp taps for scripts/dev/stress_scatter.py --map-lib / --times -- -DBIN_DEBUG=5 / 6 builds -- are in the history of this file:
+//  commit 74cae74)
 __device__ inline uint32_t bin_pack_h2(float a, float b) {
   h16x2 h; h[0] = (h16)a; h[1] = (h16)b;
   return *(const uint32_t*)&h;
 }
+#ifdef BIN_TIMING   // dev builds only (scripts/dev/bench_scatter.py --timing): shader-clock ticks per section of phase 1, block BIN_TIMING_BLOCK, waves 0 and 7
+__device__ long long g_bin_t[2][12];
+extern "C" int aln_debug_read_bin_timing(long long* host_out, int reset) {
+  if (reset) { long long z[24] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bin_t), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bin_t), sizeof(long long) * 24);
+}
+#define BT_DECL long long bt_acc[12] = {0}; long long bt_last = clock64();
+#define BT(i) { long long bt_now = clock64(); bt_acc[i] += bt_now - bt_last; bt_last = bt_now; }
+#define BT_FLUSH if (blockIdx.x == 300 && (tid == 0 || tid == 448)) { for (int i = 0; i < 12; ++i) g_bin_t[tid != 0][i] += bt_acc[i]; }
+#else
+#define BT_DECL
+#define BT(i)
+#define BT_FLUSH
+#endif
+// inclusive prefix sum over the 64 lanes of a wave through the DPP network: shifts inside the rows of 16, then the row broadcasts
+__device__ inline uint32_t wave_incl_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);    // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+  return x;
+}
 typedef uint32_t rec_pair __attribute__((ext_vector_type(4), aligned(8)));   // two 8-byte records at an 8-byte aligned LDS address
-__global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
+__global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_encode_bwd_bin(BinParams b) {   // (three blocks per CU: 80 registers)
   __shared__ uint2 sorted[BIN_CHUNK];                        // 32 KB
   __shared__ uint32_t gws[8][BIN_TILE];                      // 16 KB: the rows' gradient words of eight levels (column = thread)
-  __shared__ uint32_t cnt[2][BIN_MAX_SLICES], base[BIN_MAX_SLICES], total_s, vmax_s[2], shift_s;
+  __shared__ uint32_t cnt[2][BIN_MAX_SLICES], base_w[BIN_TILE / 64][BIN_MAX_SLICES], vmax_s[2];
   const EncParams& p = b.p;
   const int tid = threadIdx.x, lane = tid & 63;
   const int tile = blockIdx.x;
@@ -503,42 +521,77 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
   normalize_pos(x, p.e.bound, true, xn);
   const uint32_t* const grow = (const uint32_t*)(b.d_enc + (size_t)(valid ? row : 0) * pad + fdim);
   const bool al8 = (fdim * 2) % 8 == 0 && (pad * 2) % 8 == 0;   // 8-byte loads when the grid part starts 8-byte aligned in every row
+  // every load is requested before the first is parked (hipcc would otherwise wait for each one in turn), and -- round 6 -- the words of
+  // levels l .. l + 7 are requested one level EARLY, after the sorted stores of level l - 1, so that their trip to HBM (8 000 ticks
+  // per eight levels at the top of the level: 7 % of the kernel in the section clocks of a -DBIN_TIMING build) hides behind the stores,
+  // the barrier and the copy-out; the eight registers are live where the sixteen products are not
+  uint2 w2[4];
+  auto fetch_gw = [&](int l) __attribute__((always_inline)) {
+    const int nw = min(8, p.level_hi - l);
+    if (al8 && (l & 1) == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        w2[j >> 1] = make_uint2(0u, 0u);
+        if (valid && j + 1 < nw) w2[j >> 1] = *(const uint2*)(grow + l + j);
+        else if (valid && j < nw) w2[j >> 1].x = grow[l + j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        w2[j >> 1].x = (valid && j < nw) ? grow[l + j] : 0u;
+        w2[j >> 1].y = (valid && j + 1 < nw) ? grow[l + j + 1] : 0u;
+      }
+    }
+  };
+  fetch_gw(p.level_lo);
   __syncthreads();
+  BT_DECL
+  // The sorted tile of level l leaves for the record pool in BIN_TILE * 8 / 2 / BIN_TILE = 4 pieces of 16 bytes per thread, SPREAD OVER THE
+  // ARITHMETIC OF LEVEL l + 1 (round 6).  As one burst behind the last barrier of its level -- every block of the chip at about the
+  // same time -- the 743 MB of records cost the kernel 130 us of its 315 (stub: no copy-out, 185 us): the memory pipe idles while
+  // the waves compute and the waves stall on full store queues while it drains.  `sorted` is not written again before the first barrier
+  // of level l + 1, which no wave reaches before its last piece has been read.
+  uint32_t cp_n = 0u;          // 16-byte pieces of the level whose copy-out is pending
+  uint4* cp_dst = nullptr;
+  auto copy_piece = [&](int i) __attribute__((always_inline)) {
+    const uint32_t j = (uint32_t)tid + (uint32_t)i * BIN_TILE;
+#if defined(STUB_COPY)          // dev stubs: no copy-out at all / LDS reads without stores / stores without LDS reads
+    (void)j;
+#elif defined(STUB_COPY_NOSTORE)
+    if (j < cp_n) { const uint4 q = ((const uint4*)sorted)[j]; if (q.x == 0xdeadbeefu && q.y == 0x12345678u) cp_dst[j] = q; }
+#elif defined(STUB_COPY_NOLDS)
+    if (j < cp_n) cp_dst[j] = make_uint4(j, tid, i, 0u);
+#else
+    if (j < cp_n) cp_dst[j] = ((const uint4*)sorted)[j];
+#endif
+  };
   for (int l = p.level_lo; l < p.level_hi; ++l) {
+    BT(0)
     const int par = l & 1;
     const uint32_t sl = b.slice_log2[l], slot_mask = (1u << sl) - 1u;
     const int k8 = (l - p.level_lo) & 7;
-    if (k8 == 0) {   // words of levels l .. l + 7 -> this thread's column (nobody else touches it: no barrier)
-      // every load is requested before the first is parked (hipcc would otherwise wait for each one in turn: four to eight
-      // global-load latencies in a row at the top of every eighth level)
-      const int nw = min(8, p.level_hi - l);
-      uint32_t wv[8];
-      if (al8 && (l & 1) == 0) {
-        uint2 w2[4];
+    if (k8 == 0) {   // words of levels l .. l + 7 (requested a level ago: fetch_gw) -> this thread's column (nobody else touches it: no barrier)
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          w2[j >> 1] = make_uint2(0u, 0u);
-          if (valid && j + 1 < nw) w2[j >> 1] = *(const uint2*)(grow + l + j);
-          else if (valid && j < nw) w2[j >> 1].x = grow[l + j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) { wv[j] = w2[j >> 1].x; wv[j + 1] = w2[j >> 1].y; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wv[j] = (valid && j < nw) ? grow[l + j] : 0u;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gws[j][tid] = wv[j];
+      for (int j = 0; j < 8; j += 2) { gws[j][tid] = w2[j >> 1].x; gws[j + 1][tid] = w2[j >> 1].y; }
     }
+    BT(1)
+    copy_piece(0);
     const uint32_t gw = gws[k8][tid];
     const h16x2 g = *(const h16x2*)&gw;
     const float g0 = (float)g[0], g1 = (float)g[1];
     uint32_t idx[8]; float w[8]; uint32_t cell[3];
+#ifdef STUB_COMPUTE   // dev stub: no corner arithmetic (cheap fake indices / weights)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { idx[c] = ((uint32_t)tid * 2654435761u + (uint32_t)(c >> 1) * 40503u + (uint32_t)l * 977u + (c & 1)) & (p.e.grid.size[l] - 1u); w[c] = 0.125f; }
+    cell[0] = tid; cell[1] = l; cell[2] = 0;
+#else
     if (p.e.grid.dense[l]) grid_corners<1>(p.e.grid, l, xn, idx, w, cell);   // one wave-uniform branch per level, not one per corner
     else grid_corners<0>(p.e.grid, l, xn, idx, w, cell);
+#endif
     // run-dedupe along the ray: adjacent lanes in the same cell are summed into the run head
     // (levels from BIN_DEDUPE_LEVELS on skip it: at 4096 cells per axis and beyond consecutive samples practically never share
     //  a cell -- 8.1-8.3 of 8.4 M records survive -- so the compare / ballot / ladder step costs more than the records it saves)
+    copy_piece(1);
     const bool dd = l < BIN_DEDUPE_LEVELS;
     uint32_t q0 = cell[0], q1 = cell[1], q2 = cell[2];
     if (dd) { q0 = __shfl_up(cell[0], 1); q1 = __shfl_up(cell[1], 1); q2 = __shfl_up(cell[2], 1); }
@@ -548,6 +601,7 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     float v[16];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { v[2 * c] = w[c] * g0; v[2 * c + 1] = w[c] * g1; }
+    copy_piece(2);
     if (__popcll(hm) < 64) {
       // runs are contiguous: once no lane finds a run mate at distance `off`, none exists further away (most fine levels
       // leave after one step; the full ladder is 6 x 16 shuffles)
@@ -566,38 +620,43 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
     // the producer of d_enc has raised found_inf before this kernel started (what lets phase 2 apply the optimizer itself).
     // (the largest magnitude as a bit pattern: non-negative floats order like their patterns, and a NaN -- which fmaxf would
     //  silently drop -- sorts above infinity)
+    copy_piece(3);
     uint32_t umax = 0u;
+#ifdef STUB_UMAX   // dev stub: no maximum over the products, no wave fold
+    umax = __float_as_uint(v[0]) & 0x7fffffffu;
+#else
 #pragma unroll
     for (int k = 0; k < 16; ++k) umax = max(umax, __float_as_uint(v[k]) & 0x7fffffffu);
+#endif
     // A non-finite run raises the flag HERE, in phase 1: every block of phase 2 then reads a final found_inf before it applies the
     // optimizer to its slice (no partly stepped table), whoever produced d_enc.
     if (head && umax >= 0x7f800000u && b.found_inf) *b.found_inf = 1;
     const bool emit = head && umax != 0u && umax <= 0x7f800000u;     // (a NaN run is dropped; the step is skipped anyway)
-#ifdef BIN_DEBUG
-#if BIN_DEBUG == 6
-    if (g_bin_dbg && lane == 0) {   // one 100 MHz timestamp per (level, tile, wave): a wave that was switched out shows a gap
-      const unsigned long long t = wall_clock64();
-      uint32_t* o = g_bin_dbg + (((size_t)l * b.ntiles + tile) * 8 + (tid >> 6)) * 2;
-      o[0] = (uint32_t)t; o[1] = (uint32_t)(t >> 32);
-    }
-#endif
-#endif
     // Ranks within the slices.  The two x-neighbour corners of a cell (c, c + 1) almost always fall into the same slice (their
     // indices differ in the lowest bits: +1 in a dense level, ^1 for even x in a hashed one), so a PAIR takes one returning
     // atomic (+2) and, below, one 16-byte store.  (Measured: 325 -> 321 us only.  Stubbing out the atomics, the sorted stores or
     // the copy-out alone saves 114 / 125 / 96 us of 325, all three together 131: the three LDS phases are not additive costs but
     // alternatives on one critical path -- barrier to barrier -- and halving the operations of two of them moves little.)
+    BT(2)
     uint32_t rk[8];
     {
       // the tile's largest magnitude: folded over the wave with shuffles, ONE LDS atomic per wave.  (atomicMax from every lane is
       // rewritten by hipcc's atomic optimizer into a scalar loop over the active lanes -- ~6 scalar instructions per lane, 370 per
       // wave and level: half of this kernel's instruction stream, profiles/r03_pmc_sq_summary.json)
       uint32_t wm = emit ? umax : 0u;
+#ifndef STUB_UMAX
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, o));
+#endif
       if (lane == 0 && wm) atomicMax(&vmax_s[par], wm);
     }
+#ifdef STUB_ATOM   // dev stub: no ranking atomics
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rk[c] = (uint32_t)(tid * 8 + c) & 63u;
+    if (false) {
+#else
     if (emit) {
+#endif
       // the four pair atomics go out back to back (no branch between them: one LDS round trip for all four instead of one each);
       // the rare second atomic of a pair that straddles two slices follows in its own pass
 #pragma unroll
@@ -612,51 +671,57 @@ __global__ __launch_bounds__(BIN_TILE) void k_encode_bwd_bin(BinParams b) {
         if (s0 != s1) rk[c + 1] = atomicAdd(&cnt[par][s1], 1u);
       }
     }
+    BT(3)
     __syncthreads();
-    if (tid < 64) {   // exclusive prefix over the slice counters; descriptors; reset the counters for level l + 2
-      const uint32_t n = cnt[par][lane], np = n;
-      uint32_t inc = np;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
-      base[lane] = inc - np;
-      cnt[par][lane] = 0;
-      const int ex = (int)((vmax_s[par] >> 23) & 0xFFu) - 127;          // floor(log2(max)); inf / huge -> large -> shift 0
-      const int sh = min(max(14 - ex, BIN_MIN_SHIFT), BIN_MAX_SHIFT);
-      if (lane == 63) { total_s = inc; shift_s = (uint32_t)(sh + BIN_SHIFT_BIAS); }
-      b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - np) | (n << 13) | ((uint32_t)(sh + BIN_SHIFT_BIAS) << 27);
-    }
-    __syncthreads();
-    if (tid == 0) vmax_s[par] = 0u;    // next use: level l + 2, two barriers away from any reader
+    BT(4)
+    // Exclusive prefix over the slice counters, by EVERY wave for itself: one LDS read, six DPP adds (row shifts + the two row
+    // broadcasts: vector-ALU speed), the bases parked in a wave-private LDS row for the per-corner lookups below.  Round 5 had wave 0
+    // scan through six dependent ds_bpermute round trips (~1 000 ticks) with the other seven waves waiting at a second barrier.
+    const uint32_t n_sl = cnt[par][lane];
+    const uint32_t inc = wave_incl_scan(n_sl);
+    base_w[tid >> 6][lane] = inc - n_sl;
+    const uint32_t total_w = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    const int ex_t = (int)((vmax_s[par] >> 23) & 0xFFu) - 127;          // floor(log2(max)); inf / huge -> large -> shift 0
+    const int sh = min(max(14 - ex_t, BIN_MIN_SHIFT), BIN_MAX_SHIFT);
+#ifndef STUB_DESC
+    if (tid < 64) b.desc[((size_t)l * BIN_MAX_SLICES + lane) * b.ntiles + tile] = (inc - n_sl) | (n_sl << 13) | ((uint32_t)(sh + BIN_SHIFT_BIAS) << 27);
+#endif
+    BT(5)
+    BT(6)
+#ifdef STUB_STORE
+    if (emit && v[0] == 12345.f) {
+#else
     if (emit) {
-      const float sc = __uint_as_float((uint32_t)(127 - BIN_SHIFT_BIAS + shift_s) << 23);   // 2^shift
+#endif
+      const float sc = __uint_as_float((uint32_t)(127 + sh) << 23);   // 2^shift
+      const uint32_t* const bw = base_w[tid >> 6];
       uint32_t b0[4];
 #pragma unroll
-      for (int c = 0; c < 8; c += 2) b0[c >> 1] = base[idx[c] >> sl];     // (all four slice bases requested before the first store)
+      for (int c = 0; c < 8; c += 2) b0[c >> 1] = bw[idx[c] >> sl];     // (all four slice bases requested before the first store)
 #pragma unroll
       for (int c = 0; c < 8; c += 2) {
         const uint32_t hw0 = bin_pack_h2(v[2 * c] * sc, v[2 * c + 1] * sc), hw1 = bin_pack_h2(v[2 * c + 2] * sc, v[2 * c + 3] * sc);
         const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
         const uint2 r0 = make_uint2(idx[c] & slot_mask, hw0), r1 = make_uint2(idx[c + 1] & slot_mask, hw1);
-#if defined(BIN_DEBUG) && BIN_DEBUG == 5
-        if (g_bin_dbg) {
-          uint32_t* o = g_bin_dbg + ((size_t)l * p.rows + row0 + tid) * 16;
-          o[c] = r0.y; o[c + 1] = r1.y;
-          if (c == 0) { o[8] = __float_as_uint(sc); o[9] = shift_s; o[10] = __float_as_uint(v[1]); o[11] = __float_as_uint(v[3]); o[12] = r0.x; o[13] = r1.x;
-                        o[14] = base[s0] + rk[0]; o[15] = (uint32_t)row; }
-        }
-#endif
         uint2* const d0 = sorted + b0[c >> 1] + rk[c];
         if (s0 == s1) *(rec_pair*)d0 = rec_pair{r0.x, r0.y, r1.x, r1.y};      // adjacent slots: one two-record store (ds_write2_b64)
-        else { d0[0] = r0; sorted[base[s1] + rk[c + 1]] = r1; }
+        else { d0[0] = r0; sorted[bw[s1] + rk[c + 1]] = r1; }
       }
     }
+    if (k8 == 7 && l + 1 < p.level_hi) fetch_gw(l + 1);   // (behind the stores: the sixteen products are dead, the eight words fit the 80-register budget of three blocks per CU)
+    BT(7)
     __syncthreads();
-    const uint32_t total = min(total_s, (uint32_t)BIN_CHUNK);
-    uint4* dst = (uint4*)(b.pool + ((size_t)l * b.ntiles + tile) * BIN_CHUNK);
-    const uint4* src = (const uint4*)sorted;
-    for (uint32_t i = tid; i < (total + 1) / 2; i += BIN_TILE) dst[i] = src[i];
-    // (no barrier: the next level's writes to `sorted` come after two more barriers)
+    BT(8)
+    // (counters and maximum of this parity: next touched by the atomics of level l + 2, two barriers from here)
+    if (tid < BIN_MAX_SLICES) cnt[par][tid] = 0;
+    if (tid == 0) vmax_s[par] = 0u;
+    cp_n = (min(total_w, (uint32_t)BIN_CHUNK) + 1u) / 2u;
+    cp_dst = (uint4*)(b.pool + ((size_t)l * b.ntiles + tile) * BIN_CHUNK);
+    BT(9)
   }
+#pragma unroll
+  for (int i = 0; i < BIN_CHUNK / 2 / BIN_TILE; ++i) copy_piece(i);   // the last level's tile
+  BT_FLUSH
 }
 
 // Optimizer fused into phase 2 (single-GPU training): the block that owns a slice holds its exact gradient sums in LDS, so it
@@ -690,9 +755,29 @@ __device__ inline long long fx_from_half_d(h16 h, int e) {
 }
 #define FX_UNIT_LOG2 (24 + BIN_MAX_SHIFT)   // 35
 
+#ifdef ACC_TIMING   // dev builds only: shader-clock ticks per section of phase 2, block ACC_TIMING_BLOCK, waves 0 and 15
+__device__ long long g_acc_t[2][12];
+extern "C" int aln_debug_read_acc_timing(long long* host_out, int reset) {
+  if (reset) { long long z[24] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_acc_t), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_acc_t), sizeof(long long) * 24);
+}
+#ifndef ACC_TIMING_BLOCK
+#define ACC_TIMING_BLOCK 700
+#endif
+#define AT_DECL long long at_acc[12] = {0}; long long at_last = clock64();
+#define AT(i) { long long at_now = clock64(); at_acc[i] += at_now - at_last; at_last = at_now; }
+#define AT_FLUSH if (blockIdx.x == ACC_TIMING_BLOCK && (tid == 0 || tid == 960)) { for (int i = 0; i < 12; ++i) g_acc_t[tid != 0][i] += at_acc[i]; }
+#else
+#define AT_DECL
+#define AT(i)
+#define AT_FLUSH
+#endif
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
 #define ACC_THREADS 1024
 #define ACC_LPR (BIN_TILE / 256)  // 8-byte loads per lane and run held in registers: covers the average run of a hashed level twice
+#ifndef ACC_RB
 #define ACC_RB (12 / ACC_LPR)    // runs per batch in the accumulate loop (12 loads per batch: 16 spill at the 128-VGPR budget of 16 waves per CU)
+#endif
 __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
   long long* acc = (long long*)acc_smem;   // [2 features][slice entries] <= 128 KB: one plane per feature -- with the two features of
@@ -700,8 +785,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
                                            // LDS cycles of this kernel were bank conflicts); a plane spreads them over 32 bank pairs
   __shared__ unsigned long long bound_s;
   __shared__ int smin_s;
+  __shared__ uint32_t next_batch_s;   // next batch of ACC_RB tiles nobody has taken yet
   __shared__ float adam_c[4];   // skip, 1 / loss scale, lr / bc1, 1 / sqrt(bc2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = ACC_THREADS / 64;
+  AT_DECL
   int li = 0;
   while (li + 1 < a.n_levels_here && blockIdx.x >= a.blk_start[li + 1]) ++li;
   const int l = a.level_lo + li;
@@ -716,7 +803,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   // this never triggers for the hashed levels; it is what lets the two coarsest levels (thousands of records per entry at the
   // largest loss scales) share the exact path.
   const uint32_t plane = 1u << sl;   // entries per plane
-  if (tid == 0) { bound_s = 0ull; smin_s = 0; }
+  if (tid == 0) { bound_s = 0ull; smin_s = 0; next_batch_s = 0u; }
   if (a.ad.p && tid == 64) {   // (a lane of wave 1: off the critical path, needed at the flush only)
     const int found = a.ad.si[2], t = a.ad.si[4] + 1;
     const float lr = a.ad.sf[1] > 0.f ? a.ad.sf[1] : a.ad.lr;
@@ -724,19 +811,27 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     adam_c[0] = found ? 1.f : 0.f; adam_c[1] = 1.0f / a.ad.sf[0];
     adam_c[2] = (float)((double)lr / bc1); adam_c[3] = (float)(1.0 / sqrt(bc2));
   }
+  // (the first descriptors of the bound pass are requested before the accumulators are cleared: one HBM round trip under the LDS stores)
+  const uint32_t qd0 = tid < a.ntiles ? d[tid] : 0u, qd1 = tid + ACC_THREADS < a.ntiles ? d[tid + ACC_THREADS] : 0u;
   for (uint32_t i = tid; i < ne; i += ACC_THREADS) { acc[i] = 0ll; acc[plane + i] = 0ll; }
+  AT(0)
   __syncthreads();
+  AT(1)
   {
     unsigned long long bsum = 0ull; int smin = 0;
-    for (int t = tid; t < a.ntiles; t += ACC_THREADS) {
-      const uint32_t q = d[t]; const int sh = DESC_SHIFT(q);
+    auto fold = [&](uint32_t q) __attribute__((always_inline)) {
+      const int sh = DESC_SHIFT(q);
       if (DESC_COUNT(q)) { bsum += (unsigned long long)DESC_COUNT(q) << (15 - sh); smin = min(smin, sh); }   // |record| < 2^(15 - shift)
-    }
+    };
+    fold(qd0); fold(qd1);
+    for (int t = tid + 2 * ACC_THREADS; t < a.ntiles; t += ACC_THREADS) fold(d[t]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { bsum += __shfl_xor(bsum, o); smin = min(smin, __shfl_xor(smin, o)); }
     if (lane == 0 && bsum) { atomicAdd(&bound_s, bsum); atomicMin(&smin_s, smin); }
   }
+  AT(2)
   __syncthreads();
+  AT(3)
   int U = FX_UNIT_LOG2;
   // (a tile that was scaled DOWN carries records up to 2^(16 - shift): the double-precision conversion needs them below 2^51 units)
   { const unsigned long long bd = bound_s; const int lg = bd ? 64 - __clzll(bd) : 0; U = min(FX_UNIT_LOG2 + smin_s, 62 - lg); }   // bd < 2^lg
@@ -748,6 +843,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     atomicAdd((unsigned long long*)&acc[r.x], (unsigned long long)fx_from_half_d(hv[0], ex));
     atomicAdd((unsigned long long*)&acc[plane + r.x], (unsigned long long)fx_from_half_d(hv[1], ex));
   };
+#ifdef ACC_OLD   // dev builds only: round 5 -- equal static shares of the tiles per wave (same-box A/B)
   {
     // the tiles are dealt out to the 16 waves in equal contiguous shares (all waves busy for any tile count); a wave walks its
     // share in rounds of <= 64 tiles (one descriptor per lane) and batches of ACC_RB runs: the first 128 records of each run in
@@ -782,17 +878,134 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
             add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], ex[buf][u]);
         }
       };
+      AT(4)
       request(0, 0);
       for (int j0 = 0; j0 < nt; j0 += 2 * ACC_RB) {
         request(1, j0 + ACC_RB);
+        AT(5)
+#ifdef ACC_TIMING
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wait of the consume below, on its own stamp
+        AT(6)
+#endif
         consume(0, j0);
+        AT(7)
         request(0, j0 + 2 * ACC_RB);
+        AT(5)
+#ifdef ACC_TIMING
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        AT(6)
+#endif
         consume(1, j0 + ACC_RB);
+        AT(7)
       }
     }
   }
+#else
+  {
+    // Batches of ACC_RB consecutive tiles are handed out DYNAMICALLY (one LDS counter per block).  With equal static shares the 16
+    // waves of a block finished up to 65 % apart (section clocks of a -DACC_TIMING build: loop times 99 K .. 164 K ticks per wave for
+    // the same number of records -- whoever loses the issue arbitration of its SIMD falls behind for good), and the early ones sat at
+    // the block's barrier for a quarter of the kernel.  Integer accumulation is order-independent, so who adds which run changes no bit.
+    // Pipeline per wave, no drain anywhere: grab + descriptor load two batches ahead (ACC_RB lanes, one 4-byte word each), record loads
+    // one batch ahead (the first 128 records of each run in ACC_LPR 8-byte loads per lane; 16-byte loads, two records per lane, were
+    // slower: half the lanes idle through the conversions), consume.  The batch index comes back through readfirstlane: tile, start and
+    // count of every run are wave-uniform and the address arithmetic stays in scalar registers.
+    const int nbatch = (a.ntiles + ACC_RB - 1) / ACC_RB;
+    // (the counter's returning atomic is ISSUED one stage before its result is read: an LDS round trip behind the other waves' accumulate
+    //  traffic is ~1000 ticks, as long as the requests of a whole batch take to issue)
+    auto grab_issue = [&]() __attribute__((always_inline)) {
+      uint32_t g = 0u;
+      if (lane == 0) g = atomicAdd(&next_batch_s, 1u);
+      return g;
+    };
+    auto grabbed = [&](uint32_t g) __attribute__((always_inline)) { return (int)__builtin_amdgcn_readfirstlane(g); };
+    auto load_desc = [&](int bt) __attribute__((always_inline)) {
+      const int t = bt * ACC_RB + lane;
+      return (bt < nbatch && lane < ACC_RB && t < a.ntiles) ? d[t] : 0u;   // (0: start 0, count 0 -- nothing is requested for it)
+    };
+    uint2 r[2][ACC_LPR * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB]; int ex[2][ACC_RB];
+#ifdef ACC_BUFFER_LOADS
+    // records through BUFFER loads whose descriptor ends at the run's last record: lanes beyond it read zeros without a memory request,
+    // no compare / exec / branch around a load (half the scalar instructions of a request)
+    const uint32_t voff = (uint32_t)lane * 8u;
+    auto request = [&](int buf, int bt, uint32_t dq) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < ACC_RB; ++u) {
+        const uint32_t q = __builtin_amdgcn_readlane(dq, u);
+        st[buf][u] = DESC_START(q); n[buf][u] = DESC_COUNT(q); ex[buf][u] = U - DESC_SHIFT(q);
+        const uint2* src = pool + (size_t)(bt * ACC_RB + u) * BIN_CHUNK + st[buf][u];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(n[buf][u] * 8u), 0x00020000);
+#pragma unroll
+        for (int v = 0; v < ACC_LPR; ++v) {
+          const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 512u * v, 0, 0);
+          r[buf][ACC_LPR * u + v] = make_uint2(w.x, w.y);
+        }
+      }
+    };
+#else
+    auto request = [&](int buf, int bt, uint32_t dq) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < ACC_RB; ++u) {
+        const uint32_t q = __builtin_amdgcn_readlane(dq, u);
+        st[buf][u] = DESC_START(q); n[buf][u] = DESC_COUNT(q); ex[buf][u] = U - DESC_SHIFT(q);
+        const uint2* src = pool + (size_t)(bt * ACC_RB + u) * BIN_CHUNK + st[buf][u];
+#pragma unroll
+        for (int v = 0; v < ACC_LPR; ++v) {
+          r[buf][ACC_LPR * u + v] = make_uint2(0u, 0u);
+          if ((uint32_t)lane + 64u * v < n[buf][u]) r[buf][ACC_LPR * u + v] = src[lane + 64 * v];
+        }
+      }
+    };
+#endif
+    auto consume = [&](int buf, int bt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < ACC_RB; ++u) {
+#pragma unroll
+        for (int v = 0; v < ACC_LPR; ++v)
+          if ((uint32_t)lane + 64u * v < n[buf][u]) add(r[buf][ACC_LPR * u + v], ex[buf][u]);
+        for (uint32_t k = 64 * ACC_LPR + lane; k < n[buf][u]; k += 64)   // long runs
+          add(pool[(size_t)(bt * ACC_RB + u) * BIN_CHUNK + st[buf][u] + k], ex[buf][u]);
+      }
+    };
+    AT(4)
+    const uint32_t g0 = grab_issue(), g1 = grab_issue();
+    uint32_t gC = grab_issue();
+    int bA = grabbed(g0), bB = grabbed(g1);
+    uint32_t dA = load_desc(bA), dB = load_desc(bB);
+    request(0, bA, dA);
+    while (true) {   // here: batch A's records are in flight (buffer 0), batch B has its descriptors, batch C's index is on its way
+      const int bC = grabbed(gC);
+      const uint32_t gD = grab_issue();
+      const uint32_t dC = load_desc(bC);
+      request(1, bB, dB);
+      AT(5)
+#ifdef ACC_TIMING
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wait of the consume below, on its own stamp
+      AT(6)
+#endif
+      consume(0, bA);
+      AT(7)
+      if (bB >= nbatch) break;
+      const int bD = grabbed(gD);
+      gC = grab_issue();
+      const uint32_t dD = load_desc(bD);
+      request(0, bC, dC);
+      AT(5)
+#ifdef ACC_TIMING
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      AT(6)
+#endif
+      consume(1, bB);
+      AT(7)
+      if (bC >= nbatch) break;
+      bA = bC; bB = bD; dB = dD;
+    }
+  }
+#endif
   const bool bad = (badbits & 0x80008000u) != 0u;
+  AT(8)
   __syncthreads();
+  AT(9)
   const size_t g0 = 2 * ((size_t)a.offset[l] + e0);
   const double unit = ldexp(1.0, -U);
   if (a.ad.p) {
@@ -805,25 +1018,40 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     if (!skip && !bad) {   // (bad without skip: a caller fed non-finite records without raising the flag -- never write them into the parameters)
       float2* const P2 = (float2*)(a.ad.p + g0); float2* const M2 = (float2*)(a.ad.m + g0); float2* const V2 = (float2*)(a.ad.v + g0);
       h16x2* const T2 = (h16x2*)(a.ad.t16 + g0);
-      for (uint32_t e = tid; e < ne; e += ACC_THREADS) {
-        const float2 p2 = P2[e], m2 = M2[e], v2 = V2[e];
-        float gg[2] = {(float)((double)acc[e] * unit), (float)((double)acc[plane + e] * unit)};
-        float pp[2] = {p2.x, p2.y}, mm[2] = {m2.x, m2.y}, vv[2] = {v2.x, v2.y};
-        h16x2 t2;
+      // (a full slice is ACC_EPT entries per thread: their operands are all requested before the first is used -- as a plain loop
+      //  hipcc waits for every entry's three loads in turn, eight HBM round trips in a row at the end of every block)
+      constexpr int ACC_EPT = BIN_SLICE / ACC_THREADS;
+      for (uint32_t eb = 0; eb < ne; eb += ACC_EPT * ACC_THREADS) {
+        float2 p2[ACC_EPT], m2[ACC_EPT], v2[ACC_EPT];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const float gi = gg[k] * inv_scale;
-          const float mi = b1 * mm[k] + c1 * gi;
-          const float vi = b2 * vv[k] + c2 * gi * gi;
-          mm[k] = mi; vv[k] = vi;
-          const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-          pp[k] -= step_size * (mi / denom);
-          t2[k] = (h16)pp[k];
+        for (int i = 0; i < ACC_EPT; ++i) {
+          const uint32_t e = eb + tid + i * ACC_THREADS;
+          if (e < ne) { p2[i] = P2[e]; m2[i] = M2[e]; v2[i] = V2[e]; }
         }
-        M2[e] = make_float2(mm[0], mm[1]); V2[e] = make_float2(vv[0], vv[1]); P2[e] = make_float2(pp[0], pp[1]); T2[e] = t2;
+#pragma unroll
+        for (int i = 0; i < ACC_EPT; ++i) {
+          const uint32_t e = eb + tid + i * ACC_THREADS;
+          if (e >= ne) continue;
+          float gg[2] = {(float)((double)acc[e] * unit), (float)((double)acc[plane + e] * unit)};
+          float pp[2] = {p2[i].x, p2[i].y}, mm[2] = {m2[i].x, m2[i].y}, vv[2] = {v2[i].x, v2[i].y};
+          h16x2 t2;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float gi = gg[k] * inv_scale;
+            const float mi = b1 * mm[k] + c1 * gi;
+            const float vi = b2 * vv[k] + c2 * gi * gi;
+            mm[k] = mi; vv[k] = vi;
+            const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+            pp[k] -= step_size * (mi / denom);
+            t2[k] = (h16)pp[k];
+          }
+          M2[e] = make_float2(mm[0], mm[1]); V2[e] = make_float2(vv[0], vv[1]); P2[e] = make_float2(pp[0], pp[1]); T2[e] = t2;
+        }
       }
     }
     if (bad && a.found_inf) *a.found_inf = 1;   // (already set by the producer of d_enc; kept for a caller that feeds records of its own)
+    AT(10)
+    AT_FLUSH
     return;
   }
   if (a.wire) {
@@ -837,7 +1065,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
       h16x2 o; o[0] = (h16)(f0 * a.wire_mul); o[1] = (h16)(f1 * a.wire_mul);
       w2[e] = o;
     }
-    if (bad && a.found_inf) *a.found_inf = 1;   // (the engine reduces this flag over the ranks: every rank skips the step)
+    // a non-finite record anywhere in the block poisons the slice's first element (thread 0 wrote it above: program order), so the
+    // post-reduction watch (aln_grad_unpack_f16) sees it on EVERY rank whether or not the caller passed a flag
+    if (__syncthreads_or(bad) && tid == 0) {
+      a.wire[g0] = (h16)__builtin_nanf("");
+      if (a.found_inf) *a.found_inf = 1;   // (the engine reduces this flag over the ranks: every rank skips the step)
+    }
     return;
   }
   float* g = a.grad + g0;

@@ -22,7 +22,12 @@ class TrainEngine:
                  scaler=None, process_group=None, overlap_comm=True, grad_payload='f16', fuse_grid_adam=True, shard_optimizer=False,
                  shard_gather='table', exchange_at_world_1=False, direct_wire=True, level_group=4):
         self.pipe, self.P, self.L = pipe, pipe.P, pipe.L
-        self.level_group = int(level_group)   # hash-grid levels per scatter launch / gradient bucket of the overlapped exchange (level_groups)
+        # hash-grid levels per scatter launch / gradient bucket of the overlapped exchange (level_groups).  Resolved ONCE, here: an explicit
+        # argument wins; ALN_LEVEL_GROUP is only the default for level_group=None (re-reading the environment on every call let the
+        # variable override the argument, and ranks with different environments would issue different collective sequences)
+        if level_group is None:
+            level_group = os.environ.get('ALN_LEVEL_GROUP', 4)
+        self.level_group = max(1, int(level_group))
         dv = self.P.device
         # the step's intermediates live in a workspace of the engine's own: a render through the same pipeline (pipe.ws) between
         # two steps cannot move the buffers a captured step points into
@@ -185,7 +190,7 @@ class TrainEngine:
         8.4 MB buckets behind ~150 us of scatter each and expose 1.4 MB; groups of 8 expose the 11 MB of levels 0-7.  Which wins depends on
         what the links deliver, so `bench.py --gpus N` times both (dp_overlap, dp_overlap_g8)."""
         n = int(self.L.enc.grid.n_levels) if self.L.n_grid else 0
-        per = max(1, int(os.environ.get('ALN_LEVEL_GROUP', self.level_group)))
+        per = self.level_group
         groups, hi = [], n
         while hi > 0:
             lo = max(0, hi - per)
@@ -396,14 +401,20 @@ class GraphedStep:
                 self.steps += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            self._once(False)
-        self.alt_graph = None
-        if alt_body is not None:
-            self.alt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.alt_graph, stream=side):
-                self._once(True)
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self._once(False)
+            self.alt_graph = None
+            if alt_body is not None:
+                self.alt_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.alt_graph, stream=side):
+                    self._once(True)
+        except Exception as e:
+            # the eager warm-up steps above DID run (optimizer steps, collectives included): whoever catches this has to advance its step
+            # counters by them, or this rank's step numbering (RNG / data step, scheduler, checkpoints) falls behind its peers'
+            e.warmup_steps = self.steps
+            raise
         self._captured = guard() if guard is not None else None
 
     def valid(self):

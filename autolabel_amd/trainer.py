@@ -308,6 +308,9 @@ class SimpleTrainer(Trainer):
                     self.ema.update()
                 self._step_scheduler(loss)
                 return
+            # fallen back to launch-by-launch steps: the warm-up steps of the failed capture count towards this call's iterations
+            iterations = max(iterations - getattr(self, '_warmup_ran', 0), 0)
+            self._warmup_ran = 0
         iterator = iter(dataloader)
         bar = tqdm(range(iterations), desc='Loss: N/A', disable=self.mute or self.local_rank != 0)
         loss = None
@@ -355,6 +358,7 @@ class SimpleTrainer(Trainer):
             if iterations <= 0:
                 return eng.terms[4]
             err = g = None
+            unsafe = False
             try:
                 g = eng.graphed(loader.frames, loader.batch, loader.seed, self.model._seed, frame_range=loader.frame_range,
                                 first_step=self.global_step, warmup=1)
@@ -362,12 +366,15 @@ class SimpleTrainer(Trainer):
                 if not getattr(self, '_graph_warned', False):
                     self.log(f'[WARN] hipGraph replay disabled, stepping launch by launch: {e}')
                     self._graph_warned = True
-                self.use_graph = False
+                unsafe = True
                 err = e
             except Exception as e:
                 if self.world_size == 1:
                     raise
                 err = e
+            # eager warm-up steps of a capture that failed AFTER them did run (collectives included): every rank advances by the steps it
+            # executed, whether or not its capture succeeded, so the ranks keep one step numbering
+            ran = g.steps if g is not None else int(getattr(err, 'warmup_steps', 0))
             if self.world_size > 1:
                 # the fallback is a GROUP decision: a rank stepping launch by launch beside ranks that replay captured collectives
                 # would issue another collective sequence and hang the job instead of degrading it
@@ -376,12 +383,17 @@ class SimpleTrainer(Trainer):
                 if float(ok.item()) == 0.0:
                     why = f'{type(err).__name__}: {err}' if err is not None else 'another rank could not capture it'
                     self.log(f'[WARN] the data-parallel step could not be captured ({why}); every rank steps launch by launch')
-                    self.use_graph_dp = False
-                    if g is not None:     # this rank's warm-up steps did run
-                        self.global_step += g.steps
-                        loader.step += g.steps
+                    self.use_graph_dp = False      # (decided by the group, after the all-reduce: no rank switches on its own)
+                    self.global_step += ran
+                    loader.step += ran
+                    self._warmup_ran = ran
                     return None
             elif err is not None:
+                if unsafe:
+                    self.use_graph = False
+                self.global_step += ran
+                loader.step += ran
+                self._warmup_ran = ran
                 return None
             self.global_step += g.steps
             loader.step += g.steps

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from autolabel_amd import build as B
 
 tag = sys.argv[1]
-out = os.path.join(ROOT, 'scripts', 'dev', '_build')
+out = os.path.join(ROOT, "scripts", "dev", "run", "variants")
 os.makedirs(os.path.join(out, tag), exist_ok=True)
 B.build_library(verbose=False)
 objs = {s: os.path.join(B.OBJ, s + '.o') for s in B.SOURCES}
@@ -18,7 +18,7 @@ procs = []
 for spec in sys.argv[2:]:
     src, _, defs = spec.partition(':')
     o = os.path.join(out, tag, src + '.o')
-    procs.append(subprocess.Popen(['hipcc'] + B.FLAGS + [d for d in defs.split(',') if d] + ['-c', os.path.join(B.CSRC, src), '-o', o]))
+    procs.append(subprocess.Popen(['hipcc'] + B.FLAGS + [d for d in defs.split(',') if d] + ['-c', os.path.join(B.CSRC, src), '-o', o], stderr=subprocess.DEVNULL))
     objs[src] = o
 assert all(p.wait() == 0 for p in procs)
 lib = os.path.join(out, 'lib_%s.so' % tag)

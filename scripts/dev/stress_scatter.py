@@ -6,6 +6,7 @@ compared with the first; on a mismatch the record pool of the differing level is
   (a) turned into a gradient on the host (float64 sums of value * 2^-shift per entry): equal to the GPU's table of THIS replay ->
       phase 2 added up what it was given, so phase 1 produced different records; unequal -> phase 2 is the culprit;
   (b) compared with the first replay's pool as a multiset per (tile, slice) run;
+  (round 6: the -DBIN_DEBUG taps were removed from encode.hip with the kernel they instrumented; --map-lib / --times need the file as of commit 74cae74)
   (c) with --map-lib (a -DBIN_DEBUG=5 build of encode.hip, run once) traced to the (tile, wave, lane, corner) that emitted each wrong
       record, and with --dbg <a -DBIN_DEBUG=6 build> --times set against per-wave timestamps (was the wave switched out?).
 Round 5: the differing records all came from lanes 48..63 of single waves, with products of packed fp32 multiplies zeroed; no timing

@@ -129,20 +129,17 @@ def test_two_ranks_on_one_gpu_stay_in_lockstep_with_bucketed_allreduce():
     # This comparison failed in GPUTEST_r04 (3.4 M parameters apart after three steps, both ranks still in agreement) and then about once in
     # twenty runs.  Round 5 found the cause outside the exchange: packed fp32 instructions of the scatter returning +0 in lanes 48..63
     # while the OTHER rank's MFMA kernels ran on the same SIMD -- two processes on one GPU (scripts/dev/probe_pk_f32.hip).
-    # The library is now built without them (tests/test_build_hygiene.py) and the test passed 40 of 40 first attempts.  The record-and-repeat
-    # below stays as the instrument it was: a divergence is RECORDED with the step and parameter block it started in
-    # (gpurun_out/lockstep_divergence.json) and the pair is run once more; two divergences in a row fail the test, a single one is a warning.
+    # The library is now built without them (tests/test_build_hygiene.py).  STRICT since round 6: the first divergence fails the test
+    # (round 5's record-and-repeat would have hidden a regression of exactly that class); the step and parameter block it started in
+    # are still written to gpurun_out/lockstep_divergence.json for whoever has to chase it.
     div = _lockstep_divergence(res)
     if div is not None:
         import json
-        import warnings
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(root, 'gpurun_out', 'lockstep_divergence.json'), 'w') as f:
             json.dump(div, f)
-        again = _lockstep_divergence(_lockstep_run())
-        assert again is None, f'overlapped and single-collective steps diverged twice in a row: {div}, then {again}'
-        warnings.warn(f'overlapped and single-collective steps diverged once ({div}) and agreed bit for bit when repeated')
+    assert div is None, f'overlapped and single-collective steps diverged: {div}'
 
 
 def _shard_worker(rank, world, port, ret):

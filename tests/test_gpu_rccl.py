@@ -101,9 +101,15 @@ def test_rccl_world_of_one_runs_every_data_parallel_form_of_the_step():
         if 0 in got:
             res = got[0]
             break
-    if errors:
+    if errors:   # counted and reported, never silent: gpurun_out/rccl_setup_retries.json says how often the set-up retry fired and why
+        import json
         import warnings
-        warnings.warn('the RCCL worker failed before delivering results: ' + ' | '.join(errors))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        rec = os.path.join(root, 'gpurun_out', 'rccl_setup_retries.json')
+        prev = json.load(open(rec)) if os.path.exists(rec) else []
+        json.dump(prev + [dict(attempts=len(errors) + (res is not None), delivered=res is not None, errors=errors)], open(rec, 'w'))
+        warnings.warn('the RCCL worker failed before delivering results (set-up only; computed results are never retried): ' + ' | '.join(errors))
     assert res is not None, errors
     assert res['backend'] == 'nccl' and res['world'] == 1
     errors = {k: v['error'] for k, v in res.items() if isinstance(v, dict) and 'error' in v}
