@@ -4,9 +4,9 @@ against the reference's hot-path modules (its ``scripts/train.py`` and ``scripts
 on them unchanged.  NOT aliased -- out of the hot path: ``autolabel.constants``, ``autolabel.visualization``,
 ``autolabel.utils.feature_utils``, ``autolabel.backend``, ``autolabel.evaluation``; the reference's ``scripts/render.py`` imports
 the first three for its colour maps / video writer and therefore needs the reference package for those (this repo's
-``scripts/render.py`` restates the rendering part).  One data-path deviation: depth frames are resized with nearest-neighbour
-sampling here; the reference's ``cv2.resize(depth, size, cv2.INTER_NEAREST)`` passes the flag in the ``dst`` position and so
-resizes bilinearly (autolabel/dataset.py:372)."""
+``scripts/render.py`` restates the rendering part).  Depth frames of the eager loader are resized
+bilinearly like the reference's (its ``cv2.resize(depth, size, cv2.INTER_NEAREST)`` passes the flag in the ``dst`` position:
+autolabel/dataset.py:391-393; ``autolabel_amd.dataset._resize_linear``)."""
 import importlib
 import sys
 

@@ -417,7 +417,7 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
                                 // (1 KB runs for phase 2) measured: round 3 dense pair 771 -> 806 us, round 5 620 -> 607 us (step -0.3 %): no gain
                                 // worth the format change it needs -- a full 1024-row tile has 8192 records, one more than DESC_START holds
 #endif
-static_assert(BIN_TILE * 8 <= 0x1FFF, "a tile's record count (the start of a trailing empty slice) must fit the 13-bit start field of the descriptors");
+static_assert(BIN_TILE * 8 <= 0x2000, "the start of every NON-EMPTY slice of a tile must fit the 13-bit start field of the descriptors (an empty trailing slice of a full 1024-row tile wraps to 0: never read)");
 // descriptor word: start (13 bits) | count << 13 (14 bits) | (shift + BIN_SHIFT_BIAS) << 27
 #define DESC_START(q) ((q) & 0x1FFFu)
 #define DESC_COUNT(q) (((q) >> 13) & 0x3FFFu)
@@ -494,7 +494,7 @@ __device__ inline uint32_t wave_incl_scan(uint32_t x) {
   return x;
 }
 typedef uint32_t rec_pair __attribute__((ext_vector_type(4), aligned(8)));   // two 8-byte records at an 8-byte aligned LDS address
-__global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_encode_bwd_bin(BinParams b) {   // (three blocks per CU: 80 registers)
+__global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TILE <= 768 ? 6 : 4, BIN_TILE <= 768 ? 6 : 4))) void k_encode_bwd_bin(BinParams b) {   // (three blocks per CU: 80 registers)
   __shared__ uint2 sorted[BIN_CHUNK];                        // 32 KB
   __shared__ uint32_t gws[8][BIN_TILE];                      // 16 KB: the rows' gradient words of eight levels (column = thread)
   __shared__ uint32_t cnt[2][BIN_MAX_SLICES], base_w[BIN_TILE / 64][BIN_MAX_SLICES], vmax_s[2];

@@ -84,8 +84,54 @@ def _resize_nearest(img, size):
     return img[ys][:, xs]
 
 
+def _resize_linear(img, size):
+    """``cv2.resize(img, size)`` with the DEFAULT interpolation (INTER_LINEAR) on a single-channel uint16 / float32 image.
+
+    This is what the reference's eager loader applies to depth frames: ``cv2.resize(depth_image, self.camera.size, cv2.INTER_NEAREST)``
+    (autolabel/dataset.py:391-393) passes the flag in the ``dst`` position, so the interpolation argument keeps its default.  OpenCV is
+    not in this image (parity unpinned); restated from its published algorithm (modules/imgproc/src/resize.cpp):
+      * both scales exactly 2 (the default ``factor=2``): INTER_LINEAR is redirected to the fast INTER_AREA path, for 16-bit images
+        ``(a + b + c + d + 2) >> 2`` over the 2 x 2 block (round half UP);
+      * otherwise pixel-centre alignment ``fx = (dx + 0.5) * scale - 0.5`` in fp32, ``sx = floor(fx)``, clamped at both borders with
+        weight 0, fp32 weights ``(1 - fx, fx)``, horizontal pass into fp32 rows, then the vertical blend, ``saturate_cast<ushort>`` =
+        round half to EVEN and clamp to [0, 65535].
+    """
+    w, h = size
+    H, W = img.shape[:2]
+    if img.ndim != 2 or img.dtype not in (np.uint16, np.float32):
+        raise NotImplementedError(f'_resize_linear: single-channel uint16 / float32 frames only (depth PNGs are 16-bit), got {img.dtype} {img.shape}')
+    if (w, h) == (W, H):
+        return img.copy()
+    if img.dtype == np.uint16 and W == 2 * w and H == 2 * h:
+        a = img.astype(np.uint32)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint16)
+
+    def taps(n_dst, n_src):
+        scale = 1.0 / (n_dst / n_src)                        # (double, as cv::resize derives it from inv_scale)
+        f = ((np.arange(n_dst) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = (f - s0.astype(np.float32)).astype(np.float32)
+        lo = s0 < 0
+        s0[lo], f[lo] = 0, 0.0
+        hi = s0 >= n_src - 1
+        s0[hi], f[hi] = n_src - 1, 0.0
+        s1 = np.minimum(s0 + 1, n_src - 1)
+        return s0, s1, (np.float32(1.0) - f).astype(np.float32), f
+
+    x0, x1, ax0, ax1 = taps(w, W)
+    y0, y1, by0, by1 = taps(h, H)
+    src = img.astype(np.float32)
+    rows = src[:, x0] * ax0[None, :] + src[:, x1] * ax1[None, :]          # horizontal pass (fp32)
+    out = rows[y0] * by0[:, None] + rows[y1] * by1[:, None]                # vertical blend (fp32)
+    if img.dtype == np.float32:
+        return out.astype(np.float32)
+    return np.clip(np.rint(out), 0, 65535).astype(np.uint16)                # saturate_cast<ushort>: lrint (half to even) + clamp
+
+
 class LazyImageLoader:
-    """Decode + resize frames on first access, cache them (autolabel/dataset.py:55-77)."""
+    """Decode + resize frames on first access, cache them (autolabel/dataset.py:55-77).  As in the reference EVERY frame -- depth
+    included -- is converted to float32 and divided by 255 before the nearest-neighbour resize (its depth values in lazy mode are
+    therefore raw / 255, bug for bug: autolabel/dataset.py:67)."""
 
     def __init__(self, images, size, interpolation=None):
         self.images, self.size, self._cache = images, size, {}
@@ -93,8 +139,7 @@ class LazyImageLoader:
     def __getitem__(self, i):
         if i not in self._cache:
             from PIL import Image
-            arr = np.array(Image.open(self.images[i]))
-            arr = arr.astype(np.float32) / 255. if arr.dtype == np.uint8 else arr
+            arr = np.array(Image.open(self.images[i]), dtype=np.float32) / 255.
             self._cache[i] = _resize_nearest(arr, self.size)
         return self._cache[i]
 
@@ -280,7 +325,8 @@ class SceneDataset(BaseDataset):
             else:
                 rgb = np.array(Image.open(rgb_paths[i]), dtype=np.float32)[..., :3]
                 images.append(_resize_nearest(rgb, self.camera.size) / 255.)
-                depths.append(_resize_nearest(np.array(Image.open(depth_paths[i])), self.camera.size))
+                # (bilinear, not nearest: the reference passes cv2.INTER_NEAREST in the `dst` slot of cv2.resize -- autolabel/dataset.py:391-393)
+                depths.append(_resize_linear(np.array(Image.open(depth_paths[i])), self.camera.size))
             sem_path = os.path.join(self.scene.path, 'semantic', os.path.basename(depth_paths[i]))
             if self.load_semantic and os.path.exists(sem_path):
                 semantics.append(np.asarray(Image.open(sem_path).resize(self.camera.size, Image.NEAREST)))

@@ -160,6 +160,49 @@ def test_synthetic_scene_round_trips_through_scene_directory(tmp_path):
     assert b['rays_o'].shape == (1024, 3) and b['semantic'].dtype == np.int64 and (b['semantic'] >= -1).all()
 
 
+def test_depth_frames_are_resized_like_the_references_cv2_call(tmp_path):
+    """The reference's eager loader calls cv2.resize(depth, size, cv2.INTER_NEAREST) -- the flag lands in the `dst` slot, so depth is
+    resized with cv2's DEFAULT, INTER_LINEAR (autolabel/dataset.py:391-393).  Known answers of OpenCV's published algorithm (cv2 is not
+    in this image: restated, parity unpinned): exact factor 2 = the fast area path (a + b + c + d + 2) >> 2, round half UP; any other
+    scale = pixel-centre bilinear in fp32 with clamped borders, saturate_cast = round half to EVEN."""
+    from autolabel_amd.dataset import SceneDataset, _resize_linear
+    from autolabel_amd import synthetic
+    from autolabel_amd.utils import write_scene
+    a = np.array([[0, 1, 10, 20], [1, 1, 30, 40], [65535, 65535, 2, 3], [65535, 65535, 4, 5]], dtype=np.uint16)
+    # sums 3, 100, 262140, 14 -> 0.75 -> 1, 25, 65535, 3.5 -> 4 (half up; half-to-even would give 4 as well, 2.5 would not:)
+    assert _resize_linear(a, (2, 2)).tolist() == [[1, 25], [65535, 4]]
+    assert _resize_linear(np.array([[1, 2], [3, 4]], dtype=np.uint16), (1, 1)).tolist() == [[3]]          # 2.5 -> 3 (half up)
+    # 5 -> 3 per axis: taps (0, 1/3), (2, 0), (3, 2/3); values 100 * (5 y + x)
+    b = (np.arange(25, dtype=np.uint16).reshape(5, 5) * 100)
+    assert _resize_linear(b, (3, 3)).tolist() == [[200, 367, 533], [1033, 1200, 1367], [1867, 2033, 2200]]
+    # upsampling clamps at both borders (weight 0 beyond the last source pixel), half to even in the interior: 2 -> 4 of [0, 5]:
+    # fx = -0.25 -> (0, 0) ; 0.25 -> 1.25 -> 1 ; 0.75 -> 3.75 -> 4 ; 1.25 -> clamped (1, 0) -> 5
+    assert _resize_linear(np.array([[0, 5]], dtype=np.uint16), (4, 1)).tolist() == [[0, 1, 4, 5]]
+    assert _resize_linear(a, (4, 4)).tolist() == a.tolist()
+    # through the loader: factor 2 halves a 32 x 32 scene; every supervised depth is the rounded mean of its 2 x 2 block
+    scene = synthetic.make_cube_scene(n_frames=2)
+    write_scene(scene, str(tmp_path / 's'))
+    full = SceneDataset('train', str(tmp_path / 's'), factor=1.0, batch_size=512)
+    half = SceneDataset('train', str(tmp_path / 's'), factor=2.0, batch_size=512)
+    d = full.depths.reshape(2, 32, 32).astype(np.uint32)
+    want = (d[:, 0::2, 0::2] + d[:, 0::2, 1::2] + d[:, 1::2, 0::2] + d[:, 1::2, 1::2] + 2) >> 2
+    assert half.depths.shape[1:] == (16, 16) or half.depths.reshape(2, -1).shape[1] == 256
+    assert np.array_equal(half.depths.reshape(2, 16, 16), want)
+    # rgb stays nearest (the reference passes interpolation= by keyword there: autolabel/dataset.py:369-371)
+    assert np.array_equal(half.images.reshape(2, 16, 16, 3), full.images.reshape(2, 32, 32, 3)[:, 0::2, 0::2])
+
+
+def test_lazy_loader_divides_every_frame_by_255_like_the_reference(tmp_path):
+    """autolabel/dataset.py:63-70: LazyImageLoader converts whatever it opens to float32 / 255 -- depth frames too -- and resizes with
+    the interpolation it was given (nearest, by keyword: dataset.py:395-400)."""
+    from PIL import Image
+    from autolabel_amd.dataset import LazyImageLoader
+    d = (np.arange(16, dtype=np.uint16).reshape(4, 4) * 1000)
+    Image.fromarray(d).save(str(tmp_path / 'd.png'))
+    got = LazyImageLoader([str(tmp_path / 'd.png')], (2, 2))[0]
+    assert got.dtype == np.float32 and np.array_equal(got, (d.astype(np.float32) / 255.)[0::2, 0::2])
+
+
 def test_bench_refuses_a_gpu_count_that_is_not_the_world_size():
     """ADVICE r1: `--gpus N` must mean N ranks.  Under a launcher (RANK set) a mismatch exits non-zero before any GPU call;
     with no launcher bench.py starts the ranks itself (covered on the GPU box by the driver's --gpus runs)."""
