@@ -224,7 +224,10 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
 // blocks with the same row range a few microseconds later, and those run on the SAME XCD (block ids differ by multiples of nblk, a
 // multiple of 8), so the pieces merge in its L2 before they leave for HBM.  The blocks of the first phase also write the frequency
 // features and the ones padding of their rows.
-__global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg, h16* __restrict__ tiled) {
+// `pitch` != 0 (round 6): PAIR-PLANE output for the density head itself (AlnMlpDesc.x_tiled = 2) -- level l goes to plane fdim / 2 + l at
+// `pitch` words per plane, and the phases also write the frequency pairs (planes 0 .. fdim / 2 - 1) and the ones behind the last level,
+// one pair per phase like the tiled form: every plane is written with whole-wave 256-byte stores, nothing is assembled afterwards.
+__global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg, h16* __restrict__ tiled, long pitch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.x / nblk, b = blockIdx.x % nblk;
   const int base_row = (b * 4 + wave) * 64;
@@ -249,11 +252,12 @@ __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* 
       const h16x2 o = level_features(p, l, xn, lane, base_row);
       if (row < p.rows) {
         if (tiled) { const int j = fdim + 2 * l; *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = o; }
+        else if (pitch) planes[(size_t)(fdim / 2 + l) * pitch + row] = o;
         else planes[(size_t)l * p.rows + row] = o;
       }
     }
   }
-  if (tiled && row < p.rows) {
+  if ((tiled || pitch) && row < p.rows) {
     // frequency features (k_encode_assemble's arithmetic) and the ones behind the last level: one PAIR of columns per phase -- phase g
     // takes pair g of the fdim / 2 + (pad - enc_dim) / 2 extra pairs (all twelve sines in the first phase made its blocks three times
     // as long as the others); whatever does not fit the phases falls to the last one
@@ -264,11 +268,11 @@ __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* 
         if (p.e.freq_normalized) { float qn[3]; normalize_pos(xr, p.e.bound, false, qn); xr[0] = qn[0]; xr[1] = qn[1]; xr[2] = qn[2]; }
         const int j = 2 * q;
         h16x2 f; f[0] = freq_feature(p.e.n_freq, xr, j); f[1] = freq_feature(p.e.n_freq, xr, j + 1);
-        *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = f;
+        if (tiled) *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = f; else planes[(size_t)q * pitch + row] = f;
       } else {
         const int j = p.e.enc_dim + 2 * (q - npf);
         h16x2 one; one[0] = (h16)1.0f; one[1] = (h16)1.0f;
-        *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = one;
+        if (tiled) *(h16x2*)(trow + 256 * (j >> 3) + (j & 7)) = one; else planes[(size_t)(j >> 1) * pitch + row] = one;
       }
     }
   }
@@ -327,15 +331,29 @@ extern "C" int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16,
   const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
   if (!planes_ws) {   // tiled: straight into the MLP's input buffer (nblk rounded up to a multiple of 8 keeps a row range on one XCD)
     const int nblk8 = (nblk + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk8 * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)nullptr, nblk8, lg, (h16*)enc_out);
+    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk8 * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)nullptr, nblk8, lg, (h16*)enc_out, 0L);
     ALN_CHECK_LAUNCH("encode_grid_phased");
     return 0;
   }
-  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg, (h16*)nullptr);
+  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg, (h16*)nullptr, 0L);
   ALN_CHECK_LAUNCH("encode_grid_phased");
   hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
                      (const h16x2*)planes_ws, (h16*)enc_out);
   ALN_CHECK_LAUNCH("encode_assemble");
+  return 0;
+}
+
+extern "C" int aln_encode_fwd_planes(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d, const float* z,
+                                     const float* xyz, int32_t rows, int32_t rays_stride, void* planes_out, int64_t plane_pitch, void* stream) {
+  EncParams p;
+  if (int rc = fill_params(p, e, table_f16, rays_o, rays_d, z, xyz, rows, rays_stride)) return rc;
+  ALN_REQUIRE(e->use_grid && table_f16 && planes_out, "encode_fwd_planes: needs a grid encoding, its table and the plane buffer");
+  ALN_REQUIRE(plane_pitch >= rows && plane_pitch % 4 == 0 && ((uintptr_t)planes_out & 3) == 0 && e->enc_dim % 2 == 0 && (6 * e->n_freq) % 2 == 0,
+              "encode_fwd_planes: plane_pitch must be a multiple of 4 words and at least the row count");
+  if (rows == 0) return 0;
+  const int nblk = (rows + 255) / 256, ngroups = (int)e->grid.n_levels;
+  hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_out, nblk, 1, (h16*)nullptr, (long)plane_pitch);
+  ALN_CHECK_LAUNCH("encode_grid_phased");
   return 0;
 }
 
@@ -383,7 +401,7 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
   if (e->use_grid && planes_ws) {
     const int lg = ENC_LG;
     const int nblk = (rows + 255) / 256, ngroups = ((int)e->grid.n_levels + lg - 1) / lg;
-    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg, (h16*)nullptr);
+    hipLaunchKernelGGL(k_encode_grid_phased, dim3(nblk * ngroups), dim3(256), 0, (hipStream_t)stream, p, (h16x2*)planes_ws, nblk, lg, (h16*)nullptr, 0L);
     ALN_CHECK_LAUNCH("encode_grid_phased");
     hipLaunchKernelGGL(k_encode_assemble, dim3(nblk < 8192 ? nblk : 8192), dim3(256), 256 * (e->enc_pad + 8) * sizeof(h16), (hipStream_t)stream, p,
                        (const h16x2*)planes_ws, (h16*)enc_out);

@@ -113,11 +113,12 @@ __device__ long long g_ph128[32];
 #define PT_FLUSH
 #endif
 
-template <int IN, bool XT>   // XT: x rows in the tiled layout of AlnMlpDesc.x_tiled (compile-time: see mlp_fwd128.hip)
+template <int IN, int LAYOUT>   // LAYOUT = AlnMlpDesc.x_tiled: 0 row-major x rows, 1 tiled, 2 pair planes `pitch` words apart (compile-time: see mlp_fwd128.hip)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, const h16* __restrict__ x_g,
                   const h16* __restrict__ do_g, int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
-                  float* __restrict__ dw_ws, int* __restrict__ found_inf) {
+                  float* __restrict__ dw_ws, int* __restrict__ found_inf, long pitch) {
+  constexpr bool XT = LAYOUT == 1;
   constexpr int KS0 = IN / 16, IB = (IN + 31) / 32, PX = px_pitch(IN);
   constexpr int XCH = IN / 8, NXS = (TR * XCH + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -154,11 +155,16 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   auto prefetch_x = [&](int r0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
-      const int i = threadIdx.x + 256 * q, r = i / XCH, k = i % XCH;
+      // (pair planes: a wave takes 64 consecutive rows of ONE 16-byte chunk -- four planes, four coalesced 256-byte loads)
+      const int i = threadIdx.x + 256 * q, r = LAYOUT == 2 ? i % TR : i / XCH, k = LAYOUT == 2 ? i / TR : i % XCH;
       // (x rows row-major, or in the tiled layout of AlnMlpDesc.x_tiled: chunk k of row m at 32 IN (m / 32) + 256 k + 8 (m % 32))
       if (i < TR * XCH && r0 + r < rows) {
         const int m = r0 + r;
-        px[q] = *(const h16x8*)(XT ? x_g + (size_t)(m >> 5) * (32 * IN) + 256 * k + 8 * (m & 31) : x_g + (size_t)m * IN + 8 * k);
+        if constexpr (LAYOUT == 2) {
+          const uint32_t* const pl = (const uint32_t*)x_g + (size_t)(4 * k) * pitch + m;
+          px[q] = __builtin_bit_cast(h16x8, (u32x4){pl[0], pl[pitch], pl[2 * pitch], pl[3 * pitch]});
+        } else
+          px[q] = *(const h16x8*)(XT ? x_g + (size_t)(m >> 5) * (32 * IN) + 256 * k + 8 * (m & 31) : x_g + (size_t)m * IN + 8 * k);
       }
     }
   };
@@ -170,7 +176,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
     const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < NXS; ++q) {
-      const int i = threadIdx.x + 256 * q, r = i / XCH, k = i % XCH;
+      const int i = threadIdx.x + 256 * q, r = LAYOUT == 2 ? i % TR : i / XCH, k = LAYOUT == 2 ? i / TR : i % XCH;
       if (i < TR * XCH) *(LDS_VEC(h16x8)*)(tX + xrow(r) * PX + 8 * k) = (r0 + r < rows) ? px[q] : z;
     }
   };
@@ -502,15 +508,18 @@ static int launch(const AlnMlpDesc* m, const h16* x, const h16* d_out, int rows,
   constexpr int IB = (IN + 31) / 32;
   constexpr size_t lds = (2 * (size_t)TR * PX + (size_t)TR * PO + 64 + 3 * (size_t)HID * PH + (size_t)IB * KS * 512) * 2;   // + 64 halves: the transposed reads of the last row run past it
   static_assert(lds <= 160 * 1024, "LDS");
-  if (m->x_tiled) {
-    hipFuncSetAttribute((const void*)k_mlp_bwd128<IN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_mlp_bwd128<IN, true>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,
-                       (h16*)d_in, ws, found_inf);
-  } else {
-    hipFuncSetAttribute((const void*)k_mlp_bwd128<IN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_mlp_bwd128<IN, false>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,
-                       (h16*)d_in, ws, found_inf);
-  }
+#define ALN_B128(T)                                                                                                                         \
+  do {                                                                                                                                      \
+    hipFuncSetAttribute((const void*)k_mlp_bwd128<IN, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    hipLaunchKernelGGL((k_mlp_bwd128<IN, T>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,   \
+                       (h16*)d_in, ws, found_inf, (long)m->x_pitch);                                                                        \
+  } while (0)
+  if (m->x_tiled == 2) {
+    if (m->x_pitch < rows || ((uintptr_t)x & 3) != 0) { aln_set_error("mlp_bwd128: pair-plane input (x_tiled = 2) needs x_pitch >= rows"); return -1; }
+    ALN_B128(2);
+  } else if (m->x_tiled) ALN_B128(1);
+  else ALN_B128(0);
+#undef ALN_B128
   return 0;
 }
 

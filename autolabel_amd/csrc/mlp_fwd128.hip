@@ -57,12 +57,17 @@ extern "C" int aln_debug_read_fwd128(long long* host_out, int reset) {
 #define F_STAMP(i)
 #define F_FLUSH
 #endif
-// TILED: the input rows are in the tiled layout of AlnMlpDesc.x_tiled.  A COMPILE-TIME switch: as a run-time argument the address
+// LAYOUT (AlnMlpDesc.x_tiled): 0 = row-major input rows, 1 = the tiled layout, 2 = PAIR PLANES (round 6: what aln_encode_fwd_planes writes --
+// plane q = features (2 q, 2 q + 1) of every row, `pitch` words apart).  A COMPILE-TIME switch: as a run-time argument the address
 // selects cost the row-major instantiations 60 us per training step (same-box A/B of the replayed step: 1.74 -> 1.80 ms).
-template <int KS0, bool TILED>   // k-steps of the input rows (in_pad / 16: 2 = colour head, 3 = density head)
+// Planes: a request is still ONE 16-byte global_load_lds per lane, tile and k-step -- the lane fetches four consecutive ROWS of one plane
+// (lane = 8 pos + row group; the eight planes of a k-step in the order 0 4 1 5 2 6 3 7, so that the words of the two halves of the wave sit
+// 32 banks apart) -- and the read-back gathers the lane's four words (its row, planes 8 ks + 4 hf + 0..3) with two ds_read2_b32.
+template <int KS0, int LAYOUT>   // k-steps of the input rows (in_pad / 16: 2 = colour head, 3 = density head)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int rows, const int* __restrict__ rows_dev, h16* __restrict__ out,
-                  float* __restrict__ sigma) {
+                  float* __restrict__ sigma, long pitch) {
+  constexpr bool TILED = LAYOUT == 1;
   constexpr int NB = 4, KS = 8, IN = 16 * KS0;
   const int lane = threadIdx.x & 63, hf = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -94,6 +99,20 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
   // own wait: hipcc would otherwise make every LDS read wait for ALL direct-to-LDS loads in flight, the younger request included.
   __shared__ __attribute__((aligned(16))) h16 stage[4][2][2 * KS0][64 * 8];
   auto request = [&](int p, int buf) __attribute__((always_inline)) {
+    if constexpr (LAYOUT == 2) {
+      const int pos = lane >> 3, rg = lane & 7, ql = (pos >> 1) + 4 * (pos & 1);
+      const int last = ((rows - 1) >> 5) << 5;                                // first row of the last tile (rows % 32 == 0: the launcher checks)
+      const int ta = min(p * 64, last), tb = min(p * 64 + 32, last);          // clamped: a tile beyond the end is never stored
+      const uint32_t* const pl = (const uint32_t*)x + (size_t)ql * pitch + 4 * rg;
+#pragma unroll
+      for (int ks = 0; ks < KS0; ++ks) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl + (size_t)(8 * ks) * pitch + ta),
+                                         (__attribute__((address_space(3))) void*)&stage[wave][buf][ks][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl + (size_t)(8 * ks) * pitch + tb),
+                                         (__attribute__((address_space(3))) void*)&stage[wave][buf][KS0 + ks][0], 16, 0, 0);
+      }
+      return;
+    }
     const int ra = min(p * 64 + c, rows - 1), rb = min(p * 64 + 32 + c, rows - 1);   // clamped: a row beyond the end is never stored
     // row-major rows, or the tiled layout of AlnMlpDesc.x_tiled (piece 2 ks + hf of row r at 32 IN (r / 32) + 256 piece + 8 (r % 32)): the
     // pieces the lanes fetch are the same either way, only their addresses differ (tiled: a tile's piece is one contiguous 512 bytes)
@@ -110,9 +129,42 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
   };
   h16x8 xA[KS0], xB[KS0];
   const uint32_t my_slot = (uint32_t)(size_t)(__attribute__((address_space(3))) h16*)&stage[wave][0][0][8 * lane];
+  const uint32_t my_words = (uint32_t)(size_t)(__attribute__((address_space(3))) h16*)&stage[wave][0][0][0] + 128u * (uint32_t)hf + 4u * (uint32_t)c;
   auto arrived = [&](int buf) __attribute__((always_inline)) {
     // loads return in order: at most the 2 KS0 loads of the YOUNGER request may still be in flight (stores only make this wait
     // longer); every iteration issues exactly one request, so the count is the same everywhere
+    if constexpr (LAYOUT == 2) {
+      // slot s (1 KB) = [pos 0..7][32 rows] words; word j of the lane = plane 8 ks + 4 hf + j = pos 2 j + hf: 256 j + 128 hf + 4 c bytes in
+      const uint32_t a0 = my_words + (uint32_t)buf * (2 * KS0 * 1024);
+      u32x2 lo[2 * KS0], hi[2 * KS0];
+      if constexpr (KS0 == 2)
+        asm volatile("s_waitcnt vmcnt(4)\n\t"
+                     "ds_read2_b32 %0, %8 offset1:64\n\tds_read2_b32 %1, %8 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %2, %9 offset1:64\n\tds_read2_b32 %3, %9 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %4, %10 offset1:64\n\tds_read2_b32 %5, %10 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %6, %11 offset1:64\n\tds_read2_b32 %7, %11 offset0:128 offset1:192\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+                     : "v"(a0), "v"(a0 + 1024u), "v"(a0 + 2048u), "v"(a0 + 3072u) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(6)\n\t"
+                     "ds_read2_b32 %0, %12 offset1:64\n\tds_read2_b32 %1, %12 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %2, %13 offset1:64\n\tds_read2_b32 %3, %13 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %4, %14 offset1:64\n\tds_read2_b32 %5, %14 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %6, %15 offset1:64\n\tds_read2_b32 %7, %15 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %8, %16 offset1:64\n\tds_read2_b32 %9, %16 offset0:128 offset1:192\n\t"
+                     "ds_read2_b32 %10, %17 offset1:64\n\tds_read2_b32 %11, %17 offset0:128 offset1:192\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3]),
+                       "=&v"(lo[4]), "=&v"(hi[4]), "=&v"(lo[5]), "=&v"(hi[5])
+                     : "v"(a0), "v"(a0 + 1024u), "v"(a0 + 2048u), "v"(a0 + 3072u), "v"(a0 + 4096u), "v"(a0 + 5120u) : "memory");
+#pragma unroll
+      for (int ks = 0; ks < KS0; ++ks) {
+        xA[ks] = __builtin_bit_cast(h16x8, (u32x4){lo[ks][0], lo[ks][1], hi[ks][0], hi[ks][1]});
+        xB[ks] = __builtin_bit_cast(h16x8, (u32x4){lo[KS0 + ks][0], lo[KS0 + ks][1], hi[KS0 + ks][0], hi[KS0 + ks][1]});
+      }
+      return;
+    }
     const uint32_t at = my_slot + (uint32_t)buf * (2 * KS0 * 1024);
     if constexpr (KS0 == 2)
       asm volatile("s_waitcnt vmcnt(4)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
@@ -235,9 +287,13 @@ void k_mlp_fwd128(const h16* __restrict__ wf, const h16* __restrict__ x, int row
 int aln_launch_fwd128(const AlnMlpDesc* m, const void* x, int rows, const int* rows_dev, void* out, float* sigma, hipStream_t s) {
   if (m->hidden != 128 || m->n_hidden != 2 || m->out_pad != 16 || (m->in_pad != 32 && m->in_pad != 48)) return -3;
   const int pairs = (rows + 63) / 64, g = min(256, (pairs + 3) / 4);
-#define ALN_F128(KS0, T) hipLaunchKernelGGL((k_mlp_fwd128<KS0, T>), dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma)
-  if (m->in_pad == 32) { if (m->x_tiled) ALN_F128(2, true); else ALN_F128(2, false); }
-  else { if (m->x_tiled) ALN_F128(3, true); else ALN_F128(3, false); }
+  if (m->x_tiled == 2 && (rows % 32 != 0 || m->x_pitch < rows || m->x_pitch % 4 != 0 || ((uintptr_t)x & 15) != 0 || rows_dev)) {
+    aln_set_error("mlp_fwd128: pair-plane input (x_tiled = 2) needs rows %% 32 == 0, x_pitch >= rows and a multiple of 4, a 16-byte aligned base");
+    return -1;
+  }
+#define ALN_F128(KS0, T) hipLaunchKernelGGL((k_mlp_fwd128<KS0, T>), dim3(g), dim3(256), 0, s, (const h16*)m->wf, (const h16*)x, rows, rows_dev, (h16*)out, sigma, (long)m->x_pitch)
+  if (m->in_pad == 32) { if (m->x_tiled == 2) ALN_F128(2, 2); else if (m->x_tiled) ALN_F128(2, 1); else ALN_F128(2, 0); }
+  else { if (m->x_tiled == 2) ALN_F128(3, 2); else if (m->x_tiled) ALN_F128(3, 1); else ALN_F128(3, 0); }
 #undef ALN_F128
   return 0;
 }

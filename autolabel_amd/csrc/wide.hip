@@ -808,9 +808,9 @@ extern "C" int aln_wide_tn_gen(const void* g, int32_t ldg, const void* geo, int3
   ALN_REQUIRE(g && dw && ws && geo && w0 && M >= 0 && N > 0, "wide_tn_gen: bad arguments");
   ALN_REQUIRE(ldg % 8 == 0 && N % 8 == 0 && K > 0 && K % 32 == 0 && lddw >= K, "wide_tn_gen: N / K / leading dimensions must be multiples of 8 / 32");
   ALN_REQUIRE(((uintptr_t)w0 & 15) == 0 && ((uintptr_t)g & 15) == 0, "wide_tn_gen: operands must be 16-byte aligned");
-  // k_wide_tn_gen is written for the 2 x 2 wave layout (128 x 256 tiles); wide_tn_split sizes the grid for 256 x 128 tiles when K <= 128,
-  // which would leave the columns [128, N) of the slabs unwritten -- such shapes have no kernel here
-  ALN_REQUIRE(!wide_tn_narrow(K), "wide_tn_gen: K = %d <= 128 is not supported (the generated-operand kernel has the 128 x 256 tile only)", K);
+  // k_wide_tn_gen has the 2 x 2 wave layout (128 x 256 tiles) only; for K <= 128 wide_tn_split sizes the grid for 256 x 128 tiles, one
+  // block per 256 output rows -- with N > 128 the columns [128, N) of the slabs would never be written
+  ALN_REQUIRE(!wide_tn_narrow(K) || N <= 128, "wide_tn_gen: N = %d > 128 with K = %d <= 128 is not supported (the generated-operand kernel has the 128 x 256 tile only)", N, K);
   if (M == 0) return 0;
   WideTN p;
   p.a = WideSrc{nullptr, 0, 0, 0, nullptr, 0};

@@ -11,7 +11,7 @@ import torch
 from .build import LIB
 
 ALN_MAX_LEVELS = 16
-ABI_VERSION = 7   # include/autolabel_hip.h: ALN_ABI_VERSION
+ABI_VERSION = 8   # include/autolabel_hip.h: ALN_ABI_VERSION
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
 
@@ -29,7 +29,7 @@ class AlnEncDesc(C.Structure):
 
 class AlnMlpDesc(C.Structure):
     _fields_ = [('in_pad', i32), ('hidden', i32), ('out_pad', i32), ('n_hidden', i32), ('wf', vp), ('wb', vp), ('wr', vp), ('dw_ws', vp),
-                ('dw_ws_bytes', i64), ('defer_dw_reduce', i32), ('x_tiled', i32)]
+                ('dw_ws_bytes', i64), ('defer_dw_reduce', i32), ('x_tiled', i32), ('x_pitch', i64)]
 
 
 class AlnAdamFuse(C.Structure):
@@ -62,6 +62,7 @@ _SIGS = {
     'aln_encode_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'aln_encode_fwd_ws_bytes': (i64, [vp, i32]),
     'aln_encode_fwd_phased': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'aln_encode_fwd_planes': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, i64, vp]),
     'aln_encode_fwd_cells': (i32, [vp, vp, i32, u32, u32, vp, i32, i32, vp, vp, vp]),
     'aln_encode_bwd_binned_ws_bytes': (i64, [vp, i32]),
     'aln_encode_bwd_binned_tile_rows': (i32, []),

@@ -75,6 +75,7 @@ class Params:
         self.table16 = torch.zeros(max(L.n_grid, 2), dtype=torch.float16, device=device)
         self.frags, self.descs, self.wide_w, self.wide_wt = {}, {}, {}, {}
         self.desc_sigma_tiled = None
+        self.desc_sigma_planes = None   # the density head reading PAIR PLANES (AlnMlpDesc.x_tiled = 2: aln_encode_fwd_planes); x_pitch is set per call
         self.wide_wp = None    # semantic_features' second matrix with the columns of every group of 16 in the order the generated first
                                # layer leaves them in (aln_wide_nt_gen, wide.hip: wide_gen_pack)
         # sharded table optimizer (engine.TrainEngine(shard_optimizer=True, shard_gather='table')): the fp32 masters of the slices other
@@ -107,6 +108,8 @@ class Params:
                 # the same head reading its input rows in the tiled layout the level-phased gather writes (AlnMlpDesc.x_tiled)
                 self.desc_sigma_tiled = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(),
                                                      ws.data_ptr(), nws, 1, 1)
+                self.desc_sigma_planes = H.AlnMlpDesc(s.in_pad, s.hidden, s.out_pad, s.n_hidden, wf.data_ptr(), wb.data_ptr(), wr.data_ptr(),
+                                                      ws.data_ptr(), nws, 1, 2, 0)
 
     def init_(self, seed=0):
         """tcnn default initialisation: grid U(-1e-4,1e-4), MLP weights xavier-uniform per padded [out,in] matrix."""
@@ -262,6 +265,10 @@ class HipPipeline:
         # eighth of it per XCD -- at the dense renderer's 8.4 M rows per launch that is more than the 4 MB L2 and the pieces leave for HBM
         # one level at a time (measured: dense render 4.8 -> 4.65 M rays/s; marching render, 2.1 M rows: 17.5 -> 18.3; training, 0.5 M: even)
         self.tiled_max_rows = 1 << 21     # rows per gather launch in tiled mode (density_rows splits larger passes into whole-ray pieces)
+        # Training (round 6): the gather leaves the density head's input as PAIR PLANES -- every level's features as the coalesced 256-byte
+        # wave stores of round 3's plane buffers, plus the frequency pairs and the ones -- and the 128-wide forward AND backward kernels read
+        # the planes themselves (AlnMlpDesc.x_tiled = 2): no k_encode_assemble pass (2 x 22 us per step, 200 MB), no second buffer.
+        self.planes_enc_train = True
         # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
         self.recompute = all(k in params.wide_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
@@ -455,9 +462,24 @@ class HipPipeline:
         return (self.tiled_enc_enabled and self.P.desc_sigma_tiled is not None and bool(self.L.enc.use_grid) and not save and
                 all(self.phased_min_rows <= r and r % 32 == 0 for r in rows_per_pass))
 
-    def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train, ws=None, tiled=False):
+    def planes_enc(self, rows_per_pass, train):
+        """True when the training step's density head reads pair planes (see planes_enc_train): level-phased gathers for every pass,
+        recompute backward (nobody else reads the rows), whole 32-row tiles per pass."""
+        return (train and self.planes_enc_train and self.P.desc_sigma_planes is not None and bool(self.L.enc.use_grid) and self.recompute and
+                sum(rows_per_pass) % 4 == 0 and all(self.phased_min_rows <= r and r % 32 == 0 for r in rows_per_pass))
+
+    def density_rows(self, rows, rays_o, rays_d, z, xyz, stride, enc, h1, h2, out, sigma, train, ws=None, tiled=False, planes=None):
         e, s = self.L.enc, self.L.nets['sigma']
         ws = self.ws if ws is None else ws
+        if planes is not None:    # (whole plane buffer [enc_pad / 2, pitch] words, first row of this pass)
+            buf, pitch, a = planes
+            at = C.c_void_p(buf.data_ptr() + 4 * a)
+            self._k('aln_encode_fwd_planes', C.byref(e), H.ptr(self.P.table16), H.ptr(rays_o), H.ptr(rays_d), H.ptr(z), H.ptr(xyz), rows, stride,
+                    at, pitch, H.stream(), tag=('enc_fwd', rows))
+            d = self.P.desc_sigma_planes
+            d.x_pitch = pitch
+            self._k('aln_density_fwd', C.byref(d), at, rows, None, None, H.ptr(out), H.ptr(sigma), H.stream(), tag=('sigma', rows))
+            return
         if tiled:
             # (launches of at most tiled_max_rows rows, whole rays each: see tiled_max_rows)
             per = max(stride, self.tiled_max_rows // (32 * stride) * (32 * stride)) if xyz is None else self.tiled_max_rows // 32 * 32
@@ -521,14 +543,18 @@ class HipPipeline:
         else:
             H.call('aln_sample_coarse', H.ptr(rays_o), H.ptr(rays_d), N, S1, e.bound, self.min_near, int(perturb), seed, step,
                    H.ptr(noise), H.ptr(c['nears']), H.ptr(c['fars']), H.ptr(z), H.ptr(step_dev), H.stream())
-        tiled = c['enc_tiled'] = self.tiled_enc([M1] + ([N * S2] if S2 > 0 else []), train)
-        self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train, ws=ws, tiled=tiled)
+        passes = [M1] + ([N * S2] if S2 > 0 else [])
+        c['enc_planes'] = self.planes_enc(passes, train)
+        tiled = c['enc_tiled'] = not c['enc_planes'] and self.tiled_enc(passes, train)
+        self.density_rows(M1, rays_o, rays_d, z, None, S1, enc, h1, h2, sout, sigma, train, ws=ws, tiled=tiled,
+                          planes=(enc, M, 0) if c['enc_planes'] else None)
         if S2 > 0:
             zf = z[M1:]
             H.call('aln_sample_fine', H.ptr(z), H.ptr(sigma), H.ptr(c['nears']), H.ptr(c['fars']), N, S1, S2,
                    self.density_scale, int(perturb), seed, step, H.ptr(u), H.ptr(zf), H.ptr(step_dev), H.stream())
             self.density_rows(N * S2, rays_o, rays_d, zf, None, S2, enc[M1:], h1[M1:] if save else h1,
-                              h2[M1:] if save else h2, sout[M1:], sigma[M1:], train, ws=ws, tiled=tiled)
+                              h2[M1:] if save else h2, sout[M1:], sigma[M1:], train, ws=ws, tiled=tiled,
+                              planes=(enc, M, M1) if c['enc_planes'] else None)
         perm = c['perm'] = g('perm', (N, S), torch.int16)
         w_row, T_row, d_row = g('w_row', (M,), f32_), g('T_row', (M,), f32_), g('delta_row', (M,), f32_)
         c.update(w_row=w_row, T_row=T_row, delta_row=d_row)
@@ -760,7 +786,10 @@ class HipPipeline:
         H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), 16 if wide else nets['semo'].in_pad,
                0 if wide else L.D, H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
         d_enc = g('d_enc', (M, e.enc_pad), f16)
-        self._k('aln_mlp_bwd', C.byref(P.desc_sigma_tiled if c.get('enc_tiled') else P.descs['sigma']), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
+        if c.get('enc_planes'):
+            P.desc_sigma_planes.x_pitch = M
+        sigma_desc = P.desc_sigma_planes if c.get('enc_planes') else P.desc_sigma_tiled if c.get('enc_tiled') else P.descs['sigma']
+        self._k('aln_mlp_bwd', C.byref(sigma_desc), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
                 H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
         if rc:   # all fused heads' weight-gradient slabs -> P.grad, one launch (fixed summation order: bit-reproducible)

@@ -58,6 +58,7 @@ def parse():
     p.add_argument('--march-thresh', type=float, default=10.0)
     p.add_argument('--no-lseg', action='store_true', help='skip the LSeg-width (512-d feature head) leg')
     p.add_argument('--no-tiled-enc', action='store_true', help='A/B: hash-grid forward through plane buffers + the assembly pass instead of the tiled layout')
+    p.add_argument('--no-planes-enc', action='store_true', help='A/B: the training step through row-major encoded rows + the assembly pass instead of the pair planes the 128-wide kernels read themselves')
     p.add_argument('--tiled-enc-train', action='store_true', help='A/B: the tiled hash-grid output in the training step too (default: rendering only)')
     p.add_argument('--no-dp1', action='store_true', help='skip the leg that runs the data-parallel forms of the step through a one-rank RCCL group')
     p.add_argument('--no-dropin', action='store_true', help="skip the leg that times the reference's own route (scene directory -> SimpleTrainer)")
@@ -123,6 +124,7 @@ class Workload:
         pipe = HipPipeline(layout, P)
         pipe.tiled_enc_enabled = not getattr(a, 'no_tiled_enc', False)
         pipe.tiled_enc_train = bool(getattr(a, 'tiled_enc_train', False))
+        pipe.planes_enc_train = not getattr(a, 'no_planes_enc', False)
         if march:
             t = self.train
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 7
+#define ALN_ABI_VERSION 8
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -66,7 +66,11 @@ typedef struct {
                        aln_encode_fwd_phased(planes_ws = NULL) writes -- tile t = rows [32 t, 32 t + 32), inside it the in_pad / 8
                        16-byte pieces of a row piece-major: piece p of row r at halves 32 in_pad t + 256 p + 8 (r % 32) -- i.e. exactly the
                        per-lane pieces the 128-wide kernels fetch (mlp_fwd128.hip, mlp_bwd128.hip).  Only those kernels read it
-                       (aln_mlp_supports_tiled); the buffer must hold whole tiles. */
+                       (aln_mlp_supports_tiled); the buffer must hold whole tiles.
+                       2 (ABI 8): PAIR PLANES -- what aln_encode_fwd_planes writes: x points at in_pad / 2 planes of 4-byte words, plane q
+                       holding features (2 q, 2 q + 1) of every row, word r of plane q at x + 4 (q x_pitch + r) bytes.  The same kernels
+                       read it (their loaders fetch whole 16-byte pieces of a plane); the forward needs rows % 32 == 0. */
+  int64_t x_pitch;  /* x_tiled = 2: words between two planes (>= the rows of the widest launch; a multiple of 4) */
 } AlnMlpDesc;
 
 const char* aln_last_error(void);
@@ -145,6 +149,13 @@ int64_t aln_encode_fwd_ws_bytes(const AlnEncDesc* e, int32_t rows);
 int aln_encode_fwd_phased(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d,
                           const float* z, const float* xyz, int32_t rows, int32_t rays_stride, void* planes_ws, void* enc_out,
                           void* stream);
+/* The level-phased gather writing the density head's input as PAIR PLANES (AlnMlpDesc.x_tiled = 2, round 6): plane q of planes_out =
+ * the fp16 pair (2 q, 2 q + 1) of every row's encoding -- enc_pad / 2 planes in row order of the features (frequency pairs, one plane
+ * per level, the ones padding), each wave's 64 rows of a plane one coalesced 256-byte store, plane_pitch words between two planes.
+ * No assembly pass and no second buffer: the 128-wide forward and backward kernels read the planes themselves.  A launch over rows
+ * [a, a + rows) of a larger batch passes planes_out + a words (both sampling passes of a step share one set of planes). */
+int aln_encode_fwd_planes(const AlnEncDesc* e, const void* table_f16, const float* rays_o, const float* rays_d, const float* z,
+                          const float* xyz, int32_t rows, int32_t rays_stride, void* planes_out, int64_t plane_pitch, void* stream);
 /* encoding of one jittered point per occupancy-grid cell, cells [cell0, cell0 + rows) of a G^3 grid over [-bound,bound]^3 (the
  * positions of aln_grid_points, generated inside the kernel): input of the density head for the density-grid refresh,
  * NeRFRenderer.update_extra_state at autolabel/trainer.py:34-36.  planes_ws != NULL selects the level-phased kernels. */

@@ -1142,6 +1142,64 @@ def test_tiled_encoding_equals_the_row_major_encoding_bit_for_bit(H, encoding, r
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize('encoding,rows', [('hg+freq', 70000), ('hg', 65536 + 32 * 7)])
+def test_pair_plane_encoding_equals_the_row_major_encoding_bit_for_bit(H, encoding, rows):
+    """aln_encode_fwd_planes (round 6) leaves the density head's input as enc_pad / 2 planes of fp16 pairs (AlnMlpDesc.x_tiled = 2: frequency
+    pairs, one plane per level, the ones padding) at a pitch LARGER than the launch and at a row OFFSET inside the planes -- how the two
+    sampling passes of a training step share one buffer; no assembly pass.  Same bits as the row-major rows, and the density head's
+    forward and backward give the same outputs, input gradients and weight-gradient slabs from either layout."""
+    from autolabel_amd.pipeline import ModelLayout, Params
+    layout = ModelLayout(encoding, 15, 128, 128, 64, 5, bound=2.0)
+    P = Params(layout, 'cuda'); P.init_(seed=0)
+    with torch.no_grad():
+        P.flat[:layout.n_grid].mul_(3e3)
+    P.refresh_shadows()
+    e = layout.enc
+    pad = int(e.enc_pad)
+    g = torch.Generator().manual_seed(0)
+    n_rays, S = rows // 32, 32
+    rows = n_rays * S
+    ro = ((torch.rand(n_rays, 3, generator=g) - 0.5) * 1.5).cuda()
+    rd = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=1).cuda()
+    z = (torch.rand(rows, generator=g) * 2.0 + 0.2).cuda()
+    scratch = torch.empty(int(H.lib().aln_encode_fwd_ws_bytes(C.byref(e), rows)), dtype=torch.uint8, device='cuda')
+    want = torch.full((rows, pad), float('nan'), dtype=torch.float16, device='cuda')
+    H.call('aln_encode_fwd_phased', C.byref(e), H.ptr(P.table16), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, H.ptr(scratch), H.ptr(want), H.stream())
+    off, pitch = 4096, rows + 4096 + 64
+    planes = torch.full((pad // 2, pitch), -1, dtype=torch.int32, device='cuda')
+    at = C.c_void_p(planes.data_ptr() + 4 * off)
+    H.call('aln_encode_fwd_planes', C.byref(e), H.ptr(P.table16), H.ptr(ro), H.ptr(rd), H.ptr(z), None, rows, S, at, pitch, H.stream())
+    got = planes[:, off:off + rows].t().contiguous().view(torch.float16).reshape(rows, pad)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    assert bool((planes[:, :off] == -1).all()) and bool((planes[:, off + rows:] == -1).all())      # nothing outside the launch's rows
+    desc = P.desc_sigma_planes
+    assert desc is not None
+    desc.x_pitch = pitch
+    outs = []
+    for d, x in ((P.descs['sigma'], H.ptr(want)), (desc, at)):
+        out = torch.full((rows, 16), float('nan'), dtype=torch.float16, device='cuda')
+        sig = torch.full((rows,), float('nan'), device='cuda')
+        H.call('aln_density_fwd', C.byref(d), x, rows, None, None, H.ptr(out), H.ptr(sig), H.stream())
+        outs.append((out, sig))
+    assert torch.isfinite(outs[1][1]).all() and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    d_out = (torch.randn(rows, 16, generator=g) * 0.01).half().cuda()
+    res = []
+    for d, x, n in ((P.descs['sigma'], H.ptr(want), rows), (desc, at, rows), (P.descs['sigma'], H.ptr(want), rows - 45), (desc, at, rows - 45)):
+        P.grad.zero_()
+        d_in = torch.full((rows, pad), float('nan'), dtype=torch.float16, device='cuda')
+        flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+        H.call('aln_mlp_bwd', C.byref(d), x, None, None, H.ptr(d_out), n, None, None, None, H.ptr(d_in),
+               C.c_void_p(P.grad.data_ptr() + 4 * layout.offsets['sigma']), H.ptr(flag), H.stream())
+        ds = (C.c_void_p * 1)(C.addressof(d)); dws = (C.c_void_p * 1)(P.grad.data_ptr() + 4 * layout.offsets['sigma'])
+        H.call('aln_mlp_dw_reduce_all', 1, ds, dws, (C.c_int32 * 1)(n), H.stream())
+        res.append((d_in[:n].clone(), P.net_view('sigma', P.grad).clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[2][0], res[3][0]) and torch.equal(res[2][1], res[3][1])      # (a ragged row count: the backward takes any)
+    # the forward wants whole 32-row tiles and says so
+    with pytest.raises(RuntimeError, match='rows % 32'):
+        H.call('aln_density_fwd', C.byref(desc), at, rows - 5, None, None, H.ptr(outs[1][0]), H.ptr(outs[1][1]), H.stream())
+
+
 def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
     """aln_encode_fwd_cells generates the jittered cell points inside the kernel: same bits as encoding aln_grid_points' output,
     for both the tile kernel and the level-phased kernels, at a cell offset."""
