@@ -149,14 +149,22 @@ __device__ inline h16x2 level_features(const EncParams& p, int l, const float* x
       uint32_t ix;
       if (dense) { ix = cx + ay[i & 1] + az[i >> 1]; ix = ix >= size ? ix - size : ix; }
       else ix = (cx ^ ay[i & 1] ^ az[i >> 1]) & (size - 1u);
+#ifdef STUB_GATHER_NOLOAD     // dev stub: no table loads
+      r[h][i] = act ? ix * 2654435761u : 0u;
+#else
       r[h][i] = act ? tab[ix] : 0u;
+#endif
     }
   }
   const int src = 2 * (hl & 31);
   float a0 = 0.f, a1 = 0.f;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {   // corner c = x | y << 1 | z << 2 ; accumulation order c = 0..7 as in the oracle
+#ifdef STUB_GATHER_NORETURN   // dev stub: no return shuffles (wrong values)
+    const uint32_t t0 = r[0][c >> 1], t1 = r[1][c >> 1];
+#else
     const uint32_t t0 = __shfl(r[0][c >> 1], src + (c & 1)), t1 = __shfl(r[1][c >> 1], src + (c & 1));
+#endif
     const uint32_t vv = (hl >> 5) ? t1 : t0;
     h16x2 hv = *(const h16x2*)&vv;
     a0 = __fadd_rn(a0, __fmul_rn(w[c], (float)hv[0]));
@@ -227,9 +235,11 @@ __global__ __launch_bounds__(256) void k_encode_fwd(EncParams p, h16* __restrict
 // `pitch` != 0 (round 6): PAIR-PLANE output for the density head itself (AlnMlpDesc.x_tiled = 2) -- level l goes to plane fdim / 2 + l at
 // `pitch` words per plane, and the phases also write the frequency pairs (planes 0 .. fdim / 2 - 1) and the ones behind the last level,
 // one pair per phase like the tiled form: every plane is written with whole-wave 256-byte stores, nothing is assembled afterwards.
+// (round 6: several consecutive 256-row pieces of a level per block -- fewer, longer blocks -- measured 149 / 167 / 245 us for 2 / 4 / 8
+//  pieces against 146 us: the 32 768 independent short blocks are what hides the gather latency)
 __global__ __launch_bounds__(256) void k_encode_grid_phased(EncParams p, h16x2* __restrict__ planes, int nblk, int lg, h16* __restrict__ tiled, long pitch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.x / nblk, b = blockIdx.x % nblk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int base_row = (b * 4 + wave) * 64;
   if (base_row >= p.rows) return;
   const int row = base_row + lane;
@@ -791,6 +801,10 @@ extern "C" int aln_debug_read_acc_timing(long long* host_out, int reset) {
 #define AT_FLUSH
 #endif
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk_max_u16(uint32_t a, uint32_t b) {   // v_pk_max_u16
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2v, a), __builtin_bit_cast(u16x2v, b)));
+}
 #define ACC_THREADS 1024
 #define ACC_LPR (BIN_TILE / 256)  // 8-byte loads per lane and run held in registers: covers the average run of a hashed level twice
 #ifndef ACC_RB
@@ -854,10 +868,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   // (a tile that was scaled DOWN carries records up to 2^(16 - shift): the double-precision conversion needs them below 2^51 units)
   { const unsigned long long bd = bound_s; const int lg = bd ? 64 - __clzll(bd) : 0; U = min(FX_UNIT_LOG2 + smin_s, 62 - lg); }   // bd < 2^lg
   const uint2* pool = a.pool + (size_t)l * a.ntiles * BIN_CHUNK;
-  uint32_t badbits = 0u;   // bit 15 / 31 set by a record whose low / high half is inf or nan (exponent all ones: + 0x0400 carries out of the field)
+  uint32_t badbits = 0u;   // largest |half| seen, as bit patterns (two packed 15-bit maxima): >= 0x7C00 = a record value was inf or nan
   auto add = [&](uint2 r, int ex) {   // ex = U - shift of the run's tile
     const h16x2 hv = *(const h16x2*)&r.y;
-    badbits |= (r.y & 0x7C007C00u) + 0x04000400u;
+    badbits = pk_max_u16(badbits, r.y & 0x7FFF7FFFu);
     atomicAdd((unsigned long long*)&acc[r.x], (unsigned long long)fx_from_half_d(hv[0], ex));
     atomicAdd((unsigned long long*)&acc[plane + r.x], (unsigned long long)fx_from_half_d(hv[1], ex));
   };
@@ -968,10 +982,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
         st[buf][u] = DESC_START(q); n[buf][u] = DESC_COUNT(q); ex[buf][u] = U - DESC_SHIFT(q);
         const uint2* src = pool + (size_t)(bt * ACC_RB + u) * BIN_CHUNK + st[buf][u];
 #pragma unroll
-        for (int v = 0; v < ACC_LPR; ++v) {
-          r[buf][ACC_LPR * u + v] = make_uint2(0u, 0u);
+        for (int v = 0; v < ACC_LPR; ++v)   // (no zero fill: consume() reads a register under the very same predicate)
           if ((uint32_t)lane + 64u * v < n[buf][u]) r[buf][ACC_LPR * u + v] = src[lane + 64 * v];
-        }
       }
     };
 #endif
@@ -1020,7 +1032,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     }
   }
 #endif
-  const bool bad = (badbits & 0x80008000u) != 0u;
+  const bool bad = (badbits & 0xFFFFu) >= 0x7C00u || (badbits >> 16) >= 0x7C00u;
   AT(8)
   __syncthreads();
   AT(9)

@@ -17,34 +17,38 @@ struct LossArgs {
 
 // ONE launch.  (a) every block counts the rays with a valid depth / a label itself (N is a batch: 4096 ... 32768 rays = a few
 // hundred KB of L2 reads per block; integer sums, so every block holds the same two numbers) -- no separate count kernel, no
-// zero-fill of counters; (b) one wavefront per ray (4 per block): every ray is a short chain of dependent loads, so the kernel is
-// latency-bound and wants as many rays in flight as the chip holds; (c) the block's four partial loss sums go to its row of the
-// scratch behind `terms`, and the LAST block to arrive (ticket in counts[2], self-resetting) adds the rows up in block order:
-// the reported loss terms are bit-reproducible and nothing needs to be zeroed before the launch.
-__global__ __launch_bounds__(256) void k_loss(LossArgs a) {
-  __shared__ float part[4][4];
-  __shared__ int cnt_s[4][2];
+// zero-fill of counters; (b) one wavefront per ray: every ray is a short chain of dependent loads, so the kernel is latency-bound
+// and wants as many rays in flight as the chip holds -- round 6: SIXTEEN waves per block (four made every wave of a 4096-ray batch
+// walk four rays one after the other behind the count loop: 20 us; now one ray per wave and one trip of the count loop);
+// (c) the block's partial loss sums go to its row of the scratch behind `terms`, and the LAST block to arrive (ticket in counts[2],
+// self-resetting) adds the rows up in block order: the reported loss terms are bit-reproducible and nothing needs to be zeroed before
+// the launch.
+#define LOSS_WAVES 16
+__global__ __launch_bounds__(64 * LOSS_WAVES) void k_loss(LossArgs a) {
+  __shared__ float part[LOSS_WAVES][4];
+  __shared__ int cnt_s[LOSS_WAVES][2];
   __shared__ int last_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float scale = a.loss_scale ? *a.loss_scale : 1.f;
   int nd = 0, ns = 0;
   {   // 16-byte loads over the aligned body of the two arrays, the tail element-wise
     const int n4 = (((uintptr_t)a.gt_depth | (uintptr_t)a.gt_sem) & 15) == 0 ? a.N / 4 : 0;
-    for (int i = threadIdx.x; i < n4; i += 256) {
+    for (int i = threadIdx.x; i < n4; i += 64 * LOSS_WAVES) {
       const float4 d4 = ((const float4*)a.gt_depth)[i]; const int4 s4 = ((const int4*)a.gt_sem)[i];
       nd += (d4.x > DEPTH_EPSILON) + (d4.y > DEPTH_EPSILON) + (d4.z > DEPTH_EPSILON) + (d4.w > DEPTH_EPSILON);
       ns += (s4.x >= 0) + (s4.y >= 0) + (s4.z >= 0) + (s4.w >= 0);
     }
-    for (int i = 4 * n4 + threadIdx.x; i < a.N; i += 256) { nd += a.gt_depth[i] > DEPTH_EPSILON; ns += a.gt_sem[i] >= 0; }
+    for (int i = 4 * n4 + threadIdx.x; i < a.N; i += 64 * LOSS_WAVES) { nd += a.gt_depth[i] > DEPTH_EPSILON; ns += a.gt_sem[i] >= 0; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { nd += __shfl_xor(nd, o); ns += __shfl_xor(ns, o); }
   if (lane == 0) { cnt_s[wave][0] = nd; cnt_s[wave][1] = ns; }
   __syncthreads();
-  nd = cnt_s[0][0] + cnt_s[1][0] + cnt_s[2][0] + cnt_s[3][0];
-  ns = cnt_s[0][1] + cnt_s[1][1] + cnt_s[2][1] + cnt_s[3][1];
+  nd = ns = 0;
+#pragma unroll
+  for (int w = 0; w < LOSS_WAVES; ++w) { nd += cnt_s[w][0]; ns += cnt_s[w][1]; }
   float t_rgb = 0, t_depth = 0, t_feat = 0, t_sem = 0;
-  for (int ray = blockIdx.x * 4 + wave; ray < a.N; ray += gridDim.x * 4) {
+  for (int ray = blockIdx.x * LOSS_WAVES + wave; ray < a.N; ray += gridDim.x * LOSS_WAVES) {
     if (lane < 3) {
       float diff = a.image[3 * (size_t)ray + lane] - a.gt_rgb[3 * (size_t)ray + lane];
       t_rgb += diff * diff;
@@ -96,7 +100,11 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     float* slot = a.terms + 8 + 4 * blockIdx.x;
-    for (int k = 0; k < 4; ++k) slot[k] = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+    for (int k = 0; k < 4; ++k) {   // (fixed order: waves 0 .. 15)
+      float t = 0.f;
+      for (int w = 0; w < LOSS_WAVES; ++w) t += part[w][k];
+      slot[k] = t;
+    }
     // publish the row, then take a ticket (release fence; the explicit wait keeps the write-back ahead of the ticket)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -109,9 +117,10 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
     // others under the HIP memory model, even though one buffer_inv happens to cover the CU's L1 on gfx950); last block only
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (threadIdx.x < gridDim.x) v = *(const float4*)(a.terms + 8 + 4 * threadIdx.x);
+    if (threadIdx.x < gridDim.x) v = *(const float4*)(a.terms + 8 + 4 * threadIdx.x);   // (gridDim.x <= LOSS_MAX_BLOCKS = 256: waves 0 .. 3 hold rows)
     v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);
-    if (lane == 0) { part[wave][0] = v.x; part[wave][1] = v.y; part[wave][2] = v.z; part[wave][3] = v.w; }
+    __syncthreads();     // (everybody has read `part` above)
+    if (lane == 0 && wave < 4) { part[wave][0] = v.x; part[wave][1] = v.y; part[wave][2] = v.z; part[wave][3] = v.w; }
     __syncthreads();
     if (threadIdx.x == 0) {
       float sum[4];
@@ -140,8 +149,8 @@ extern "C" int aln_loss_fwd_bwd(const float* image, const float* depth, const fl
   if (N <= 0) return 0;
   LossArgs a{image, depth, semantic, features, gt_rgb, gt_depth, gt_sem, gt_feat, N, C, D, Cf, w_rgb, w_depth, w_sem, w_feat,
              counts, loss_scale, g_image, g_depth, g_sem, g_feat, terms};
-  int nb = (N + 3) / 4;
-  hipLaunchKernelGGL(k_loss, dim3(nb < LOSS_MAX_BLOCKS ? nb : LOSS_MAX_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
+  int nb = (N + LOSS_WAVES - 1) / LOSS_WAVES;
+  hipLaunchKernelGGL(k_loss, dim3(nb < LOSS_MAX_BLOCKS ? nb : LOSS_MAX_BLOCKS), dim3(64 * LOSS_WAVES), 0, (hipStream_t)stream, a);
   ALN_CHECK_LAUNCH("loss");
   return 0;
 }

@@ -1918,6 +1918,33 @@ static int launch_dw(const h16* dA, int OW, const h16* X, int IW, int rows, cons
   return 0;
 }
 
+// The density head's recompute backward with its dL/dout rows ASSEMBLED BY THE KERNEL'S LOADER from their three producers (round 6: no
+// aln_assemble_grads pass, no d_sigma_out buffer): row r = [ d_h0[r] | d_semf_in[r][0..G) + d_color_in[cidx_row[r]][16 .. 16 + G) ], the
+// colour term only where cidx_row[r] >= 0 -- the arithmetic of aln_assemble_grads with d_semo_in = NULL (the fused semantic pair has folded
+// its skip connection into d_semf_in).  128-wide two-hidden-layer head with 48 inputs and 16 outputs only (returns -3 otherwise).
+extern "C" int aln_mlp_bwd_dso(const AlnMlpDesc* m, const void* x, const float* d_h0, const void* d_semf_in, const void* d_color_in,
+                               const int32_t* cidx_row, int32_t G, int32_t rows, void* d_in, float* dW, int32_t* found_inf, void* stream) {
+  ALN_REQUIRE(m && x && d_h0 && d_semf_in && d_color_in && cidx_row && m->wb && m->wf, "mlp_bwd_dso: NULL pointer");
+  ALN_REQUIRE(G >= 0 && G <= 15, "mlp_bwd_dso: G = %d out of range", G);
+  if (m->hidden != 128 || m->n_hidden != 2 || m->out_pad != 16 || m->in_pad != 48) return -3;
+  if (rows <= 0) return 0;
+  const int g = bwd_recomp_blocks(m, rows);
+  const MlpLayers LL = mlp_layers(m->in_pad, m->hidden, m->out_pad, m->n_hidden);
+  const int n_w = (int)(LL.w_off[LL.n - 1] + (size_t)LL.in_[LL.n - 1] * LL.out_[LL.n - 1]);
+  ALN_REQUIRE(!dW || (m->dw_ws && (size_t)m->dw_ws_bytes >= (size_t)g * n_w * sizeof(float)),
+              "mlp_bwd_dso: AlnMlpDesc.dw_ws must hold %d slabs of %d floats (aln_mlp_dw_ws_bytes)", g, n_w);
+  float* ws = dW ? (float*)m->dw_ws : nullptr;
+  const AlnDsoSrc dso{d_h0, d_semf_in, d_color_in, cidx_row, G};
+  const int rc = aln_launch_bwd128(m, x, nullptr, rows, nullptr, d_in, ws, g, found_inf, (hipStream_t)stream, &dso);
+  if (rc) return rc;
+  ALN_CHECK_LAUNCH("mlp_bwd128_dso");
+  if (ws && !m->defer_dw_reduce) {
+    hipLaunchKernelGGL(k_dw_reduce, dim3((n_w + DWR_E - 1) / DWR_E), dim3(DWR_G * DWR_E), 0, (hipStream_t)stream, ws, g, n_w, dW);
+    ALN_CHECK_LAUNCH("dw_reduce");
+  }
+  return 0;
+}
+
 extern "C" int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out,
                            int32_t rows, const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW,
                            int32_t* found_inf, void* stream) {

@@ -113,11 +113,16 @@ __device__ long long g_ph128[32];
 #define PT_FLUSH
 #endif
 
-template <int IN, int LAYOUT>   // LAYOUT = AlnMlpDesc.x_tiled: 0 row-major x rows, 1 tiled, 2 pair planes `pitch` words apart (compile-time: see mlp_fwd128.hip)
+// DSO (round 6, the density head in the training step): the dL/dout rows do not exist in memory -- the loader builds row r itself from
+// its three producers, exactly as k_assemble_dsigma_out (heads.hip) did in a pass of its own (28 us, 100 MB per step):
+//   [ d_h0[r] | d_semf_in[r][0..G) + d_color_in[cidx[r]][16 .. 16 + G) ]     (autolabel/models.py:175-188: sigma = h0, geo_feat = h[1:])
+// fp32 sums in the same order, one rounding to fp16, zeros from column G + 1 on; a value beyond the fp16 range raises found_inf.
+struct DsoSrc { const float* d_h0; const h16* d_semf; const h16* d_color; const int* cidx; int G; };
+template <int IN, int LAYOUT, bool DSO>   // LAYOUT = AlnMlpDesc.x_tiled: 0 row-major x rows, 1 tiled, 2 pair planes `pitch` words apart (compile-time: see mlp_fwd128.hip)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, const h16* __restrict__ x_g,
                   const h16* __restrict__ do_g, int rows, const int* __restrict__ rows_dev, h16* __restrict__ d_in,
-                  float* __restrict__ dw_ws, int* __restrict__ found_inf, long pitch) {
+                  float* __restrict__ dw_ws, int* __restrict__ found_inf, long pitch, DsoSrc dso) {
   constexpr bool XT = LAYOUT == 1;
   constexpr int KS0 = IN / 16, IB = (IN + 31) / 32, PX = px_pitch(IN);
   constexpr int XCH = IN / 8, NXS = (TR * XCH + 255) / 256;
@@ -168,9 +173,28 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
       }
     }
   };
+  h16x8 pc;                 // DSO: the colour head's chunk of the row (requested a phase after the row's compact index)
+  int pci = -1; float ph0 = 0.f;
+  h16x2 nanz = {0, 0};
   auto prefetch_o = [&](int r0) __attribute__((always_inline)) {
     const int r = threadIdx.x >> 1, k = threadIdx.x & 1;
-    if (r0 + r < rows) po = *(const h16x8*)(do_g + (size_t)(r0 + r) * OUT + 8 * k);
+    if constexpr (DSO) {
+      pci = -1;
+      if (r0 + r < rows) {
+        const int m = r0 + r;
+        po = *(const h16x8*)(dso.d_semf + (size_t)m * 16 + 8 * k);      // (chunk k of the semantic pair's d_semf_in row)
+        pci = dso.cidx[m];
+        if (k == 0) ph0 = dso.d_h0[m];
+      }
+    } else {
+      if (r0 + r < rows) po = *(const h16x8*)(do_g + (size_t)(r0 + r) * OUT + 8 * k);
+    }
+  };
+  auto prefetch_o2 = [&]() __attribute__((always_inline)) {   // DSO: the dependent load, one phase later (its index has arrived: no stall)
+    if constexpr (DSO) {
+      const int k = threadIdx.x & 1;
+      if (pci >= 0) pc = *(const h16x8*)(dso.d_color + (size_t)pci * 32 + 16 + 8 * k);
+    }
   };
   auto stash_x = [&](int r0, lds_h16* tX) __attribute__((always_inline)) {
     const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -183,7 +207,24 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   auto stash_o = [&](int r0) __attribute__((always_inline)) {
     const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     const int r = threadIdx.x >> 1, k = threadIdx.x & 1;
-    *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = (r0 + r < rows) ? po : z;
+    if constexpr (DSO) {
+      // s[j] = geo_feat gradient 8 k + j; the output row is shifted by one column (column 0 = d_h0): this thread writes columns
+      // 8 k .. 8 k + 7 = [d_h0 | left neighbour's s[7]], s[0..6]
+      float sv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sv[j] = (float)po[j]; if (pci >= 0) sv[j] += (float)pc[j]; }
+      const float left7 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[7]), 0xA0 /* quad_perm [0,0,2,2] */, 0xF, 0xF, true));
+      h16x8 o;
+      o[0] = k == 0 ? (h16)ph0 : (8 <= dso.G ? (h16)left7 : (h16)0.f);
+#pragma unroll
+      for (int j = 1; j < 8; ++j) o[j] = (8 * k + j <= dso.G) ? (h16)sv[j - 1] : (h16)0.f;
+      const u32x4 ow = __builtin_bit_cast(u32x4, o);
+      if (r0 + r < rows)
+        nanz = nan_fold(__builtin_bit_cast(h16x2, ow[0]), nan_fold(__builtin_bit_cast(h16x2, ow[1]), nan_fold(__builtin_bit_cast(h16x2, ow[2]),
+                        nan_fold(__builtin_bit_cast(h16x2, ow[3]), nanz))));
+      *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = (r0 + r < rows) ? o : z;
+    } else
+      *(LDS_VEC(h16x8)*)(tO + r * PO + 8 * k) = (r0 + r < rows) ? po : z;
   };
 
   f32x16 dwl, dwm[4], dwf[IB];
@@ -193,7 +234,6 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
   for (int b = 0; b < 4; ++b) dwm[b] = zero16;
 #pragma unroll
   for (int b = 0; b < IB; ++b) dwf[b] = zero16;
-  h16x2 nanz = {0, 0};
 #define SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
 
   // A fragments of the register chain come from an LDS tile through a ring of RING slots, requested DEPTH steps ahead: one wave
@@ -207,10 +247,10 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
 
   PT_DECL
   if ((int)blockIdx.x < ntiles) {
-    prefetch_x(blockIdx.x * TR); prefetch_o(blockIdx.x * TR);
+    prefetch_x(blockIdx.x * TR); prefetch_o(blockIdx.x * TR); prefetch_o2();
     __syncthreads();                       // zero fill done
     stash_x(blockIdx.x * TR, tXb); stash_o(blockIdx.x * TR);
-    { const int nt = blockIdx.x + gridDim.x; if (nt < ntiles) { prefetch_x(nt * TR); prefetch_o(nt * TR); } }
+    { const int nt = blockIdx.x + gridDim.x; if (nt < ntiles) { prefetch_x(nt * TR); prefetch_o(nt * TR); prefetch_o2(); } }
     __syncthreads();
     {   // first layer of the first tile (every later one runs inside phase D of the tile before)
       f32x16 acc[4];
@@ -405,6 +445,7 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
 #pragma unroll
       for (int ks = 0; ks < DEPTH; ++ks) req(ks);
       req_w(0);
+      if (more && nt2 < ntiles) prefetch_o2();   // (DSO: the colour chunk of the tile whose first loads went out in phase C)
       if (more) {
         if (KS0 > 1) {
 #pragma unroll
@@ -503,22 +544,24 @@ void k_mlp_bwd128(const h16* __restrict__ wf_g, const h16* __restrict__ wb_g, co
 
 template <int IN>
 static int launch(const AlnMlpDesc* m, const h16* x, const h16* d_out, int rows, const int* rows_dev, void* d_in, float* ws, int g,
-           int* found_inf, hipStream_t s) {
+           int* found_inf, hipStream_t s, const DsoSrc* dso) {
   constexpr int PX = px_pitch(IN);
   constexpr int IB = (IN + 31) / 32;
   constexpr size_t lds = (2 * (size_t)TR * PX + (size_t)TR * PO + 64 + 3 * (size_t)HID * PH + (size_t)IB * KS * 512) * 2;   // + 64 halves: the transposed reads of the last row run past it
   static_assert(lds <= 160 * 1024, "LDS");
-#define ALN_B128(T)                                                                                                                         \
+#define ALN_B128(T, D)                                                                                                                      \
   do {                                                                                                                                      \
-    hipFuncSetAttribute((const void*)k_mlp_bwd128<IN, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-    hipLaunchKernelGGL((k_mlp_bwd128<IN, T>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev,   \
-                       (h16*)d_in, ws, found_inf, (long)m->x_pitch);                                                                        \
+    hipFuncSetAttribute((const void*)k_mlp_bwd128<IN, T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+    hipLaunchKernelGGL((k_mlp_bwd128<IN, T, D>), dim3(g), dim3(256), lds, s, (const h16*)m->wf, (const h16*)m->wb, x, d_out, rows, rows_dev, \
+                       (h16*)d_in, ws, found_inf, (long)m->x_pitch, dso ? *dso : DsoSrc{});                                                 \
   } while (0)
-  if (m->x_tiled == 2) {
-    if (m->x_pitch < rows || ((uintptr_t)x & 3) != 0) { aln_set_error("mlp_bwd128: pair-plane input (x_tiled = 2) needs x_pitch >= rows"); return -1; }
-    ALN_B128(2);
-  } else if (m->x_tiled) ALN_B128(1);
-  else ALN_B128(0);
+  if (m->x_tiled == 2 && (m->x_pitch < rows || ((uintptr_t)x & 3) != 0)) { aln_set_error("mlp_bwd128: pair-plane input (x_tiled = 2) needs x_pitch >= rows"); return -1; }
+  if (dso) {
+    if constexpr (IN == 48) { if (m->x_tiled == 2) ALN_B128(2, true); else if (m->x_tiled) ALN_B128(1, true); else ALN_B128(0, true); }
+    else return -3;
+  } else if (m->x_tiled == 2) ALN_B128(2, false);
+  else if (m->x_tiled) ALN_B128(1, false);
+  else ALN_B128(0, false);
 #undef ALN_B128
   return 0;
 }
@@ -534,11 +577,13 @@ extern "C" int aln_debug_read_phases128(long long* host_out, int reset) {
 // (NULL: no weight gradients), g = aln_mlp_bwd_blocks.  Returns -3 when the shape has no instantiation (a 64-wide input --
 // the 'freq' encoding -- does not fit the LDS budget with a double-buffered x tile: it stays on k_mlp_bwd_recomp8).
 int aln_launch_bwd128(const AlnMlpDesc* m, const void* x, const void* d_out, int rows, const int* rows_dev, void* d_in, float* ws,
-                      int g, int* found_inf, hipStream_t s) {
+                      int g, int* found_inf, hipStream_t s, const AlnDsoSrc* dso_in) {
   if (m->hidden != 128 || m->n_hidden != 2 || m->out_pad != 16) return -3;
+  DsoSrc dso_v, *dso = nullptr;
+  if (dso_in) { dso_v = DsoSrc{dso_in->d_h0, (const h16*)dso_in->d_semf_in, (const h16*)dso_in->d_color_in, dso_in->cidx_row, dso_in->G}; dso = &dso_v; }
   switch (m->in_pad) {
-    case 32: return launch<32>(m, (const h16*)x, (const h16*)d_out, rows, rows_dev, d_in, ws, g, found_inf, s);
-    case 48: return launch<48>(m, (const h16*)x, (const h16*)d_out, rows, rows_dev, d_in, ws, g, found_inf, s);
+    case 32: return launch<32>(m, (const h16*)x, (const h16*)d_out, rows, rows_dev, d_in, ws, g, found_inf, s, dso);
+    case 48: return launch<48>(m, (const h16*)x, (const h16*)d_out, rows, rows_dev, d_in, ws, g, found_inf, s, dso);
     default: return -3;
   }
 }

@@ -146,7 +146,9 @@ __device__ inline float half_sum32(float v) {
   return v + __shfl_xor(v, 16);
 }
 // mlp_bwd128.hip: recompute backward of the 128-wide heads (plain x / dL/dout rows); -3 = shape not instantiated
+// dso != NULL: the dL/dout rows are assembled by the kernel's own loader from their three producers (the density head of the training step)
+struct AlnDsoSrc { const float* d_h0; const void* d_semf_in; const void* d_color_in; const int* cidx_row; int G; };
 int aln_launch_bwd128(const AlnMlpDesc* m, const void* x, const void* d_out, int rows, const int* rows_dev, void* d_in, float* ws,
-                      int g, int* found_inf, hipStream_t s);
+                      int g, int* found_inf, hipStream_t s, const AlnDsoSrc* dso = nullptr);
 // mlp_fwd128.hip: forward of the 128-wide heads over plain rows, weights resident in registers; -3 = shape not instantiated
 int aln_launch_fwd128(const AlnMlpDesc* m, const void* x, int rows, const int* rows_dev, void* out, float* sigma, hipStream_t s);

@@ -93,6 +93,7 @@ _SIGS = {
     'aln_mlp_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_density_fwd': (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     'aln_mlp_bwd': (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'aln_mlp_bwd_dso': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     'aln_sem_heads_fwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     'aln_sem_heads_fwd_sums': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     'aln_sem_heads_bwd': (i32, [vp] * 7 + [i32] * 7 + [vp] * 4 + [i32] + [vp] * 3),

@@ -269,6 +269,7 @@ class HipPipeline:
         # wave stores of round 3's plane buffers, plus the frequency pairs and the ones -- and the 128-wide forward AND backward kernels read
         # the planes themselves (AlnMlpDesc.x_tiled = 2): no k_encode_assemble pass (2 x 22 us per step, 200 MB), no second buffer.
         self.planes_enc_train = True
+        self.fold_dsigma = True          # (bench.py --no-fold-dsigma: A/B against the aln_assemble_grads pass)
         # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
         self.recompute = all(k in params.wide_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
@@ -781,16 +782,24 @@ class HipPipeline:
             d_fin = g('d_semf_in', (M, fs.in_pad), f16)
             H.call('aln_mlp_bwd', C.byref(P.descs['semf']), H.ptr(c['semf_in']), hp(c['fh1']), hp(c['fh2']), H.ptr(d_feat), M,
                    None, H.ptr(dA1), H.ptr(dA2), H.ptr(d_fin), gp('semf'), fi, H.stream())
-        d_sout = g('d_sigma_out', (M, 16), f16)
         wide = sem and c.get('sem_wide') and not lin   # the wide path hands over the 16 geo columns of d(semo_in) only
-        H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), 16 if wide else nets['semo'].in_pad,
-               0 if wide else L.D, H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
         d_enc = g('d_enc', (M, e.enc_pad), f16)
         if c.get('enc_planes'):
             P.desc_sigma_planes.x_pitch = M
         sigma_desc = P.desc_sigma_planes if c.get('enc_planes') else P.desc_sigma_tiled if c.get('enc_tiled') else P.descs['sigma']
-        self._k('aln_mlp_bwd', C.byref(sigma_desc), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
-                H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
+        # the density head's dL/dout rows [d_h0 | d(geo_feat) of the semantic pair + of the colour head] are built by its backward kernel's
+        # own loader (aln_mlp_bwd_dso) where that kernel exists: no aln_assemble_grads pass, no d_sigma_out buffer
+        dso = (self.fold_dsigma and rc and d_fin is not None and d_oin is None and nets['semf'].in_pad == 16 and cs.in_pad == 32 and
+               nets['sigma'].in_pad == 48 and nets['sigma'].hidden == 128 and nets['sigma'].n_hidden == 2)
+        if dso:
+            self._k('aln_mlp_bwd_dso', C.byref(sigma_desc), H.ptr(c['enc']), H.ptr(d_h0), H.ptr(d_fin), H.ptr(d_cin), H.ptr(c['cidx_row']), L.G, M,
+                    H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
+        else:
+            d_sout = g('d_sigma_out', (M, 16), f16)
+            H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_fin), nets['semf'].in_pad, H.ptr(d_oin), 16 if wide else nets['semo'].in_pad,
+                   0 if wide else L.D, H.ptr(d_cin), cs.in_pad, H.ptr(c['cidx_row']), M, L.G, H.ptr(d_sout), fi, H.stream())
+            self._k('aln_mlp_bwd', C.byref(sigma_desc), H.ptr(c['enc']), hp(c['h1']), hp(c['h2']), H.ptr(d_sout), M, None,
+                    H.ptr(dA1), H.ptr(dA2), H.ptr(d_enc), gp('sigma'), fi, H.stream(), tag=('sigma', M))
         ro, rd, z = c['rays_o'], c['rays_d'], c['z']
         if rc:   # all fused heads' weight-gradient slabs -> P.grad, one launch (fixed summation order: bit-reproducible)
             heads = [k for k in ('color', 'semf', 'semo', 'sigma') if k in P.descs and (sem or k in ('color', 'sigma'))]

@@ -50,6 +50,7 @@ def parse():
     p.add_argument('--render-frames', type=int, default=6)
     p.add_argument('--event-steps', type=int, default=20, help='launch-by-launch steps with HIP events (roofline); 0 = skip')
     p.add_argument('--quality-steps', type=int, default=1500, help='total optimizer steps before the held-out metrics; 0 = skip')
+    p.add_argument('--trained-steps', type=int, default=200, help='replays timed again AFTER the quality schedule (the `trained` sub-leg); 0 = skip')
     p.add_argument('--quality-seeds', type=int, default=3, help='runs (seed sets) the reported quality is the mean / min over')
     p.add_argument('--dp-leg-timeout', type=float, default=300.0, help='--gpus N: seconds a data-parallel leg may take before the watchdog prints the best finished leg and exits')
     p.add_argument('--dp-tail-timeout', type=float, default=1200.0, help='--gpus N: the same for everything after the legs')
@@ -59,6 +60,7 @@ def parse():
     p.add_argument('--no-lseg', action='store_true', help='skip the LSeg-width (512-d feature head) leg')
     p.add_argument('--no-tiled-enc', action='store_true', help='A/B: hash-grid forward through plane buffers + the assembly pass instead of the tiled layout')
     p.add_argument('--no-planes-enc', action='store_true', help='A/B: the training step through row-major encoded rows + the assembly pass instead of the pair planes the 128-wide kernels read themselves')
+    p.add_argument('--no-fold-dsigma', action='store_true', help="A/B: the density head's dL/dout rows through aln_assemble_grads instead of the backward kernel's own loader")
     p.add_argument('--tiled-enc-train', action='store_true', help='A/B: the tiled hash-grid output in the training step too (default: rendering only)')
     p.add_argument('--no-dp1', action='store_true', help='skip the leg that runs the data-parallel forms of the step through a one-rank RCCL group')
     p.add_argument('--no-dropin', action='store_true', help="skip the leg that times the reference's own route (scene directory -> SimpleTrainer)")
@@ -125,6 +127,7 @@ class Workload:
         pipe.tiled_enc_enabled = not getattr(a, 'no_tiled_enc', False)
         pipe.tiled_enc_train = bool(getattr(a, 'tiled_enc_train', False))
         pipe.planes_enc_train = not getattr(a, 'no_planes_enc', False)
+        pipe.fold_dsigma = not getattr(a, 'no_fold_dsigma', False)
         if march:
             t = self.train
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)
@@ -854,9 +857,23 @@ def main():
 
     # quality of the trained state: continue to --quality-steps optimizer steps, held-out metrics, then the other seed sets
     quality = None
+    trained = None
     if args.quality_steps > 0:
         train_schedule(eng, step, done, args.quality_steps)
         sync()
+        if world == 1 and use_graph and args.trained_steps > 0:
+            # the metric is "rays/s at fixed PSNR / mIoU": the same step timed again AT the trained state the quality numbers describe
+            # (the density field has sharpened: fewer live colour rows, zero-weight records dropped by the scatter).  These replays train
+            # on, like any others; the held-out metrics below are taken after them.
+            t0 = time.time()
+            for _ in range(args.trained_steps):
+                step()
+            sync()
+            dt_tr = time.time() - t0
+            live_tr = float(eng.ws.get('n_live', (1,), torch.int32).item())
+            trained = {'value': B * args.trained_steps / dt_tr, 'unit': 'rays/s', 'ms_per_step': 1000 * dt_tr / args.trained_steps, 'steps': args.trained_steps,
+                       'timed_state': 'trained: steps %d..%d (after the quality schedule)' % (done[0] - args.trained_steps, done[0]),
+                       'live_row_fraction': live_tr / float(B * (eng.S1 + eng.S2))}
         if rank == 0:
             q = heldout_metrics(wl.renderer(eng, False), wl.test, wl.n_classes)
             q.update(steps=done[0], adam_steps_applied=int(eng.state_i[0].item()))
@@ -882,6 +899,7 @@ def main():
             'n_ranks_seen': n_ranks_seen, 'dp_legs': dp_legs,
             'loss_terms_last_timed_step': dict(zip(('rgb', 'depth', 'feature', 'semantic', 'total'), terms)),
             'quality': quality,
+            'trained': trained,
         }
         if roof:
             res['roofline'] = roof

@@ -226,6 +226,13 @@ int aln_mlp_supports_tiled(int32_t in_pad, int32_t hidden, int32_t out_pad, int3
 int aln_mlp_has_recompute(int32_t in_pad, int32_t hidden, int32_t out_pad, int32_t n_hidden);
 int aln_mlp_bwd(const AlnMlpDesc* m, const void* x, const void* h1, const void* h2, const void* d_out, int32_t rows,
                 const int32_t* rows_dev, void* dA1, void* dA2, void* d_in, float* dW, int32_t* found_inf, void* stream);
+/* aln_mlp_bwd (recompute) of the DENSITY head with its dL/dout rows assembled inside the kernel's loader (ABI 8): row r =
+ * [ d_h0[r] | d_semf_in[r][0 .. G) + d_color_in[cidx_row[r]][16 .. 16 + G) ] (the colour term where cidx_row[r] >= 0), fp32 sums rounded
+ * once to fp16 -- what aln_assemble_grads(d_semo_in = NULL) writes into d_sigma_out (autolabel/models.py:175-188: the density head's
+ * output row is [sigma logit | geo_feat], and geo_feat feeds the colour and the semantic heads); that pass and its buffer are not
+ * needed.  d_semf_in [rows, 16] f16, d_color_in [live rows, 32] f16, 128-wide head with 48 inputs only (-3 otherwise). */
+int aln_mlp_bwd_dso(const AlnMlpDesc* m, const void* x, const float* d_h0, const void* d_semf_in, const void* d_color_in,
+                    const int32_t* cidx_row, int32_t G, int32_t rows, void* d_in, float* dW, int32_t* found_inf, void* stream);
 /* deferred weight-gradient reduction (AlnMlpDesc.defer_dw_reduce): dW[k] += sum of the slabs head k's last recompute backward
  * over rows[k] rows left in its dw_ws, all heads in ONE launch; aln_mlp_bwd_blocks = the number of slabs (the backward's grid) */
 int32_t aln_mlp_bwd_blocks(const AlnMlpDesc* m, int32_t rows);

@@ -1200,6 +1200,60 @@ def test_pair_plane_encoding_equals_the_row_major_encoding_bit_for_bit(H, encodi
         H.call('aln_density_fwd', C.byref(desc), at, rows - 5, None, None, H.ptr(outs[1][0]), H.ptr(outs[1][1]), H.stream())
 
 
+@pytest.mark.parametrize('rows,G', [(128 * 300 + 77, 15), (4096, 9)])
+def test_density_backward_assembles_its_output_gradient_rows_itself(H, rows, G):
+    """aln_mlp_bwd_dso (round 6): the density head's backward builds its dL/dout rows [d_h0 | d geo_feat of the semantic pair + of the colour
+    head] in its own loader.  Same bits as aln_assemble_grads followed by aln_mlp_bwd -- input gradients, weight-gradient slabs, and the
+    overflow flag when an assembled value leaves the fp16 range."""
+    from autolabel_amd.pipeline import ModelLayout, Params
+    layout = ModelLayout('hg+freq', G, 128, 128, 64, 5, bound=2.0)
+    P = Params(layout, 'cuda'); P.init_(seed=0)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(rows, 48, generator=g) * 0.5).half().cuda()
+    d_h0 = (torch.randn(rows, generator=g) * 0.02).cuda()
+    d_semf = (torch.randn(rows, 16, generator=g) * 0.02).half().cuda()
+    live = torch.rand(rows, generator=g) > 0.3
+    n_live = int(live.sum())
+    cidx = torch.full((rows,), -1, dtype=torch.int32)
+    cidx[live] = torch.arange(n_live, dtype=torch.int32)
+    cidx = cidx.cuda()
+    d_cin = (torch.randn(n_live, 32, generator=g) * 0.02).half().cuda()
+    desc = P.descs['sigma']
+    gp = C.c_void_p(P.grad.data_ptr() + 4 * layout.offsets['sigma'])
+
+    def reduce_():
+        ds = (C.c_void_p * 1)(C.addressof(desc)); dws = (C.c_void_p * 1)(P.grad.data_ptr() + 4 * layout.offsets['sigma'])
+        H.call('aln_mlp_dw_reduce_all', 1, ds, dws, (C.c_int32 * 1)(rows), H.stream())
+
+    def two_pass(d_semf_, flag):
+        d_sout = torch.full((rows, 16), float('nan'), dtype=torch.float16, device='cuda')
+        H.call('aln_assemble_grads', H.ptr(d_h0), H.ptr(d_semf_), 16, None, 80, 64, H.ptr(d_cin), 32, H.ptr(cidx), rows, G, H.ptr(d_sout), H.ptr(flag), H.stream())
+        P.grad.zero_()
+        d_in = torch.full((rows, 48), float('nan'), dtype=torch.float16, device='cuda')
+        H.call('aln_mlp_bwd', C.byref(desc), H.ptr(x), None, None, H.ptr(d_sout), rows, None, None, None, H.ptr(d_in), gp, H.ptr(flag), H.stream())
+        reduce_()
+        return d_in, P.net_view('sigma', P.grad).clone()
+
+    def fused(d_semf_, flag):
+        P.grad.zero_()
+        d_in = torch.full((rows, 48), float('nan'), dtype=torch.float16, device='cuda')
+        H.call('aln_mlp_bwd_dso', C.byref(desc), H.ptr(x), H.ptr(d_h0), H.ptr(d_semf_), H.ptr(d_cin), H.ptr(cidx), G, rows, H.ptr(d_in), gp, H.ptr(flag), H.stream())
+        reduce_()
+        return d_in, P.net_view('sigma', P.grad).clone()
+
+    f0, f1 = torch.zeros(1, dtype=torch.int32, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+    a, b = two_pass(d_semf, f0), fused(d_semf, f1)
+    assert torch.isfinite(b[0]).all() and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert int(f0.item()) == 0 and int(f1.item()) == 0
+    # an assembled column beyond the fp16 range (two large halves adding up) raises the flag on both routes
+    big = d_semf.clone(); big[rows // 2, 3] = 60000.0
+    d_cin[int(cidx[rows // 2].item()) if int(cidx[rows // 2].item()) >= 0 else 0, 16 + 3] = 60000.0
+    if int(cidx[rows // 2].item()) >= 0:
+        two_pass(big, f0); fused(big, f1)
+        torch.cuda.synchronize()
+        assert int(f0.item()) == 1 and int(f1.item()) == 1
+
+
 def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
     """aln_encode_fwd_cells generates the jittered cell points inside the kernel: same bits as encoding aln_grid_points' output,
     for both the tile kernel and the level-phased kernels, at a cell offset."""
