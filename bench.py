@@ -238,18 +238,24 @@ def quality_runs(wl, args, first, march):
 
 
 def oracle_gate_record():
-    """HIP-vs-oracle quality deltas of the matched-quality gate, read from the COMMITTED record of its last multi-seed run
-    (profiles/r05_quality_gate_5x5.json, written by scripts/dev/quality_gate_run.py = tests/test_gpu_quality.run_gate with 5 + 5 seeds):
-    the oracle trainees are far too slow to run inside a bench; this only carries their numbers next to the bench's own quality."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r05_quality_gate_5x5.json')
-    try:
-        r = json.load(open(path))
-    except Exception:
-        return None
-    return {'source': 'profiles/r05_quality_gate_5x5.json (committed record, not measured in this run)',
-            'delta_psnr_db': r.get('delta_psnr_db'), 'delta_miou_pt': r.get('delta_miou_pt'), 'se_delta_psnr_db': r.get('se_delta_psnr_db'),
-            'se_delta_miou_pt': r.get('se_delta_miou_pt'), 'n_hip_runs': len(r.get('hip', [])), 'n_oracle_runs': len(r.get('oracle_runs', [])),
-            'two_sided_ok': r.get('two_sided_ok'), 'gate_model': r.get('model'), 'gate_scene': r.get('scene')}
+    """HIP-vs-oracle quality deltas of the matched-quality gate, read from the COMMITTED records of its last multi-seed runs
+    (scripts/dev/quality_gate_run.py = tests/test_gpu_quality.run_gate): profiles/r05_quality_gate_5x5.json (5 + 5 seeds on the reduced
+    gate model) and profiles/r06_quality_gate_benchmodel.json (3 + 3 seeds at the BENCH's own model: L = 16, T = 2^19, 128 + 128 samples).
+    The oracle trainees are far too slow to run inside a bench; this only carries their numbers next to the bench's own quality."""
+    def rec(name):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', name)
+        try:
+            r = json.load(open(path))
+        except Exception:
+            return None
+        return {'source': 'profiles/%s (committed record, not measured in this run)' % name,
+                'delta_psnr_db': r.get('delta_psnr_db'), 'delta_miou_pt': r.get('delta_miou_pt'), 'se_delta_psnr_db': r.get('se_delta_psnr_db'),
+                'se_delta_miou_pt': r.get('se_delta_miou_pt'), 'n_hip_runs': len(r.get('hip', [])), 'n_oracle_runs': len(r.get('oracle_runs', [])),
+                'two_sided_ok': r.get('two_sided_ok'), 'gate_model': r.get('model'), 'gate_scene': r.get('scene')}
+    out = rec('r05_quality_gate_5x5.json')
+    if out is not None:
+        out['bench_model'] = rec('r06_quality_gate_benchmodel.json')
+    return out
 
 
 def scatter_roofline(eng, events, rows_per_step, n_event_steps):
@@ -271,18 +277,18 @@ def scatter_roofline(eng, events, rows_per_step, n_event_steps):
     records = eng.pipe.binned_record_count(rows_per_step, ws=eng.ws)   # records of the last launch (same state as the events)
     rec_bytes = 2 * 8 * records if records else None                  # written once by phase 1, read once by phase 2
     return {'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair' + ("; the table's Adam step inside phase 2)" if fused else ')'),
-            'bound': 'hbm (limiter: lds+valu in phase 1, record rate in phase 2)',
+            'bound': 'hbm (limiter: lds staging + pool writes in phase 1, instruction issue in phase 2)',
             'achieved': alg / avg_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / avg_s / 1e9 / 8000.0, 'traffic': None,
             'avg_launch_us': avg_s * 1e6, 'launches': len(durs), 'rows_per_launch': rows_per_step, 'algorithmic_bytes_per_launch': alg,
             'algorithmic_bytes_scatter': alg_scatter, 'algorithmic_bytes_optimizer': alg_adam, 'optimizer_fused_into_phase2': fused,
             'pair_without_optimizer_us': getattr(eng, 'pair_without_optimizer_us', None),
             'records_per_launch': records, 'record_bytes': 8, 'record_traffic_bytes_per_launch': rec_bytes,
             'records_per_s': records / avg_s if records else None,
-            'limiter': 'not HBM bandwidth: phase 1 costs the same ~23 us per level whether the level leaves 0.6 M or 8.4 M records '
-                       '(per-level trace in DESIGN.md 4.1): fixed work per (tile, level) -- corner indices / weights / run merge (VALU) and '
-                       'the LDS sort (random LDS accesses run at ~6 lanes/clk/CU), about half each; phase 2 sustains 1.4 G records/s per CU '
-                       '= ~10 GB/s per CU of 512-byte record runs (2.5 TB/s over the chip) with the fp16 -> 64-bit fixed-point decode and two '
-                       'LDS atomics per record overlapped underneath',
+            'limiter': 'not HBM bandwidth alone (round-6 section clocks and stubs, profiles/NOTES_experiments.md): phase 1 is the sum of its parts -- '
+                       'corner arithmetic, ranking atomics, sorted LDS stores and the copy-out of the 743 MB of records (LDS read-back + global stores: '
+                       '40 % of the kernel; the plain write of that pool alone is 114 us at 6.85 TB/s); phase 2 is instruction-issue-bound at 4 waves per '
+                       'SIMD (~23 instructions to request a run, ~25 per 64-lane piece of it, runs of ~45 records fill 55 % of the lanes) plus the '
+                       "table's optimizer step at cache bandwidth; its 16 waves per block share the tiles dynamically since round 6 (-17 %)",
             'note': 'HIP events around the launch pair over %d launch-by-launch steps right after the timed region (the timed region itself '
                     'replays a hipGraph, which cannot carry events); phase 1 sorts fp16x2 (index, value) records by table slice in LDS and '
                     'streams them out (8 B/record), phase 2 streams them back and accumulates in 64-bit fixed point in LDS: no global '
