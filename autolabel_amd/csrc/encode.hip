@@ -433,19 +433,21 @@ extern "C" int aln_encode_fwd_cells(const AlnEncDesc* e, const void* table_f16, 
 //   phase 1 (k_encode_bwd_bin): a block owns a tile of 512 consecutive sample rows.  Per level it computes the run-deduped
 //     (index, w * dL/dfeat) records, counting-sorts them in LDS by table SLICE (1/64 of the level: 8192 entries for a hashed
 //     level, 64 for the 16^3 level) and writes the sorted records as ONE contiguous run into the tile's fixed chunk of the record
-//     pool, plus one (start, count, shift) descriptor per slice.  Records are 8 bytes: slot within the slice | fp16x2 value.
+//     pool, plus one (start, count, shift) descriptor per slice.  Round 6: a record is a PAIR -- the two x-neighbour corners of a cell,
+//     which practically always fall into one slice -- in 12 bytes: slot0 | slot1 << 13, fp16x2 value 0, fp16x2 value 1 (round 5: two
+//     8-byte records).  The copy-out of the pool through LDS is 40 % of phase 1 and proportional to its bytes (stub: -30 us).
 //   phase 2 (k_encode_bwd_accum): a block owns one (level, slice); it streams that slice's runs of every tile, accumulates
 //     them with 64-bit integer LDS atomics (exact, order-independent) and adds the slice to the gradient table with plain
 //     coalesced stores.  Every level has the same 64-way split, so no entry is ever shared by two blocks: the whole gradient
 //     table is bit-reproducible run to run (round 2 split the tiles of the two coarsest levels over blocks that met in fp32
 //     global atomics).
-// HBM traffic: 8 B written + 8 B read per record (<= 8 x 16 records per sample) instead of 4 atomic requests per (sample, level).
+// HBM traffic: 12 B written + 12 B read per pair record (<= 4 x 16 per sample) instead of 4 atomic requests per (sample, level).
 #ifndef BIN_TILE
 #define BIN_TILE 512            // sample rows per phase-1 block (= threads: lane = sample, so runs along a ray dedupe in-wave); -DBIN_TILE=1024
                                 // (1 KB runs for phase 2) measured: round 3 dense pair 771 -> 806 us, round 5 620 -> 607 us (step -0.3 %): no gain
                                 // worth the format change it needs -- a full 1024-row tile has 8192 records, one more than DESC_START holds
 #endif
-static_assert(BIN_TILE * 8 <= 0x2000, "the start of every NON-EMPTY slice of a tile must fit the 13-bit start field of the descriptors (an empty trailing slice of a full 1024-row tile wraps to 0: never read)");
+static_assert(BIN_TILE * 8 <= 0x1FFF, "a tile's worst-case pair-record count must fit the 13-bit start field of the descriptors");
 // descriptor word: start (13 bits) | count << 13 (14 bits) | (shift + BIN_SHIFT_BIAS) << 27
 #define DESC_START(q) ((q) & 0x1FFFu)
 #define DESC_COUNT(q) (((q) >> 13) & 0x3FFFu)
@@ -455,7 +457,16 @@ static_assert(BIN_TILE * 8 <= 0x2000, "the start of every NON-EMPTY slice of a t
 #define BIN_SLICE_LOG2 13       // largest slice: 8192 table entries (x 2 features x 8 B = 128 KB of LDS accumulators in phase 2)
 #define BIN_SLICE (1 << BIN_SLICE_LOG2)
 #define BIN_MAX_SLICES 64       // slices per level (2^19 entries / 8192)
-#define BIN_CHUNK (BIN_TILE * 8)   // records per (tile, level) chunk of the pool
+#define BIN_CHUNK (BIN_TILE * 4)   // PAIR records per (tile, level) chunk of the pool
+#define BIN_REC_WORDS 3             // 4-byte words per pair record: [slot0 | slot1 << 13] [fp16x2 value 0] [fp16x2 value 1] -- an ODD record of a chunk
+                                   // keeps its slot word FIRST, an even one LAST, so that the 8 value bytes are 8-byte aligned in both (LDS stores)
+// A pair whose two corners fall into DIFFERENT slices (x + 1 carries past the slice width: x = ...1111111111111 -- ~2^-13 of the pairs of a
+// fine hashed level on continuous positions, but EVERY sample clamped onto the +x face of the box at the levels of 8192 cells and more:
+// 16 % of the pairs of levels 9 .. 15 on the bench scene) becomes TWO records, each in the run of its own slice with an empty second half
+// (value word 0: phase 2 skips it).  A tile's level can therefore hold up to 2 x BIN_CHUNK records: the pool's chunks have room for the
+// worst case, the LDS tile for BIN_CHUNK -- records ranked beyond that (the highest slices of a tile full of clamped samples) go straight
+// to their place in the pool with 12-byte stores instead of through the sorted LDS tile.
+#define BIN_CHUNK_WORDS (2 * BIN_CHUNK * BIN_REC_WORDS)              // pitch of a (tile, level) chunk of the pool: 48 KB
 #define BIN_MAX_SHIFT 11        // largest per-tile up-scaling of the fp16 record values (BIN_MIN_SHIFT: largest down-scaling)
 #ifndef BIN_DEDUPE_LEVELS
 #define BIN_DEDUPE_LEVELS 8
@@ -475,13 +486,13 @@ struct BinParams {
   EncParams p;
   const h16* d_enc;
   int32_t* found_inf; // raised by phase 1 when a run is non-finite (before phase 2 can step anything)
-  uint2* pool;        // [n_levels][ntiles][BIN_CHUNK] records
+  uint32_t* pool;     // [n_levels][ntiles] chunks of BIN_CHUNK_WORDS words: up to 2 x BIN_CHUNK pair records of BIN_REC_WORDS words
   uint32_t* desc;     // [n_levels][BIN_MAX_SLICES][ntiles]  DESC_START | DESC_COUNT | DESC_SHIFT
   int ntiles;
   int rows1, stride2; // rows [0, rows1) use p.rays_stride samples per ray, the rest stride2 (coarse + fine pass in one launch)
   const uint16_t* perm;   // optional [rays][stride1 + stride2]: sample ids of a ray in depth order (sampling.hip) -- the tile then walks the
                           // samples in that order, so the coarse and the fine samples of one cell form ONE run of the in-wave dedupe
-  uint8_t slice_log2[ALN_MAX_LEVELS];
+  uint32_t slice_log2_w[ALN_MAX_LEVELS / 4];   // slice_log2 of level l = byte l & 3 of word l >> 2
 };
 
 __device__ inline void bin_row_position(const BinParams& b, int row, float* x) {
@@ -521,9 +532,8 @@ __device__ inline uint32_t wave_incl_scan(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
   return x;
 }
-typedef uint32_t rec_pair __attribute__((ext_vector_type(4), aligned(8)));   // two 8-byte records at an 8-byte aligned LDS address
 __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TILE <= 768 ? 6 : 4, BIN_TILE <= 768 ? 6 : 4))) void k_encode_bwd_bin(BinParams b) {   // (three blocks per CU: 80 registers)
-  __shared__ uint2 sorted[BIN_CHUNK];                        // 32 KB
+  __shared__ __attribute__((aligned(16))) uint32_t sorted[BIN_CHUNK * BIN_REC_WORDS];   // 24 KB
   __shared__ uint32_t gws[8][BIN_TILE];                      // 16 KB: the rows' gradient words of eight levels (column = thread)
   __shared__ uint32_t cnt[2][BIN_MAX_SLICES], base_w[BIN_TILE / 64][BIN_MAX_SLICES], vmax_s[2];
   const EncParams& p = b.p;
@@ -554,27 +564,22 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
   // per eight levels at the top of the level: 7 % of the kernel in the section clocks of a -DBIN_TIMING build) hides behind the stores,
   // the barrier and the copy-out; the eight registers are live where the sixteen products are not
   uint2 w2[4];
+  // (unconditional loads from clamped addresses, masked where they are parked, a level later: with a load per branch hipcc waited for each
+  //  in turn -- vmcnt(0), eight HBM round trips in a row and every store of the copy-out drained in front of the first)
   auto fetch_gw = [&](int l) __attribute__((always_inline)) {
     const int nw = min(8, p.level_hi - l);
-    if (al8 && (l & 1) == 0) {
+    if (al8 && (l & 1) == 0 && (nw & 1) == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        w2[j >> 1] = make_uint2(0u, 0u);
-        if (valid && j + 1 < nw) w2[j >> 1] = *(const uint2*)(grow + l + j);
-        else if (valid && j < nw) w2[j >> 1].x = grow[l + j];
-      }
+      for (int j = 0; j < 8; j += 2) w2[j >> 1] = *(const uint2*)(grow + l + min(j, nw - 2));
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        w2[j >> 1].x = (valid && j < nw) ? grow[l + j] : 0u;
-        w2[j >> 1].y = (valid && j + 1 < nw) ? grow[l + j + 1] : 0u;
-      }
+      for (int j = 0; j < 8; j += 2) { w2[j >> 1].x = grow[l + min(j, nw - 1)]; w2[j >> 1].y = grow[l + min(j + 1, nw - 1)]; }
     }
   };
   fetch_gw(p.level_lo);
   __syncthreads();
   BT_DECL
-  // The sorted tile of level l leaves for the record pool in BIN_TILE * 8 / 2 / BIN_TILE = 4 pieces of 16 bytes per thread, SPREAD OVER THE
+  // The sorted tile of level l leaves for the record pool in 3 pieces of 16 bytes per thread (24 KB), SPREAD OVER THE
   // ARITHMETIC OF LEVEL l + 1 (round 6).  As one burst behind the last barrier of its level -- every block of the chip at about the
   // same time -- the 743 MB of records cost the kernel 130 us of its 315 (stub: no copy-out, 185 us): the memory pipe idles while
   // the waves compute and the waves stall on full store queues while it drains.  `sorted` is not written again before the first barrier
@@ -596,11 +601,14 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
   for (int l = p.level_lo; l < p.level_hi; ++l) {
     BT(0)
     const int par = l & 1;
-    const uint32_t sl = b.slice_log2[l], slot_mask = (1u << sl) - 1u;
+    // (slice_log2 is read as a WORD of the kernel arguments and shifted: indexed as bytes hipcc fetched it with a vector load, and the
+    //  s_waitcnt vmcnt(0) in front of its first use made every level wait for all of the wave's stores in flight -- the copy-out)
+    const uint32_t sl = (b.slice_log2_w[l >> 2] >> (8 * (l & 3))) & 0xFFu, slot_mask = (1u << sl) - 1u;
     const int k8 = (l - p.level_lo) & 7;
     if (k8 == 0) {   // words of levels l .. l + 7 (requested a level ago: fetch_gw) -> this thread's column (nobody else touches it: no barrier)
+      const int nw = min(8, p.level_hi - l);
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) { gws[j][tid] = w2[j >> 1].x; gws[j + 1][tid] = w2[j >> 1].y; }
+      for (int j = 0; j < 8; j += 2) { gws[j][tid] = (valid && j < nw) ? w2[j >> 1].x : 0u; gws[j + 1][tid] = (valid && j + 1 < nw) ? w2[j >> 1].y : 0u; }
     }
     BT(1)
     copy_piece(0);
@@ -648,7 +656,6 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
     // the producer of d_enc has raised found_inf before this kernel started (what lets phase 2 apply the optimizer itself).
     // (the largest magnitude as a bit pattern: non-negative floats order like their patterns, and a NaN -- which fmaxf would
     //  silently drop -- sorts above infinity)
-    copy_piece(3);
     uint32_t umax = 0u;
 #ifdef STUB_UMAX   // dev stub: no maximum over the products, no wave fold
     umax = __float_as_uint(v[0]) & 0x7fffffffu;
@@ -666,7 +673,7 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
     // the copy-out alone saves 114 / 125 / 96 us of 325, all three together 131: the three LDS phases are not additive costs but
     // alternatives on one critical path -- barrier to barrier -- and halving the operations of two of them moves little.)
     BT(2)
-    uint32_t rk[8];
+    uint32_t rk[8];   // (ranks of the four PAIRS: even entries)
     {
       // the tile's largest magnitude: folded over the wave with shuffles, ONE LDS atomic per wave.  (atomicMax from every lane is
       // rewritten by hipcc's atomic optimizer into a scalar loop over the active lanes -- ~6 scalar instructions per lane, 370 per
@@ -685,19 +692,12 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
 #else
     if (emit) {
 #endif
-      // the four pair atomics go out back to back (no branch between them: one LDS round trip for all four instead of one each);
-      // the rare second atomic of a pair that straddles two slices follows in its own pass
+      // the four pair atomics go out back to back (no branch between them: one LDS round trip for all four instead of one each)
 #pragma unroll
-      for (int c = 0; c < 8; c += 2) {
-        const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
-        rk[c] = atomicAdd(&cnt[par][s0], s0 == s1 ? 2u : 1u);
-      }
+      for (int c = 0; c < 8; c += 2) rk[c] = atomicAdd(&cnt[par][idx[c] >> sl], 1u);
+      // (a pair that straddles two slices -- BIN_CHUNK_WORDS -- takes a second record, in the slice of its second corner)
 #pragma unroll
-      for (int c = 0; c < 8; c += 2) {
-        const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
-        rk[c + 1] = rk[c] + 1u;
-        if (s0 != s1) rk[c + 1] = atomicAdd(&cnt[par][s1], 1u);
-      }
+      for (int c = 0; c < 8; c += 2) if ((idx[c] >> sl) != (idx[c + 1] >> sl)) rk[c + 1] = atomicAdd(&cnt[par][idx[c + 1] >> sl], 1u);
     }
     BT(3)
     __syncthreads();
@@ -726,14 +726,31 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
       uint32_t b0[4];
 #pragma unroll
       for (int c = 0; c < 8; c += 2) b0[c >> 1] = bw[idx[c] >> sl];     // (all four slice bases requested before the first store)
+      // record p of the chunk sits at word 3 p: the value pair at the 8-byte aligned one of words (3 p, 3 p + 1), the slot word beside it;
+      // positions beyond the LDS tile (only with straddling pairs: BIN_CHUNK_WORDS) are written to the pool directly
+      uint32_t* const chunk = b.pool + ((size_t)l * b.ntiles + tile) * BIN_CHUNK_WORDS;
+      auto put = [&](uint32_t pos, uint32_t slots, uint32_t h0, uint32_t h1) __attribute__((always_inline)) {
+        const uint32_t odd = pos & 1u;
+        if (pos < (uint32_t)BIN_CHUNK) {   // (two branches, not a pointer select: that would be a flat store)
+          uint32_t* const w = sorted + 3u * pos;
+          *(uint2*)(w + odd) = make_uint2(h0, h1);
+          w[odd ? 0 : 2] = slots;
+        } else {
+          uint32_t* const w = chunk + 3u * pos;
+          *(uint2*)(w + odd) = make_uint2(h0, h1);
+          w[odd ? 0 : 2] = slots;
+        }
+      };
 #pragma unroll
       for (int c = 0; c < 8; c += 2) {
         const uint32_t hw0 = bin_pack_h2(v[2 * c] * sc, v[2 * c + 1] * sc), hw1 = bin_pack_h2(v[2 * c + 2] * sc, v[2 * c + 3] * sc);
         const uint32_t s0 = idx[c] >> sl, s1 = idx[c + 1] >> sl;
-        const uint2 r0 = make_uint2(idx[c] & slot_mask, hw0), r1 = make_uint2(idx[c + 1] & slot_mask, hw1);
-        uint2* const d0 = sorted + b0[c >> 1] + rk[c];
-        if (s0 == s1) *(rec_pair*)d0 = rec_pair{r0.x, r0.y, r1.x, r1.y};      // adjacent slots: one two-record store (ds_write2_b64)
-        else { d0[0] = r0; sorted[bw[s1] + rk[c + 1]] = r1; }
+        const uint32_t m0 = idx[c] & slot_mask, m1 = idx[c + 1] & slot_mask;
+        if (s0 == s1) put(b0[c >> 1] + rk[c], m0 | (m1 << 13), hw0, hw1);
+        else {
+          put(b0[c >> 1] + rk[c], m0 | (m0 << 13), hw0, 0u);
+          put(bw[s1] + rk[c + 1], m1 | (m1 << 13), hw1, 0u);
+        }
       }
     }
     if (k8 == 7 && l + 1 < p.level_hi) fetch_gw(l + 1);   // (behind the stores: the sixteen products are dead, the eight words fit the 80-register budget of three blocks per CU)
@@ -743,12 +760,12 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
     // (counters and maximum of this parity: next touched by the atomics of level l + 2, two barriers from here)
     if (tid < BIN_MAX_SLICES) cnt[par][tid] = 0;
     if (tid == 0) vmax_s[par] = 0u;
-    cp_n = (min(total_w, (uint32_t)BIN_CHUNK) + 1u) / 2u;
-    cp_dst = (uint4*)(b.pool + ((size_t)l * b.ntiles + tile) * BIN_CHUNK);
+    cp_n = (min(total_w, (uint32_t)BIN_CHUNK) * (BIN_REC_WORDS * 4u) + 15u) / 16u;      // 16-byte pieces of the level's pair records
+    cp_dst = (uint4*)(b.pool + ((size_t)l * b.ntiles + tile) * BIN_CHUNK_WORDS);
     BT(9)
   }
 #pragma unroll
-  for (int i = 0; i < BIN_CHUNK / 2 / BIN_TILE; ++i) copy_piece(i);   // the last level's tile
+  for (int i = 0; i < (BIN_CHUNK * BIN_REC_WORDS * 4 / 16 + BIN_TILE - 1) / BIN_TILE; ++i) copy_piece(i);   // the last level's tile
   BT_FLUSH
 }
 
@@ -762,7 +779,7 @@ struct AccAdam {
   float lr, beta1, beta2, eps; double log_beta1, log_beta2;
 };
 struct AccParams {
-  const uint2* pool; const uint32_t* desc; float* grad; int32_t* found_inf; AccAdam ad;
+  const uint32_t* pool; const uint32_t* desc; float* grad; int32_t* found_inf; AccAdam ad;
   h16* wire; float wire_mul;   // data parallelism with fp16 on the wire: the slice leaves as fp16(sum * wire_mul) -- no fp32 gradient
   int ntiles, level_lo, n_levels_here;
   uint32_t blk_start[ALN_MAX_LEVELS + 1];   // first block of each launched level (levels enumerated from level_lo)
@@ -779,6 +796,12 @@ struct AccParams {
 // (ds_add_f32 runs at 0.33 lanes/clk/CU on gfx950, ds_add_u64 at 4.6: profiles/r02_probe_lds_atomics.txt.)
 __device__ inline long long fx_from_half_d(h16 h, int e) {
   const double z = ldexp((double)(float)h, e) + 6755399441055744.0;
+  return __double_as_longlong(z) - 0x4338000000000000LL;
+}
+// the same number with the scaling done in single precision: h * 2^e (sc = 2^e, -126 <= e <= 127) is exact -- 11 significant bits, far
+// inside the exponent range -- and a full-rate multiply, where v_ldexp_f64 is not
+__device__ inline long long fx_from_half_s(h16 h, float sc) {
+  const double z = (double)((float)h * sc) + 6755399441055744.0;
   return __double_as_longlong(z) - 0x4338000000000000LL;
 }
 #define FX_UNIT_LOG2 (24 + BIN_MAX_SHIFT)   // 35
@@ -801,14 +824,18 @@ extern "C" int aln_debug_read_acc_timing(long long* host_out, int reset) {
 #define AT_FLUSH
 #endif
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3v __attribute__((ext_vector_type(3), aligned(4)));   // a 12-byte pair record
 typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
 __device__ inline uint32_t pk_max_u16(uint32_t a, uint32_t b) {   // v_pk_max_u16
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2v, a), __builtin_bit_cast(u16x2v, b)));
 }
 #define ACC_THREADS 1024
-#define ACC_LPR (BIN_TILE / 256)  // 8-byte loads per lane and run held in registers: covers the average run of a hashed level twice
 #ifndef ACC_RB
-#define ACC_RB (12 / ACC_LPR)    // runs per batch in the accumulate loop (12 loads per batch: 16 spill at the 128-VGPR budget of 16 waves per CU)
+#define ACC_RB 8    // tiles (= runs of the slice) per batch of the accumulate loop
+#endif
+typedef uint32_t acc_sv __attribute__((ext_vector_type(ACC_RB)));
+#ifndef ACC_TR
+#define ACC_TR 4    // trips of 64 pair records per batch whose loads are requested a batch ahead (two batches of registers)
 #endif
 __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
@@ -843,6 +870,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
     adam_c[0] = found ? 1.f : 0.f; adam_c[1] = 1.0f / a.ad.sf[0];
     adam_c[2] = (float)((double)lr / bc1); adam_c[3] = (float)(1.0 / sqrt(bc2));
   }
+  const uint32_t* pool = a.pool + (size_t)l * a.ntiles * BIN_CHUNK_WORDS;
   // (the first descriptors of the bound pass are requested before the accumulators are cleared: one HBM round trip under the LDS stores)
   const uint32_t qd0 = tid < a.ntiles ? d[tid] : 0u, qd1 = tid + ACC_THREADS < a.ntiles ? d[tid + ACC_THREADS] : 0u;
   for (uint32_t i = tid; i < ne; i += ACC_THREADS) { acc[i] = 0ll; acc[plane + i] = 0ll; }
@@ -867,81 +895,38 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
   int U = FX_UNIT_LOG2;
   // (a tile that was scaled DOWN carries records up to 2^(16 - shift): the double-precision conversion needs them below 2^51 units)
   { const unsigned long long bd = bound_s; const int lg = bd ? 64 - __clzll(bd) : 0; U = min(FX_UNIT_LOG2 + smin_s, 62 - lg); }   // bd < 2^lg
-  const uint2* pool = a.pool + (size_t)l * a.ntiles * BIN_CHUNK;
   uint32_t badbits = 0u;   // largest |half| seen, as bit patterns (two packed 15-bit maxima): >= 0x7C00 = a record value was inf or nan
-  auto add = [&](uint2 r, int ex) {   // ex = U - shift of the run's tile
-    const h16x2 hv = *(const h16x2*)&r.y;
-    badbits = pk_max_u16(badbits, r.y & 0x7FFF7FFFu);
-    atomicAdd((unsigned long long*)&acc[r.x], (unsigned long long)fx_from_half_d(hv[0], ex));
-    atomicAdd((unsigned long long*)&acc[plane + r.x], (unsigned long long)fx_from_half_d(hv[1], ex));
-  };
-#ifdef ACC_OLD   // dev builds only: round 5 -- equal static shares of the tiles per wave (same-box A/B)
-  {
-    // the tiles are dealt out to the 16 waves in equal contiguous shares (all waves busy for any tile count); a wave walks its
-    // share in rounds of <= 64 tiles (one descriptor per lane) and batches of ACC_RB runs: the first 128 records of each run in
-    // ACC_LPR 8-byte loads per lane (16-byte loads, two records per lane, were slower: half the lanes idle through the conversions),
-    // the next batch requested before the current one is consumed (2 x ACC_RB KB in flight per wave)
-    const int share = ((a.ntiles + nw - 1) / nw + ACC_RB - 1) / ACC_RB * ACC_RB;
-    const int tlo = min(wave * share, a.ntiles), thi = min(tlo + share, a.ntiles);
-    for (int t0 = tlo; t0 < thi; t0 += 64) {
-      const int nt = min(64, thi - t0);
-      const uint32_t dd = (lane < nt) ? d[t0 + lane] : 0u;
-      uint2 r[2][ACC_LPR * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB]; int ex[2][ACC_RB];
-      auto request = [&](int buf, int j0) {
-#pragma unroll
-        for (int u = 0; u < ACC_RB; ++u) {
-          const uint32_t q = __builtin_amdgcn_readlane(dd, (j0 + u) & 63);
-          st[buf][u] = DESC_START(q); n[buf][u] = (j0 + u < nt) ? DESC_COUNT(q) : 0u; ex[buf][u] = U - DESC_SHIFT(q);
-          const uint2* src = pool + (size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u];
-#pragma unroll
-          for (int v = 0; v < ACC_LPR; ++v) {
-            r[buf][ACC_LPR * u + v] = make_uint2(0u, 0u);
-            if ((uint32_t)lane + 64u * v < n[buf][u]) r[buf][ACC_LPR * u + v] = src[lane + 64 * v];
-          }
-        }
-      };
-      auto consume = [&](int buf, int j0) {
-#pragma unroll
-        for (int u = 0; u < ACC_RB; ++u) {
-#pragma unroll
-          for (int v = 0; v < ACC_LPR; ++v)
-            if ((uint32_t)lane + 64u * v < n[buf][u]) add(r[buf][ACC_LPR * u + v], ex[buf][u]);
-          for (uint32_t k = 64 * ACC_LPR + lane; k < n[buf][u]; k += 64)   // long runs
-            add(pool[(size_t)(t0 + j0 + u) * BIN_CHUNK + st[buf][u] + k], ex[buf][u]);
-        }
-      };
-      AT(4)
-      request(0, 0);
-      for (int j0 = 0; j0 < nt; j0 += 2 * ACC_RB) {
-        request(1, j0 + ACC_RB);
-        AT(5)
-#ifdef ACC_TIMING
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wait of the consume below, on its own stamp
-        AT(6)
-#endif
-        consume(0, j0);
-        AT(7)
-        request(0, j0 + 2 * ACC_RB);
-        AT(5)
-#ifdef ACC_TIMING
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        AT(6)
-#endif
-        consume(1, j0 + ACC_RB);
-        AT(7)
-      }
+  auto add = [&](u32x3v w, uint32_t odd_pos, int ex) {   // pair record at an odd / even position of its chunk; ex = U - shift of the run's tile
+    // (an odd record keeps its slot word first, an even one last: BIN_REC_WORDS)
+    const bool odd = odd_pos != 0u;
+    const uint32_t slots = odd ? w.x : w.z, v0 = odd ? w.y : w.x, v1 = odd ? w.z : w.y;
+    const h16x2 h0 = __builtin_bit_cast(h16x2, v0), h1 = __builtin_bit_cast(h16x2, v1);
+    badbits = pk_max_u16(badbits, pk_max_u16(v0 & 0x7FFF7FFFu, v1 & 0x7FFF7FFFu));
+    const uint32_t s0 = slots & 0x1FFFu, s1 = (slots >> 13) & 0x1FFFu;
+#ifdef ACC_LDEXP64
+    atomicAdd((unsigned long long*)&acc[s0], (unsigned long long)fx_from_half_d(h0[0], ex));
+    atomicAdd((unsigned long long*)&acc[plane + s0], (unsigned long long)fx_from_half_d(h0[1], ex));
+    if (v1 & 0x7FFF7FFFu) {   // (the empty second half of a pair that straddled two slices adds nothing)
+      atomicAdd((unsigned long long*)&acc[s1], (unsigned long long)fx_from_half_d(h1[0], ex));
+      atomicAdd((unsigned long long*)&acc[plane + s1], (unsigned long long)fx_from_half_d(h1[1], ex));
     }
-  }
 #else
+    const float sc = __uint_as_float((uint32_t)(127 + ex) << 23);   // 2^ex
+    atomicAdd((unsigned long long*)&acc[s0], (unsigned long long)fx_from_half_s(h0[0], sc));
+    atomicAdd((unsigned long long*)&acc[plane + s0], (unsigned long long)fx_from_half_s(h0[1], sc));
+    if (v1 & 0x7FFF7FFFu) {   // (the empty second half of a pair that straddled two slices adds nothing)
+      atomicAdd((unsigned long long*)&acc[s1], (unsigned long long)fx_from_half_s(h1[0], sc));
+      atomicAdd((unsigned long long*)&acc[plane + s1], (unsigned long long)fx_from_half_s(h1[1], sc));
+    }
+#endif
+  };
   {
     // Batches of ACC_RB consecutive tiles are handed out DYNAMICALLY (one LDS counter per block).  With equal static shares the 16
     // waves of a block finished up to 65 % apart (section clocks of a -DACC_TIMING build: loop times 99 K .. 164 K ticks per wave for
     // the same number of records -- whoever loses the issue arbitration of its SIMD falls behind for good), and the early ones sat at
     // the block's barrier for a quarter of the kernel.  Integer accumulation is order-independent, so who adds which run changes no bit.
     // Pipeline per wave, no drain anywhere: grab + descriptor load two batches ahead (ACC_RB lanes, one 4-byte word each), record loads
-    // one batch ahead (the first 128 records of each run in ACC_LPR 8-byte loads per lane; 16-byte loads, two records per lane, were
-    // slower: half the lanes idle through the conversions), consume.  The batch index comes back through readfirstlane: tile, start and
-    // count of every run are wave-uniform and the address arithmetic stays in scalar registers.
+    // one batch ahead (12 bytes per lane and trip), consume.  The batch index comes back through readfirstlane.
     const int nbatch = (a.ntiles + ACC_RB - 1) / ACC_RB;
     // (the counter's returning atomic is ISSUED one stage before its result is read: an LDS round trip behind the other waves' accumulate
     //  traffic is ~1000 ticks, as long as the requests of a whole batch take to issue)
@@ -951,50 +936,65 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
       return g;
     };
     auto grabbed = [&](uint32_t g) __attribute__((always_inline)) { return (int)__builtin_amdgcn_readfirstlane(g); };
+    // (every load of the pipeline is UNCONDITIONAL -- out-of-range lanes read a valid address and drop the value: behind a load in a
+    //  branch hipcc's wait insertion no longer knows how many younger loads are in flight and waits for all of them, vmcnt(0), which
+    //  put the batch requested a moment ago in front of every accumulate)
     auto load_desc = [&](int bt) __attribute__((always_inline)) {
-      const int t = bt * ACC_RB + lane;
-      return (bt < nbatch && lane < ACC_RB && t < a.ntiles) ? d[t] : 0u;   // (0: start 0, count 0 -- nothing is requested for it)
+      const int t = min(bt, nbatch - 1) * ACC_RB + (lane % ACC_RB);
+      const uint32_t q = d[min(t, a.ntiles - 1)];
+      return (bt < nbatch && lane < ACC_RB && t < a.ntiles) ? q : 0u;   // (0: start 0, count 0 -- nothing is requested for it)
     };
-    uint2 r[2][ACC_LPR * ACC_RB]; uint32_t st[2][ACC_RB], n[2][ACC_RB]; int ex[2][ACC_RB];
-#ifdef ACC_BUFFER_LOADS
-    // records through BUFFER loads whose descriptor ends at the run's last record: lanes beyond it read zeros without a memory request,
-    // no compare / exec / branch around a load (half the scalar instructions of a request)
-    const uint32_t voff = (uint32_t)lane * 8u;
+    // The runs of a batch -- ACC_RB tiles, ~32 pair records each at a hashed level -- are walked as ONE stream, 64 pair records per trip:
+    // lane i of trip t takes record g = 64 t + i of the concatenation.  (One run per trip left half the lanes idle: the add side is
+    // bound by instruction issue, and the conversions of a half-empty wave cost what those of a full one do.)  The descriptor lanes
+    // (0 .. ACC_RB - 1) scan their counts (DPP) and pack, per run, the word offset of the stream's position 0 and U - shift; both go to
+    // scalar registers, and a lane picks its run's fields with a compare + select chain over them (a bpermute would queue behind the
+    // accumulate atomics of the batch before: LDS instructions complete in order).
+    // The first ACC_TR trips of a batch are requested a batch ahead (registers); a longer batch loops.
+    u32x3v r[2][ACC_TR]; uint32_t pe[2][ACC_TR], inc_[2], fld_[2], tot[2];
+    // pe: word offset of the lane's record from the batch's first chunk (20 bits; its parity = the record's) | (U - shift + 128) << 20
+    // (vector VALUES, not arrays: through an array hipcc turned the select chain into a select of addresses and one scratch load)
+    auto locate = [&](uint32_t g, acc_sv sI, acc_sv sF) __attribute__((always_inline)) {
+      uint32_t f = sF[0];
+#pragma unroll
+      for (int u = 1; u < ACC_RB; ++u) f = g >= sI[u - 1] ? sF[u] : f;
+      return ((3u * g + f) & 0xFFFFFu) | (f & 0xFFF00000u);
+    };
+    auto spread = [&](uint32_t x) __attribute__((always_inline)) {   // descriptor lanes -> scalar registers
+      acc_sv s;
+#pragma unroll
+      for (int u = 0; u < ACC_RB; ++u) s[u] = (uint32_t)__builtin_amdgcn_readlane((int)x, u);
+      return s;
+    };
     auto request = [&](int buf, int bt, uint32_t dq) __attribute__((always_inline)) {
+      const uint32_t nq = DESC_COUNT(dq);   // (0 beyond the ACC_RB descriptor lanes)
+      uint32_t inc = nq;
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);    // row_shr:1
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);    // row_shr:2
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);    // row_shr:4
+      if (ACC_RB > 8) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);    // row_shr:8
+      const uint32_t fld = (((uint32_t)lane * BIN_CHUNK_WORDS + 3u * (DESC_START(dq) - (inc - nq))) & 0xFFFFFu) | ((uint32_t)(U - DESC_SHIFT(dq) + 128) << 20);
+      inc_[buf] = inc; fld_[buf] = fld;
+      const acc_sv sI = spread(inc), sF = spread(fld);
+      tot[buf] = sI[ACC_RB - 1];
+      const uint32_t* const src = pool + (size_t)min(bt, nbatch - 1) * (ACC_RB * BIN_CHUNK_WORDS);
 #pragma unroll
-      for (int u = 0; u < ACC_RB; ++u) {
-        const uint32_t q = __builtin_amdgcn_readlane(dq, u);
-        st[buf][u] = DESC_START(q); n[buf][u] = DESC_COUNT(q); ex[buf][u] = U - DESC_SHIFT(q);
-        const uint2* src = pool + (size_t)(bt * ACC_RB + u) * BIN_CHUNK + st[buf][u];
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(n[buf][u] * 8u), 0x00020000);
-#pragma unroll
-        for (int v = 0; v < ACC_LPR; ++v) {
-          const u32x2v w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 512u * v, 0, 0);
-          r[buf][ACC_LPR * u + v] = make_uint2(w.x, w.y);
-        }
+      for (int t = 0; t < ACC_TR; ++t) {
+        pe[buf][t] = locate(64u * t + (uint32_t)lane, sI, sF);
+        r[buf][t] = *(const u32x3v*)(src + (64u * t + (uint32_t)lane < tot[buf] ? pe[buf][t] & 0xFFFFFu : 0u));   // (lanes past the stream: the batch's first words, unused)
       }
     };
-#else
-    auto request = [&](int buf, int bt, uint32_t dq) __attribute__((always_inline)) {
-#pragma unroll
-      for (int u = 0; u < ACC_RB; ++u) {
-        const uint32_t q = __builtin_amdgcn_readlane(dq, u);
-        st[buf][u] = DESC_START(q); n[buf][u] = DESC_COUNT(q); ex[buf][u] = U - DESC_SHIFT(q);
-        const uint2* src = pool + (size_t)(bt * ACC_RB + u) * BIN_CHUNK + st[buf][u];
-#pragma unroll
-        for (int v = 0; v < ACC_LPR; ++v)   // (no zero fill: consume() reads a register under the very same predicate)
-          if ((uint32_t)lane + 64u * v < n[buf][u]) r[buf][ACC_LPR * u + v] = src[lane + 64 * v];
-      }
-    };
-#endif
     auto consume = [&](int buf, int bt) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < ACC_RB; ++u) {
-#pragma unroll
-        for (int v = 0; v < ACC_LPR; ++v)
-          if ((uint32_t)lane + 64u * v < n[buf][u]) add(r[buf][ACC_LPR * u + v], ex[buf][u]);
-        for (uint32_t k = 64 * ACC_LPR + lane; k < n[buf][u]; k += 64)   // long runs
-          add(pool[(size_t)(bt * ACC_RB + u) * BIN_CHUNK + st[buf][u] + k], ex[buf][u]);
+      for (int t = 0; t < ACC_TR; ++t)
+        if (64u * t + (uint32_t)lane < tot[buf]) add(r[buf][t], pe[buf][t] & 1u, (int)(pe[buf][t] >> 20) - 128);
+      if (64u * ACC_TR < tot[buf]) {   // a long batch
+        const uint32_t* const src = pool + (size_t)bt * (ACC_RB * BIN_CHUNK_WORDS);
+        const acc_sv sI = spread(inc_[buf]), sF = spread(fld_[buf]);
+        for (uint32_t g = 64u * ACC_TR + (uint32_t)lane; g < tot[buf]; g += 64u) {
+          const uint32_t q = locate(g, sI, sF);
+          add(*(const u32x3v*)(src + (q & 0xFFFFFu)), q & 1u, (int)(q >> 20) - 128);
+        }
       }
     };
     AT(4)
@@ -1031,7 +1031,6 @@ __global__ __launch_bounds__(ACC_THREADS) void k_encode_bwd_accum(AccParams a) {
       bA = bC; bB = bD; dB = dD;
     }
   }
-#endif
   const bool bad = (badbits & 0xFFFFu) >= 0x7C00u || (badbits >> 16) >= 0x7C00u;
   AT(8)
   __syncthreads();
@@ -1118,7 +1117,8 @@ extern "C" int32_t aln_encode_bwd_binned_tile_rows(void) { return BIN_TILE; }
 extern "C" int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows) {
   if (!e || !e->use_grid || rows <= 0) return 0;
   const int64_t ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
-  return nl * ntiles * BIN_CHUNK * (int64_t)sizeof(uint2) + nl * BIN_MAX_SLICES * ntiles * (int64_t)sizeof(uint32_t);
+  // [pool: chunks of pair records][descriptors]
+  return nl * ntiles * (int64_t)(BIN_CHUNK_WORDS * sizeof(uint32_t)) + nl * BIN_MAX_SLICES * ntiles * (int64_t)sizeof(uint32_t);
 }
 
 static int binned_launch(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z,
@@ -1158,10 +1158,14 @@ static int binned_launch(const AlnEncDesc* e, const float* rays_o, const float* 
   const int ntiles = (rows + BIN_TILE - 1) / BIN_TILE, nl = e->grid.n_levels;
   b.p.level_lo = level_lo; b.p.level_hi = level_hi;
   b.d_enc = (const h16*)d_enc; b.found_inf = found_inf; b.ntiles = ntiles; b.rows1 = rows_pass1; b.stride2 = stride2 > 0 ? stride2 : 1;
-  b.pool = (uint2*)ws; b.perm = perm;
-  b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * BIN_CHUNK * sizeof(uint2));
+  b.pool = (uint32_t*)ws; b.perm = perm;
+  b.desc = (uint32_t*)((char*)ws + (size_t)nl * ntiles * (BIN_CHUNK_WORDS * sizeof(uint32_t)));
   AccParams a;
-  for (int l = 0; l < ALN_MAX_LEVELS; ++l) b.slice_log2[l] = a.slice_log2[l] = (uint8_t)(l < nl ? bin_slice_log2(e->grid.size[l]) : 0);
+  for (int l = 0; l < ALN_MAX_LEVELS / 4; ++l) b.slice_log2_w[l] = 0u;
+  for (int l = 0; l < ALN_MAX_LEVELS; ++l) {
+    a.slice_log2[l] = (uint8_t)(l < nl ? bin_slice_log2(e->grid.size[l]) : 0);
+    b.slice_log2_w[l >> 2] |= (uint32_t)a.slice_log2[l] << (8 * (l & 3));
+  }
   if (phases & 1) {
     hipLaunchKernelGGL(k_encode_bwd_bin, dim3(ntiles), dim3(BIN_TILE), 0, (hipStream_t)stream, b);
     ALN_CHECK_LAUNCH("encode_bwd_bin");

@@ -336,14 +336,15 @@ class HipPipeline:
         self.refresh_bitfield()
 
     def binned_record_count(self, M, ws=None):
-        """Records the last binned hash-grid backward over M sample rows streamed through HBM (sum of the per-(level, slice,
-        tile) descriptor counts; 8 bytes each, written once by phase 1 and read once by phase 2).  Host sync: reporting only."""
+        """PAIR records (12 bytes: the two x-neighbour corners of a cell) the last binned hash-grid backward over M sample rows streamed
+        through HBM (sum of the per-(level, slice, tile) descriptor counts; written once by phase 1 and read once by phase 2).  Host
+        sync: reporting only."""
         t = (self.ws if ws is None else ws).bufs.get('enc_bwd_bins')
         if t is None:
             return None
         tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
         nl, nt = int(self.L.enc.grid.n_levels), (M + tile - 1) // tile
-        pool = nl * nt * tile * 8 * 8
+        pool = int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(self.L.enc), M)) - nl * 64 * nt * 4   # (the descriptors close the workspace)
         desc = t[1][pool:pool + nl * 64 * nt * 4].view(torch.int32)
         return int(((desc >> 13) & 0x3FFF).sum().item())
 

@@ -274,16 +274,16 @@ def scatter_roofline(eng, events, rows_per_step, n_event_steps):
     fused = bool(eng.fuse_grid_adam)
     alg_adam = 26.0 * L.n_grid if fused else 0.0
     alg = alg_scatter + alg_adam
-    records = eng.pipe.binned_record_count(rows_per_step, ws=eng.ws)   # records of the last launch (same state as the events)
-    rec_bytes = 2 * 8 * records if records else None                  # written once by phase 1, read once by phase 2
+    records = eng.pipe.binned_record_count(rows_per_step, ws=eng.ws)   # PAIR records of the last launch (same state as the events)
+    rec_bytes = 2 * 12 * records if records else None                 # 12 bytes each, written once by phase 1, read once by phase 2
     return {'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair' + ("; the table's Adam step inside phase 2)" if fused else ')'),
             'bound': 'hbm (limiter: lds staging + pool writes in phase 1, instruction issue in phase 2)',
             'achieved': alg / avg_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / avg_s / 1e9 / 8000.0, 'traffic': None,
             'avg_launch_us': avg_s * 1e6, 'launches': len(durs), 'rows_per_launch': rows_per_step, 'algorithmic_bytes_per_launch': alg,
             'algorithmic_bytes_scatter': alg_scatter, 'algorithmic_bytes_optimizer': alg_adam, 'optimizer_fused_into_phase2': fused,
             'pair_without_optimizer_us': getattr(eng, 'pair_without_optimizer_us', None),
-            'records_per_launch': records, 'record_bytes': 8, 'record_traffic_bytes_per_launch': rec_bytes,
-            'records_per_s': records / avg_s if records else None,
+            'pair_records_per_launch': records, 'pair_record_bytes': 12, 'record_traffic_bytes_per_launch': rec_bytes,
+            'pair_records_per_s': records / avg_s if records else None,
             'limiter': 'not HBM bandwidth alone (round-6 section clocks and stubs, profiles/NOTES_experiments.md): phase 1 is the sum of its parts -- '
                        'corner arithmetic, ranking atomics, sorted LDS stores and the copy-out of the 743 MB of records (LDS read-back + global stores: '
                        '40 % of the kernel; the plain write of that pool alone is 114 us at 6.85 TB/s); phase 2 is instruction-issue-bound at 4 waves per '

@@ -178,7 +178,8 @@ typedef struct {
   float lr, beta1, beta2, eps;
 } AlnAdamFuse;
 int64_t aln_encode_bwd_binned_ws_bytes(const AlnEncDesc* e, int32_t rows);
-int32_t aln_encode_bwd_binned_tile_rows(void);   /* sample rows per phase-1 tile (layout of ws: pool chunks of 8 x tile records, then descriptors) */
+int32_t aln_encode_bwd_binned_tile_rows(void);   /* sample rows per phase-1 tile (layout of ws: per (level, tile) a pool chunk with room for 8 x tile PAIR records of 12 bytes --
+                                                  * slot0 | slot1 << 13, fp16x2 value 0, fp16x2 value 1 -- then the [level][slice][tile] descriptors) */
 int aln_encode_bwd_binned(const AlnEncDesc* e, const float* rays_o, const float* rays_d, const float* z, const float* xyz,
                           int32_t rows, int32_t rows_pass1, int32_t rays_stride1, int32_t rays_stride2,
                           const uint16_t* depth_order /* optional [rays, stride1 + stride2] */, const void* d_enc,

@@ -127,7 +127,7 @@ if hasattr(lib, 'aln_debug_read_acc_timing'):   # a -DACC_TIMING build: ticks pe
 r = dict(p1=timeit(lambda: phase(1), a.reps), p2=0.0, pair=0.0, fused=0.0) if a.p1_only else dict(p1=timeit(lambda: phase(1), a.reps), p2=timeit(lambda: phase(2), a.reps), pair=timeit(lambda: phase(3), a.reps), fused=timeit(fused, a.reps))
 tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
 nt = (M + tile - 1) // tile
-desc = ws[16 * nt * tile * 8 * 8:].view(torch.int32)[:16 * 64 * nt]
+desc = ws[ws.numel() - 16 * 64 * nt * 4:].view(torch.int32)[:16 * 64 * nt]     # (pair records since round 6)
 r['records'] = int(((desc >> 13) & 0x3FFF).sum().item())
 if a.save:
     grad.zero_(); phase(3); torch.cuda.synchronize()

@@ -117,7 +117,7 @@ def test_binned_scatter_is_the_adjoint_of_the_gather_at_full_size(H):
     def records():
         tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
         nt, nl = (M + tile - 1) // tile, 16
-        pool = nl * nt * tile * 8 * 8
+        pool = int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), M)) - nl * 64 * nt * 4    # (the descriptors close the workspace)
         return int(((ws[pool:pool + nl * 64 * nt * 4].view(torch.int32) >> 13) & 0x3FFF).sum().item())
     n_plain = records()     # (of the last pass-major launch over all levels... the level groups wrote the same descriptors)
     walk, walk2 = torch.zeros_like(grad), torch.zeros_like(grad)

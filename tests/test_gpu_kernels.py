@@ -221,7 +221,7 @@ def _binned_bwd(H, e, ro, rd, z, rows, rows1, s1, s2, d_enc, grad, lo=0, hi=None
 def _record_count(H, e, ws, rows):
     tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
     nl, nt = int(e.grid.n_levels), (rows + tile - 1) // tile
-    pool = nl * nt * tile * 8 * 8
+    pool = int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)) - nl * 64 * nt * 4    # (the descriptors close the workspace)
     desc = ws[pool:pool + nl * 64 * nt * 4].view(torch.int32)
     return int(((desc >> 13) & 0x3FFF).sum().item())
 
