@@ -33,7 +33,7 @@ if a.child is None:
                 if l.startswith('timing'):
                     print('   ', l)
             d = json.loads(line[-1])
-            print(f"{os.path.basename(lib) or 'product':28s} round {rnd}: phase1 {d['p1']:7.1f}  phase2 {d['p2']:7.1f}  pair {d['pair']:7.1f}  fused-adam pair {d['fused']:7.1f} us"
+            print(f"{os.path.basename(lib) or 'product':28s} round {rnd}: phase1 {d['p1']:7.1f}  phase2 {d['p2']:7.1f}  pair {d['pair']:7.1f}  fused-adam pair {d['fused']:7.1f} us (in 2 / 4 level groups {d.get('fg2', 0):.1f} / {d.get('fg4', 0):.1f})"
                   f"   records {d['records'] / 1e6:.2f} M", flush=True)
     if a.check:
         import torch
@@ -89,6 +89,13 @@ def fused():
            0, 16, H.ptr(flag), C.byref(ad), H.stream())
 
 
+def fused_groups(ng):   # the same work as `fused`, level group by level group (is a group's pool still in the Infinity Cache when phase 2 reads it?)
+    step = 16 // ng
+    for lo in range(0, 16, step):
+        H.call('aln_encode_bwd_binned', C.byref(e), H.ptr(ro), H.ptr(rd), H.ptr(z), None, M, M1, S1, S2, H.ptr(perm), H.ptr(d_enc), None, H.ptr(ws),
+               lo, lo + step, H.ptr(flag), C.byref(ad), H.stream())
+
+
 def timeit(fn, reps):
     for _ in range(2):
         fn()
@@ -124,7 +131,7 @@ if hasattr(lib, 'aln_debug_read_acc_timing'):   # a -DACC_TIMING build: ticks pe
     for w in range(2):
         t = [buf[12 * w + i] for i in range(11)]
         print(f'timing acc wave {"0" if w == 0 else "15"}: total {sum(t)} ticks: ' + '  '.join(f'{n} {v}' for n, v in zip(names, t)), file=sys.stderr)
-r = dict(p1=timeit(lambda: phase(1), a.reps), p2=0.0, pair=0.0, fused=0.0) if a.p1_only else dict(p1=timeit(lambda: phase(1), a.reps), p2=timeit(lambda: phase(2), a.reps), pair=timeit(lambda: phase(3), a.reps), fused=timeit(fused, a.reps))
+r = dict(p1=timeit(lambda: phase(1), a.reps), p2=0.0, pair=0.0, fused=0.0) if a.p1_only else dict(p1=timeit(lambda: phase(1), a.reps), p2=timeit(lambda: phase(2), a.reps), pair=timeit(lambda: phase(3), a.reps), fused=timeit(fused, a.reps), fg2=timeit(lambda: fused_groups(2), a.reps), fg4=timeit(lambda: fused_groups(4), a.reps))
 tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
 nt = (M + tile - 1) // tile
 desc = ws[ws.numel() - 16 * 64 * nt * 4:].view(torch.int32)[:16 * 64 * nt]     # (pair records since round 6)
