@@ -152,7 +152,7 @@ __device__ inline h16x2 level_features(const EncParams& p, int l, const float* x
 #ifdef STUB_GATHER_NOLOAD     // dev stub: no table loads
       r[h][i] = act ? ix * 2654435761u : 0u;
 #else
-      r[h][i] = act ? tab[ix] : 0u;
+      r[h][i] = act ? tab[ix] : 0u;   // (round 6: `nt` on these loads 145 -> 365 us -- they leave the L2; sc0 / sc1 / both: 146-150 us)
 #endif
     }
   }

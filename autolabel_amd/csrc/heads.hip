@@ -19,6 +19,33 @@ extern "C" int aln_sigma_act(const void* sigma_out, int32_t rows, float* sigma, 
   return 0;
 }
 
+// One input row of the colour head: color_in[ci] = [SH16(dir(ray(row))), geo_feat[row] (G), 1...], width in_pad, whole 16-byte
+// chunks in and out (a row is 64 B for in_pad = 32).  Shared by k_build_color_in and the compaction's second pass.
+struct ColorInSrc { const float* rd; const float* dirs; int N, S1, S2; const h16* sigma_out; int G, in_pad; h16* cin; };
+// (Round 6, measured and rejected: FOUR lanes per row, lane q storing chunk q -- 1 KB of contiguous rows per wave instruction instead of
+//  four 16-byte stores at a 64-byte stride: 27 -> 35 us standalone, 37 -> 87 us inside the compaction.  The kernel moves 100 MB per
+//  million live rows at 3.7 TB/s as it is; the stores were not the problem, the four-fold arithmetic is one.)
+__device__ inline void build_color_row(const ColorInSrc& s, int row, int ci) {
+  const float* d;
+  if (s.dirs) d = s.dirs + 3 * (size_t)row;
+  else { int ray = row < s.N * s.S1 ? row / s.S1 : (row - s.N * s.S1) / s.S2; d = s.rd + 3 * (size_t)ray; }
+  float sh[16];
+  sh4_of_dir(d, sh);
+  const h16x8 lo = *(const h16x8*)(s.sigma_out + (size_t)row * 16), hi = *(const h16x8*)(s.sigma_out + (size_t)row * 16 + 8);
+  h16x8 c0, c1, c2, c3;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c0[j] = (h16)sh[j]; c1[j] = (h16)sh[8 + j]; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {   // geo_feat[g] = sigma_out[row][1 + g], ones from G on
+    h16 a = (j < 7) ? lo[j + 1] : hi[0], b = (j < 7) ? hi[j + 1] : (h16)1.0f;
+    c2[j] = (j < s.G) ? a : (h16)1.0f; c3[j] = (8 + j < s.G) ? b : (h16)1.0f;
+  }
+  h16* o = s.cin + (size_t)ci * s.in_pad;
+  *(h16x8*)o = c0; *(h16x8*)(o + 8) = c1; *(h16x8*)(o + 16) = c2;
+  if (s.in_pad >= 32) *(h16x8*)(o + 24) = c3;
+  for (int j = 32; j < s.in_pad; ++j) o[j] = (h16)1.0f;
+}
+
 // live = w > thresh (renderer: mask = weights > 1e-4).  Ballot compaction in ROW ORDER: pass 1 counts the live rows of every
 // 4096-row chunk, pass 2 re-derives the bits, takes the sum of the earlier chunks' counts as its base (<= 512 chunks at 2^21
 // rows: one coalesced read per block) and writes.  The compact order is a pure function of w_row -- the color head sees its rows,
@@ -45,7 +72,7 @@ __global__ __launch_bounds__(256) void k_compact_count(const float* __restrict__
   }
 }
 __global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ w_row, int rows, float thresh, const int* __restrict__ chunk_cnt,
-                                                     int* __restrict__ n_live, int* __restrict__ live_idx, int* __restrict__ cidx_row) {
+                                                     int* __restrict__ n_live, int* __restrict__ live_idx, int* __restrict__ cidx_row, ColorInSrc col) {
   __shared__ int s_cnt[4], s_part[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
@@ -77,7 +104,10 @@ __global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ 
       if (r < rows) {
         int ci = live ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
         cidx_row[r] = ci;
-        if (live) live_idx[ci] = r;
+        if (live) {
+          live_idx[ci] = r;
+          if (col.cin) build_color_row(col, r, ci);   // (round 6: the colour head's input row, built where its place becomes known)
+        }
       }
       off += __popcll(m);
     }
@@ -86,17 +116,32 @@ __global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ 
 }
 // chunk_ws: caller-owned scratch of aln_compact_live_ws_ints(rows) int32 (the per-chunk counts between the two passes)
 extern "C" int32_t aln_compact_live_ws_ints(int32_t rows) { return rows > 0 ? (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK : 0; }
-extern "C" int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx,
-                                int32_t* cidx_row, int32_t* chunk_ws, void* stream) {
+static int compact_launch(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx, int32_t* cidx_row,
+                          int32_t* chunk_ws, ColorInSrc col, void* stream) {
   ALN_REQUIRE(w_row && n_live && live_idx && cidx_row && chunk_ws, "compact_live: NULL pointer");
   if (rows <= 0) { hipMemsetAsync(n_live, 0, sizeof(int), (hipStream_t)stream); return 0; }
   const int nchunks = (rows + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
   hipLaunchKernelGGL(k_compact_count, dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh, chunk_ws);
   ALN_CHECK_LAUNCH("compact_count");
   hipLaunchKernelGGL(k_compact_live, dim3(nchunks < 1024 ? nchunks : 1024), dim3(256), 0, (hipStream_t)stream, w_row, rows, thresh,
-                     (const int*)chunk_ws, n_live, live_idx, cidx_row);
+                     (const int*)chunk_ws, n_live, live_idx, cidx_row, col);
   ALN_CHECK_LAUNCH("compact_live");
   return 0;
+}
+extern "C" int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx,
+                                int32_t* cidx_row, int32_t* chunk_ws, void* stream) {
+  return compact_launch(w_row, rows, thresh, n_live, live_idx, cidx_row, chunk_ws, ColorInSrc{}, stream);
+}
+// the same, and color_in[cidx_row[r]] (aln_build_color_in's rows, bit for bit) for every live row r out of the second pass: no
+// k_build_color_in launch, no second read of live_idx (the training step, round 6)
+extern "C" int aln_compact_live_color_in(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx,
+                                         int32_t* cidx_row, int32_t* chunk_ws, const float* rays_d, const float* dirs, int32_t N,
+                                         int32_t S1, int32_t S2, const void* sigma_out, int32_t G, int32_t in_pad, void* color_in,
+                                         void* stream) {
+  ALN_REQUIRE((rays_d || dirs) && sigma_out && color_in, "compact_live_color_in: NULL pointer");
+  ALN_REQUIRE(G + 1 <= 16 && 16 + G <= in_pad && in_pad % 8 == 0 && (G <= 8 || in_pad >= 32), "compact_live_color_in: geo_feat_dim %d unsupported", G);
+  return compact_launch(w_row, rows, thresh, n_live, live_idx, cidx_row, chunk_ws,
+                        ColorInSrc{rays_d, dirs, N, S1, S2, (const h16*)sigma_out, G, in_pad, (h16*)color_in}, stream);
 }
 
 __global__ void k_sh4(const float* __restrict__ dirs, int rows, int pitch, h16* __restrict__ out) {
@@ -116,33 +161,9 @@ extern "C" int aln_sh4(const float* dirs, int32_t rows, int32_t out_pitch, void*
   return 0;
 }
 
-// color_in[ci] = [SH16(dir(ray(row))), geo_feat[row] (G), 1...]   width in_pad
-__global__ void k_build_color_in(const int* __restrict__ live_idx, const int* __restrict__ n_live, int max_rows,
-                                 const float* __restrict__ rd, const float* __restrict__ dirs, int N, int S1, int S2,
-                                 const h16* __restrict__ sigma_out, int G, int in_pad, h16* __restrict__ cin) {
-  // one thread per row, whole 16-byte chunks in and out (a row is 64 B for in_pad = 32)
-  int n = live_idx ? min(*n_live, max_rows) : max_rows;
-  for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n; ci += gridDim.x * blockDim.x) {
-    int row = live_idx ? live_idx[ci] : ci;
-    const float* d;
-    if (dirs) d = dirs + 3 * (size_t)row;
-    else { int ray = row < N * S1 ? row / S1 : (row - N * S1) / S2; d = rd + 3 * (size_t)ray; }
-    float sh[16];
-    sh4_of_dir(d, sh);
-    const h16x8 lo = *(const h16x8*)(sigma_out + (size_t)row * 16), hi = *(const h16x8*)(sigma_out + (size_t)row * 16 + 8);
-    h16x8 c0, c1, c2, c3;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { c0[j] = (h16)sh[j]; c1[j] = (h16)sh[8 + j]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {   // geo_feat[g] = sigma_out[row][1 + g], ones from G on
-      h16 a = (j < 7) ? lo[j + 1] : hi[0], b = (j < 7) ? hi[j + 1] : (h16)1.0f;
-      c2[j] = (j < G) ? a : (h16)1.0f; c3[j] = (8 + j < G) ? b : (h16)1.0f;
-    }
-    h16* o = cin + (size_t)ci * in_pad;
-    *(h16x8*)o = c0; *(h16x8*)(o + 8) = c1; *(h16x8*)(o + 16) = c2;
-    if (in_pad >= 32) *(h16x8*)(o + 24) = c3;
-    for (int j = 32; j < in_pad; ++j) o[j] = (h16)1.0f;
-  }
+__global__ void k_build_color_in(const int* __restrict__ live_idx, const int* __restrict__ n_live, int max_rows, ColorInSrc src) {
+  int n = live_idx ? min(*n_live, max_rows) : max_rows;   // one thread per row
+  for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n; ci += gridDim.x * blockDim.x) build_color_row(src, live_idx ? live_idx[ci] : ci, ci);
 }
 extern "C" int aln_build_color_in(const int32_t* live_idx, const int32_t* n_live, int32_t max_rows, const float* rays_d,
                                   const float* dirs, int32_t N, int32_t S1, int32_t S2, const void* sigma_out, int32_t G,
@@ -151,7 +172,7 @@ extern "C" int aln_build_color_in(const int32_t* live_idx, const int32_t* n_live
   ALN_REQUIRE(G + 1 <= 16 && 16 + G <= in_pad && in_pad % 8 == 0 && (G <= 8 || in_pad >= 32), "build_color_in: geo_feat_dim %d unsupported", G);
   if (max_rows <= 0) return 0;
   hipLaunchKernelGGL(k_build_color_in, dim3(aln_grid_for(max_rows, 256)), dim3(256), 0, (hipStream_t)stream, live_idx, n_live,
-                     max_rows, rays_d, dirs, N, S1, S2, (const h16*)sigma_out, G, in_pad, (h16*)color_in);
+                     max_rows, ColorInSrc{rays_d, dirs, N, S1, S2, (const h16*)sigma_out, G, in_pad, (h16*)color_in});
   ALN_CHECK_LAUNCH("build_color_in");
   return 0;
 }

@@ -11,7 +11,7 @@ import torch
 from .build import LIB
 
 ALN_MAX_LEVELS = 16
-ABI_VERSION = 8   # include/autolabel_hip.h: ALN_ABI_VERSION
+ABI_VERSION = 9   # include/autolabel_hip.h: ALN_ABI_VERSION
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
 
 
@@ -100,6 +100,7 @@ _SIGS = {
     'aln_sigma_act': (i32, [vp, i32, vp, vp]),
     'aln_compact_live_ws_ints': (i32, [i32]),
     'aln_compact_live': (i32, [vp, i32, f32, vp, vp, vp, vp, vp]),
+    'aln_compact_live_color_in': (i32, [vp, i32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp]),
     'aln_color_fwd': (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp]),
     'aln_build_color_in': (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp]),
     'aln_build_sem_in': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),

@@ -270,6 +270,7 @@ class HipPipeline:
         # the planes themselves (AlnMlpDesc.x_tiled = 2): no k_encode_assemble pass (2 x 22 us per step, 200 MB), no second buffer.
         self.planes_enc_train = True
         self.fold_dsigma = True          # (bench.py --no-fold-dsigma: A/B against the aln_assemble_grads pass)
+        self.fold_color_in = True        # (bench.py --no-fold-color-in: A/B against the aln_build_color_in pass)
         # backward rebuilds hidden activations from the layer inputs (no h1/h2 saved in forward) when every fused head has a
         # recompute kernel; other shapes (e.g. 64-wide density / color nets) save them and use the generic backward kernels
         self.recompute = all(k in params.wide_w or H.lib().aln_mlp_has_recompute(s.in_pad, s.hidden, s.out_pad, s.n_hidden)
@@ -571,15 +572,21 @@ class HipPipeline:
         n_live, live_idx, cidx = g('n_live', (1,), i32_), g('live_idx', (M,), i32_), g('cidx_row', (M,), i32_)
         c.update(n_live=n_live, live_idx=live_idx, cidx_row=cidx)
         chunk_ws = g('compact_ws', (max(int(H.lib().aln_compact_live_ws_ints(M)), 1),), i32_)
-        H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(chunk_ws), H.stream())
         cs = nets['color']
         cin = c['color_in'] = g('color_in', (M, cs.in_pad), f16)
+        build_cin = train or cs.in_pad != 32
+        if build_cin and self.fold_color_in:   # (the input rows of the colour head leave the compaction's second pass: no k_build_color_in launch)
+            H.call('aln_compact_live_color_in', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(chunk_ws),
+                   H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G, cs.in_pad, H.ptr(cin), H.stream())
+        else:
+            H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(chunk_ws), H.stream())
         ch1 = c['ch1'] = g('ch1', (M if save else 1, cs.hidden), f16)
         ch2 = c['ch2'] = g('ch2', (M if save else 1, cs.hidden), f16)
         cout = c['color_out'] = g('color_out', (M, cs.out_pad), f16)
-        if train or cs.in_pad != 32:
-            H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G,
-                   cs.in_pad, H.ptr(cin), H.stream())
+        if build_cin:
+            if not self.fold_color_in:
+                H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), L.G,
+                       cs.in_pad, H.ptr(cin), H.stream())
             self._k('aln_mlp_fwd', C.byref(P.descs['color']), H.ptr(cin), M, H.ptr(n_live), H.ptr(ch1) if save else None,
                     H.ptr(ch2) if save else None, H.ptr(cout), H.stream(), tag=('color', n_live))
         else:   # inference: the input rows are built inside the kernel (no color_in round trip through HBM)

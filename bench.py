@@ -61,6 +61,7 @@ def parse():
     p.add_argument('--no-tiled-enc', action='store_true', help='A/B: hash-grid forward through plane buffers + the assembly pass instead of the tiled layout')
     p.add_argument('--no-planes-enc', action='store_true', help='A/B: the training step through row-major encoded rows + the assembly pass instead of the pair planes the 128-wide kernels read themselves')
     p.add_argument('--no-fold-dsigma', action='store_true', help="A/B: the density head's dL/dout rows through aln_assemble_grads instead of the backward kernel's own loader")
+    p.add_argument('--no-fold-color-in', action='store_true', help="A/B: the colour head's input rows through aln_build_color_in instead of the compaction's second pass")
     p.add_argument('--tiled-enc-train', action='store_true', help='A/B: the tiled hash-grid output in the training step too (default: rendering only)')
     p.add_argument('--no-dp1', action='store_true', help='skip the leg that runs the data-parallel forms of the step through a one-rank RCCL group')
     p.add_argument('--no-dropin', action='store_true', help="skip the leg that times the reference's own route (scene directory -> SimpleTrainer)")
@@ -128,6 +129,7 @@ class Workload:
         pipe.tiled_enc_train = bool(getattr(a, 'tiled_enc_train', False))
         pipe.planes_enc_train = not getattr(a, 'no_planes_enc', False)
         pipe.fold_dsigma = not getattr(a, 'no_fold_dsigma', False)
+        pipe.fold_color_in = not getattr(a, 'no_fold_color_in', False)
         if march:
             t = self.train
             pipe.enable_marching(G=128, max_steps=1024, samples=a.march_samples, density_thresh=a.march_thresh)
@@ -277,21 +279,21 @@ def scatter_roofline(eng, events, rows_per_step, n_event_steps):
     records = eng.pipe.binned_record_count(rows_per_step, ws=eng.ws)   # PAIR records of the last launch (same state as the events)
     rec_bytes = 2 * 12 * records if records else None                 # 12 bytes each, written once by phase 1, read once by phase 2
     return {'kernel': 'k_encode_bwd_bin + k_encode_bwd_accum (hash-grid backward, one launch pair' + ("; the table's Adam step inside phase 2)" if fused else ')'),
-            'bound': 'hbm (limiter: lds staging + pool writes in phase 1, instruction issue in phase 2)',
+            'bound': "hbm (phase 2 with the table's optimizer inside runs at the HBM rate of its own traffic; phase 1 is latency- and issue-bound)",
             'achieved': alg / avg_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': alg / avg_s / 1e9 / 8000.0, 'traffic': None,
             'avg_launch_us': avg_s * 1e6, 'launches': len(durs), 'rows_per_launch': rows_per_step, 'algorithmic_bytes_per_launch': alg,
             'algorithmic_bytes_scatter': alg_scatter, 'algorithmic_bytes_optimizer': alg_adam, 'optimizer_fused_into_phase2': fused,
             'pair_without_optimizer_us': getattr(eng, 'pair_without_optimizer_us', None),
             'pair_records_per_launch': records, 'pair_record_bytes': 12, 'record_traffic_bytes_per_launch': rec_bytes,
             'pair_records_per_s': records / avg_s if records else None,
-            'limiter': 'not HBM bandwidth alone (round-6 section clocks and stubs, profiles/NOTES_experiments.md): phase 1 is the sum of its parts -- '
-                       'corner arithmetic, ranking atomics, sorted LDS stores and the copy-out of the 743 MB of records (LDS read-back + global stores: '
-                       '40 % of the kernel; the plain write of that pool alone is 114 us at 6.85 TB/s); phase 2 is instruction-issue-bound at 4 waves per '
-                       'SIMD (~23 instructions to request a run, ~25 per 64-lane piece of it, runs of ~45 records fill 55 % of the lanes) plus the '
-                       "table's optimizer step at cache bandwidth; its 16 waves per block share the tiles dynamically since round 6 (-17 %)",
+            'limiter': 'round-6 section clocks and stub builds (profiles/NOTES_experiments.md): phase 2 with the optimizer inside reads the 585 MB of '
+                       'pair records and moves 436 MB of optimizer state in ~205 us = 4.9 TB/s -- taking the LDS atomics or the conversions out of it '
+                       'changes nothing (without the optimizer: 232 -> 191 / 211 us), its own traffic is the roof; phase 1 (~295 us) is three times '
+                       'its HBM time: per level corner arithmetic, ranking atomics, the sorted LDS stores and the copy-out share one critical '
+                       'path between two barriers, 2.67 rounds of 768 resident blocks',
             'note': 'HIP events around the launch pair over %d launch-by-launch steps right after the timed region (the timed region itself '
-                    'replays a hipGraph, which cannot carry events); phase 1 sorts fp16x2 (index, value) records by table slice in LDS and '
-                    'streams them out (8 B/record), phase 2 streams them back and accumulates in 64-bit fixed point in LDS: no global '
+                    'replays a hipGraph, which cannot carry events); phase 1 sorts PAIR records (two slots, two fp16x2 values: 12 B) by table slice in LDS and '
+                    'streams them out, phase 2 streams them back and accumulates in 64-bit fixed point in LDS: no global '
                     'atomics, bit-reproducible; on one GPU phase 2 applies Adam to its slice of the table from those sums (no gradient round '
                     'trip through HBM, no separate optimizer pass over the 14.2 M table parameters); pair_without_optimizer_us = the same pair '
                     'with the optimizer left to aln_adam_step (4 extra launch-by-launch steps, bit-identical results)' % n_event_steps}

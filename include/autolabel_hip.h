@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define ALN_MAX_LEVELS 16
-#define ALN_ABI_VERSION 8
+#define ALN_ABI_VERSION 9
 
 /* tcnn GridEncoding config, autolabel/models.py:38-48 */
 typedef struct {
@@ -275,6 +275,11 @@ int aln_sigma_act(const void* sigma_out /*[rows,16] f16*/, int32_t rows, float* 
 int32_t aln_compact_live_ws_ints(int32_t rows);
 int aln_compact_live(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx, int32_t* cidx_row,
                      int32_t* chunk_ws, void* stream);
+/* aln_compact_live + aln_build_color_in in the compaction's second pass (round 6, ABI 9): color_in[cidx_row[r]] is written for
+ * every live row r where its place becomes known -- the same rows bit for bit, one launch and one read of live_idx less */
+int aln_compact_live_color_in(const float* w_row, int32_t rows, float thresh, int32_t* n_live, int32_t* live_idx, int32_t* cidx_row,
+                              int32_t* chunk_ws, const float* rays_d, const float* dirs, int32_t N, int32_t S1, int32_t S2,
+                              const void* sigma_out, int32_t G, int32_t in_pad, void* color_in, void* stream);
 /* tcnn SphericalHarmonics(degree 4) of the remapped direction (autolabel/models.py:97-103,205-207): out[r, 0:16] f16 */
 int aln_sh4(const float* dirs /*[rows,3]*/, int32_t rows, int32_t out_pitch /*halves, >= 16*/, void* out, void* stream);
 /* color_net forward with its input rows built inside the kernel from live_idx / directions / sigma_out (inference path:

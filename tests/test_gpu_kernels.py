@@ -1274,3 +1274,40 @@ def test_cell_mode_encoding_equals_encoding_of_the_grid_points(H):
         planes = torch.empty(int(H.lib().aln_encode_fwd_ws_bytes(C.byref(e), rows)), dtype=torch.uint8, device='cuda') if phased else None
         H.call('aln_encode_fwd_cells', C.byref(e), H.ptr(table), G, 11, 1, H.ptr(step_dev), a, rows, H.ptr(planes), H.ptr(got), H.stream())
         assert torch.equal(got, want), f'phased={phased}'
+
+
+@pytest.mark.parametrize('N,S1,S2,G', [(300, 32, 32, 15), (37, 24, 8, 9), (1, 5, 3, 15)])
+def test_compaction_builds_the_colour_input_rows_in_its_second_pass(H, N, S1, S2, G):
+    """aln_compact_live_color_in (round 6): the same n_live / live_idx / cidx_row as aln_compact_live, and the colour head's input rows
+    [SH16(dir) | geo_feat | 1] of aln_build_color_in bit for bit -- written where a live row's place becomes known (one launch less;
+    autolabel/models.py:190-203: the boolean-mask gather in front of color_net)."""
+    M = N * (S1 + S2)
+    g = torch.Generator().manual_seed(5)
+    w_row = (torch.rand(M, generator=g) * 3e-4).cuda()          # about two thirds of the rows pass the 1e-4 threshold
+    rays_d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1).cuda()
+    sout = torch.randn(M, 16, generator=g).half().cuda()
+    nws = max(int(H.lib().aln_compact_live_ws_ints(M)), 1)
+
+    def run(fused):
+        n_live = torch.full((1,), -7, dtype=torch.int32, device='cuda')
+        live_idx = torch.full((M,), -7, dtype=torch.int32, device='cuda')
+        cidx = torch.full((M,), -7, dtype=torch.int32, device='cuda')
+        ws = torch.zeros(nws, dtype=torch.int32, device='cuda')
+        cin = torch.full((M, 32), float('nan'), dtype=torch.float16, device='cuda')
+        if fused:
+            H.call('aln_compact_live_color_in', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(ws), H.ptr(rays_d), None,
+                   N, S1, S2, H.ptr(sout), G, 32, H.ptr(cin), H.stream())
+        else:
+            H.call('aln_compact_live', H.ptr(w_row), M, 1e-4, H.ptr(n_live), H.ptr(live_idx), H.ptr(cidx), H.ptr(ws), H.stream())
+            H.call('aln_build_color_in', H.ptr(live_idx), H.ptr(n_live), M, H.ptr(rays_d), None, N, S1, S2, H.ptr(sout), G, 32, H.ptr(cin), H.stream())
+        torch.cuda.synchronize()
+        return int(n_live.item()), live_idx, cidx, cin
+
+    n0, li0, ci0, cin0 = run(False)
+    n1, li1, ci1, cin1 = run(True)
+    live = (w_row > 1e-4)
+    assert n0 == n1 == int(live.sum().item()) and 0 < n0 < M
+    assert torch.equal(li0[:n0], li1[:n1]) and torch.equal(li0[:n0].long(), live.nonzero().flatten())
+    assert torch.equal(ci0, ci1)
+    assert torch.equal(cin0[:n0].view(torch.int16), cin1[:n1].view(torch.int16))
+    assert torch.isnan(cin1[n1:]).all()          # nothing is written past the live rows

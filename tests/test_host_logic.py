@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_every_declared_symbol():
     from autolabel_amd import hip
     L = hip.lib()
-    assert L.aln_abi_version() == hip.ABI_VERSION == 8
+    assert L.aln_abi_version() == hip.ABI_VERSION == 9
     header = open(os.path.join(ROOT, 'include', 'autolabel_hip.h')).read()
     declared = set(re.findall(r'\b(aln_[a-z0-9_]+)\s*\(', header))
     assert declared, 'no declarations found'
