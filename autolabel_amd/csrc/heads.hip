@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void k_compact_count(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < COMPACT_ITERS; ++i) {
       const int r = r0 + i * 64 + lane;
-      cnt += __popcll(__ballot(r < rows && w_row[r] > thresh));
+      const float wv = w_row[min(r, rows - 1)];   // (unconditional: behind a load in a branch hipcc waits for each of the sixteen in turn)
+      cnt += __popcll(__ballot(r < rows && wv > thresh));
     }
     if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < COMPACT_ITERS; ++i) {
       int r = r0 + i * 64 + lane;
-      bool live = r < rows && w_row[r] > thresh;
+      const float wv = w_row[min(r, rows - 1)];
+      bool live = r < rows && wv > thresh;
       bits |= (unsigned)live << i;
       cnt += __popcll(__ballot(live));
     }

@@ -30,6 +30,22 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void k_loss(LossArgs a) {
   __shared__ int last_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float scale = a.loss_scale ? *a.loss_scale : 1.f;
+  // Everything a ray reads, requested unconditionally (clamped lanes, values dropped where they do not apply): with a load per
+  // `if (lane < 3)` / `if (lane == 0)` / label branch hipcc waited for each in turn -- ten HBM round trips per ray in a kernel that is
+  // nothing but one wave's chain of them (round 6).  The first ray's request goes out BEFORE the count loop below: one trip for both.
+  struct RayIn { float im, gt, gd, dp, sem, f, gf; int label; };
+  const bool feat_gt = a.g_feat && a.gt_feat && a.Cf > 0;
+  auto fetch = [&](int ray) {
+    RayIn q{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, -1};
+    ray = min(ray, a.N - 1);   // (past the batch: a valid ray, never used -- a branch here would put a wait behind it)
+    const int l3 = min(lane, 2);
+    q.im = a.image[3 * (size_t)ray + l3]; q.gt = a.gt_rgb[3 * (size_t)ray + l3];
+    q.gd = a.gt_depth[ray]; q.dp = a.depth[ray];
+    if (a.g_sem) { q.label = a.gt_sem[ray]; q.sem = a.semantic[(size_t)ray * a.C + min(lane, a.C - 1)]; }
+    if (feat_gt) { const int d = min(lane, a.Cf - 1); q.f = a.features[(size_t)ray * a.D + d]; q.gf = a.gt_feat[(size_t)ray * a.Cf + d]; }
+    return q;
+  };
+  RayIn cur = fetch(blockIdx.x * LOSS_WAVES + wave);
   int nd = 0, ns = 0;
   {   // 16-byte loads over the aligned body of the two arrays, the tail element-wise
     const int n4 = (((uintptr_t)a.gt_depth | (uintptr_t)a.gt_sem) & 15) == 0 ? a.N / 4 : 0;
@@ -49,15 +65,18 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void k_loss(LossArgs a) {
   for (int w = 0; w < LOSS_WAVES; ++w) { nd += cnt_s[w][0]; ns += cnt_s[w][1]; }
   float t_rgb = 0, t_depth = 0, t_feat = 0, t_sem = 0;
   for (int ray = blockIdx.x * LOSS_WAVES + wave; ray < a.N; ray += gridDim.x * LOSS_WAVES) {
+    const float q_im = cur.im, q_gt = cur.gt, q_gd = cur.gd, q_dp = cur.dp, q_sem = cur.sem, q_f = cur.f, q_gf = cur.gf;
+    const int label = cur.label;
+    cur = fetch(ray + gridDim.x * LOSS_WAVES);   // (the next ray of this wave, if the batch has more rays than the launch has waves)
     if (lane < 3) {
-      float diff = a.image[3 * (size_t)ray + lane] - a.gt_rgb[3 * (size_t)ray + lane];
+      float diff = q_im - q_gt;
       t_rgb += diff * diff;
       a.g_image[3 * (size_t)ray + lane] = scale * a.w_rgb * 2.f * diff / (3.f * a.N);
     }
     if (lane == 0) {
-      float g = 0.f, gd = a.gt_depth[ray];
+      float g = 0.f, gd = q_gd;
       if (gd > DEPTH_EPSILON) {
-        float diff = a.depth[ray] - gd;
+        float diff = q_dp - gd;
         t_depth += fabsf(diff);
         g = scale * a.w_depth * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) / (float)nd;
       }
@@ -67,7 +86,8 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void k_loss(LossArgs a) {
       for (int d = lane; d < a.D; d += 64) {
         float g = 0.f;
         if (a.gt_feat && d < a.Cf) {
-          float diff = a.features[(size_t)ray * a.D + d] - a.gt_feat[(size_t)ray * a.Cf + d];
+          const float fv = d < 64 ? q_f : a.features[(size_t)ray * a.D + d], gv = d < 64 ? q_gf : a.gt_feat[(size_t)ray * a.Cf + d];   // (the first 64 columns came with the batch above)
+          float diff = fv - gv;
           t_feat += fabsf(diff);
           g = scale * a.w_feat * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) / ((float)a.N * a.Cf);
         }
@@ -75,17 +95,17 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void k_loss(LossArgs a) {
       }
     }
     if (a.g_sem) {
-      int label = a.gt_sem[ray];
       if (label >= 0) {
+        auto sem_at = [&](int c) { return c < 64 ? q_sem : a.semantic[(size_t)ray * a.C + c]; };   // (c = lane + 64 k: the first chunk is in a register)
         float mx = -INFINITY;
-        for (int c = lane; c < a.C; c += 64) mx = fmaxf(mx, a.semantic[(size_t)ray * a.C + c]);
+        for (int c = lane; c < a.C; c += 64) mx = fmaxf(mx, sem_at(c));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float se = 0.f;
-        for (int c = lane; c < a.C; c += 64) se += expf(a.semantic[(size_t)ray * a.C + c] - mx);
+        for (int c = lane; c < a.C; c += 64) se += expf(sem_at(c) - mx);
         se = wave_sum(se);
         for (int c = lane; c < a.C; c += 64) {
-          float l = a.semantic[(size_t)ray * a.C + c];
+          float l = sem_at(c);
           float pr = expf(l - mx) / se;
           if (c == label) t_sem += -(l - mx - logf(se));
           a.g_sem[(size_t)ray * a.C + c] = scale * a.w_sem * (pr - (c == label ? 1.f : 0.f)) / (float)ns;

@@ -105,8 +105,21 @@ __global__ __launch_bounds__(RG_BLOCK) void k_raygen_train(RaygenArgs args) {
         int lo_o = off[a.frame_lo], hi_o = off[a.frame_hi];
         if (hi_o > lo_o) {
           int r = lo_o + (int)(aln_rand_u32(a.k_cls, 3u * (uint32_t)ch + 2u) % (uint32_t)(hi_o - lo_o));
-          int f0 = a.frame_lo, f1 = a.frame_hi;      // largest f with off[f] <= r
-          while (f1 - f0 > 1) { int m = (f0 + f1) >> 1; if (off[m] <= r) f0 = m; else f1 = m; }
+          int f0 = a.frame_lo, f1 = a.frame_hi;      // largest f with off[f] <= r  (invariant: off[f0] <= r < off[f1])
+          // sixteen-way search: fifteen pivots per step, all requested at once -- two HBM round trips for 200 frames where the binary
+          // search made eight, one after the other, and this kernel is nothing but the longest such chain of its 64 waves (round 6)
+          while (f1 - f0 > 1) {
+            const int stp = (f1 - f0 + 15) / 16;
+            int v[15];
+#pragma unroll
+            for (int j = 0; j < 15; ++j) v[j] = off[min(f0 + stp * (j + 1), f1)];
+            int n0 = f0, n1 = f1;
+#pragma unroll
+            for (int j = 0; j < 15; ++j) { const int m = f0 + stp * (j + 1); if (m < f1 && v[j] <= r) n0 = m; }
+#pragma unroll
+            for (int j = 14; j >= 0; --j) { const int m = f0 + stp * (j + 1); if (m < f1 && v[j] > r) n1 = m; }
+            f0 = n0; f1 = n1;
+          }
           frame = f0;
           pix = a.fr.cls_pixels[off[f0] + (int)(aln_rand_u32(a.k_pix, (uint32_t)b) % (uint32_t)(off[f0 + 1] - off[f0]))];
         } else labelled = false;                     // this rank's frame shard has no pixel of that class
@@ -119,15 +132,32 @@ __global__ __launch_bounds__(RG_BLOCK) void k_raygen_train(RaygenArgs args) {
       if (feats) frow[threadIdx.x] = feature_row(a.fr, frame, pix);
       float jx = a.jitter ? a.jitter[2 * b] : aln_rand_uniform(a.k_jx, (uint32_t)b);
       float jy = a.jitter ? a.jitter[2 * b + 1] : aln_rand_uniform(a.k_jy, (uint32_t)b);
-      float d[3], nn;
-      pixel_direction(a.fr.rotations + 9 * (size_t)frame, pix, a.fr.w, a.fr.fx, a.fr.fy, a.fr.cx, a.fr.cy, true, jx, jy, d, &nn);
+      // every read of the ray FIRST, then its stores (round 6): the outputs may alias the frame arrays as far as hipcc knows, so a load
+      // written behind a store is issued behind it -- the rotation, the origin, the pixel, its depth and its label were five round trips
+      float Rm[9], org[3], rgb[3] = {0.f, 0.f, 0.f};
+      const size_t src = (size_t)frame * ((size_t)a.fr.w * a.fr.h) + pix;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        a.out.rays_d[3 * (size_t)b + k] = d[k];
-        a.out.rays_o[3 * (size_t)b + k] = a.fr.origins[3 * (size_t)frame + k];
+      for (int k = 0; k < 9; ++k) Rm[k] = a.fr.rotations[9 * (size_t)frame + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) org[k] = a.fr.origins[3 * (size_t)frame + k];
+      if (a.out.pixels) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rgb[k] = a.fr.images[3 * src + k];
       }
+      uint16_t dep_raw = 0; uint8_t sem_raw = 0;
+      if (a.out.depth) dep_raw = a.fr.depths[src];
+      if (a.out.semantic) sem_raw = a.fr.semantics[src];
+      float d[3], nn;
+      pixel_direction(Rm, pix, a.fr.w, a.fr.fx, a.fr.fy, a.fr.cx, a.fr.cy, true, jx, jy, d, &nn);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { a.out.rays_d[3 * (size_t)b + k] = d[k]; a.out.rays_o[3 * (size_t)b + k] = org[k]; }
       a.out.norms[b] = nn;
-      gather_pixel<false>(a.fr, a.out, b, frame, pix);
+      if (a.out.pixels) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.out.pixels[3 * (size_t)b + k] = rgb[k];
+      }
+      if (a.out.depth) a.out.depth[b] = (float)((double)dep_raw / 1000.0);       // dataset.py:220
+      if (a.out.semantic) a.out.semantic[b] = (int)sem_raw - 1;                  // dataset.py:221-222
     }
     if (feats) {
       __syncthreads();

@@ -137,14 +137,34 @@ __global__ __launch_bounds__(64) void k_sample_fine(const float* __restrict__ zc
   float* u = w + S1;        // [S2p]
   const int lane = threadIdx.x;
   for (int ray = blockIdx.x; ray < N; ray += gridDim.x) {
+    // (round 6: the ray's distances and densities are requested together, before near / far are used -- one HBM round trip at the top of
+    //  the wave's chain instead of one per 64 samples and array; see k_composite_fwd)
+    constexpr int KU = 4;
+    const bool fast = S1 <= 64 * KU;
+    float zr[KU], sr[KU];
+    if (fast) {
+#pragma unroll
+      for (int q = 0; q < KU; ++q) { const int i = min(lane + 64 * q, S1 - 1); zr[q] = zc[(size_t)ray * S1 + i]; sr[q] = sigma[(size_t)ray * S1 + i]; }
+    }
     const float sd = __fdiv_rn(__fsub_rn(fars[ray], nears[ray]), (float)S1);
-    for (int i = lane; i < S1; i += 64) z[i] = zc[(size_t)ray * S1 + i];
+    if (fast) {
+#pragma unroll
+      for (int q = 0; q < KU; ++q) { const int i = lane + 64 * q; if (i < S1) z[i] = zr[q]; }
+    } else {
+      for (int i = lane; i < S1; i += 64) z[i] = zc[(size_t)ray * S1 + i];
+    }
     __syncthreads();
-    for (int i = lane; i < S1; i += 64) {
+    auto alpha_of = [&](int i, float sigma_i) {
       float delta = (i + 1 < S1) ? z[i + 1] - z[i] : sd;
-      float alpha = 1.f - expf(-delta * density_scale * sigma[(size_t)ray * S1 + i]);
+      float alpha = 1.f - expf(-delta * density_scale * sigma_i);
       w[i] = alpha;
       a[i] = 1.f - alpha + 1e-15f;
+    };
+    if (fast) {
+#pragma unroll
+      for (int q = 0; q < KU; ++q) { const int i = lane + 64 * q; if (i < S1) alpha_of(i, sr[q]); }
+    } else {
+      for (int i = lane; i < S1; i += 64) alpha_of(i, sigma[(size_t)ray * S1 + i]);
     }
     __syncthreads();
     scan_excl_prod(a, b, S1, lane);
@@ -243,13 +263,36 @@ __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
   float* T = v + S;
   float* zin = T + S;      // unsorted z [S]
   uint16_t* lid = (uint16_t*)(zin + S);  // [S]
+  constexpr int KU = 4;   // samples per lane whose inputs are requested up front (the training step: 256 samples per ray)
+  const bool fast = S <= 64 * KU;
   for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
+    // One wave walks one ray and every ray of a batch is resident at once: the kernel's time is the length of this wave's chain of HBM
+    // round trips.  Round 6: everything the ray reads -- distances, densities, near / far, the norm, origin and direction -- is requested
+    // HERE, before the first value is used (it was: four serial trips for z, four for sigma behind the rank searches, three for the scalars).
+    float zr[KU], sr[KU];
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int i = lane + 64 * u;
+        const size_t row = row_of(ray, i < S ? i : 0, p.N, p.S1, p.S2);
+        zr[u] = p.z[row]; sr[u] = p.sigma[row];
+      }
+    }
+    const float near_ = p.nears[ray], far_ = p.fars[ray], norm_ = p.norms[ray];
+    float ro[3], rd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ro[k] = p.ro[3 * (size_t)ray + k]; rd[k] = p.rd[3 * (size_t)ray + k]; }
     // (a NaN distance -- a diverged field -- would make the two rank rules below inconsistent and leave slots of the
     //  permutation unwritten; it is ordered like +inf instead.  Finite inputs are untouched.)
-    for (int i = lane; i < S; i += 64) { const float zz = p.z[row_of(ray, i, p.N, p.S1, p.S2)]; zin[i] = zz == zz ? zz : 3.0e38f; }
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) { const int i = lane + 64 * u; if (i < S) zin[i] = zr[u] == zr[u] ? zr[u] : 3.0e38f; }
+    } else {
+      for (int i = lane; i < S; i += 64) { const float zz = p.z[row_of(ray, i, p.N, p.S1, p.S2)]; zin[i] = zz == zz ? zz : 3.0e38f; }
+    }
     __syncthreads();
     const float* zc = zin; const float* zf = zin + p.S1;
-    for (int i = lane; i < S; i += 64) {
+    auto place = [&](int i, float sigma_i) {
       int pos;
       if (i < p.S1) {  // # fine strictly less
         float x = zc[i]; int lo = 0, hi = p.S2;
@@ -261,11 +304,17 @@ __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
         pos = (i - p.S1) + lo;
       }
       zs[pos] = zin[i];
-      sg[pos] = p.sigma[row_of(ray, i, p.N, p.S1, p.S2)];
+      sg[pos] = sigma_i;
       lid[pos] = (uint16_t)i;
+    };
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) { const int i = lane + 64 * u; if (i < S) place(i, sr[u]); }
+    } else {
+      for (int i = lane; i < S; i += 64) place(i, p.sigma[row_of(ray, i, p.N, p.S1, p.S2)]);
     }
     __syncthreads();
-    const float sd = __fdiv_rn(__fsub_rn(p.fars[ray], p.nears[ray]), (float)p.S1);
+    const float sd = __fdiv_rn(__fsub_rn(far_, near_), (float)p.S1);
     for (int k = lane; k < S; k += 64) {
       float delta = p.delta_in ? p.delta_in[(size_t)ray * S + k] : ((k + 1 < S) ? zs[k + 1] - zs[k] : sd);
       float alpha = 1.f - expf(-delta * p.density_scale * sg[k]);
@@ -276,7 +325,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
     __syncthreads();
     scan_excl_prod(v, T, S, lane);
     __syncthreads();
-    const float inv_norm = 1.0f / p.norms[ray];
+    const float inv_norm = 1.0f / norm_;
     float a_w = 0.f, a_d = 0.f, a_c[3] = {0, 0, 0};
     for (int k = lane; k < S; k += 64) {
       float w = sg[k] * T[k];
@@ -284,7 +333,7 @@ __global__ __launch_bounds__(64) void k_composite_fwd(CompFwd p) {
       p.w_row[row] = w; p.T_row[row] = T[k]; p.delta_row[row] = zin[k];
       p.perm[(size_t)ray * S + k] = lid[k];
       float x[3];
-      aln_sample_xyz(p.ro + 3 * (size_t)ray, p.rd + 3 * (size_t)ray, zs[k], p.bound, x);
+      aln_sample_xyz(ro, rd, zs[k], p.bound, x);
       a_w += w; a_d += w * (zs[k] * inv_norm);
       a_c[0] += w * x[0]; a_c[1] += w * x[1]; a_c[2] += w * x[2];
       v[k] = w;  // keep for variance pass
@@ -335,16 +384,26 @@ struct CompOut {
 __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
   const int S = p.S1 + p.S2, lane = threadIdx.x;
   for (int ray = blockIdx.x; ray < p.N; ray += gridDim.x) {
-    // rgb: lanes split the samples, wave-reduce
+    // rgb: lanes split the samples, wave-reduce.  Four samples per lane at a time, every load UNCONDITIONAL (clamped sample / compact
+    // index, the value dropped afterwards): the whole kernel is one wave's chain of HBM round trips -- all rays are resident at once -- and
+    // with a load per branch hipcc waits for each in turn: eight dependent round trips for 256 samples, now two (round 6).
     float c0 = 0, c1 = 0, c2 = 0;
-    for (int k = lane; k < S; k += 64) {
-      size_t row = row_of(ray, k, p.N, p.S1, p.S2);
-      int ci = p.cidx_row[row];
-      if (ci >= 0) {
-        float w = p.w_row[row];
-        h16x4 o = *(const h16x4*)(p.color_out + (size_t)ci * 16);
-        c0 += w / (1.f + expf(-(float)o[0])); c1 += w / (1.f + expf(-(float)o[1])); c2 += w / (1.f + expf(-(float)o[2]));
+    for (int k0 = 0; k0 < S; k0 += 256) {
+      int ci[4]; float w[4]; h16x4 o[4]; bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 64 * u + lane;
+        ok[u] = k < S;
+        const size_t row = row_of(ray, ok[u] ? k : 0, p.N, p.S1, p.S2);
+        ci[u] = p.cidx_row[row]; w[u] = p.w_row[row];
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = *(const h16x4*)(p.color_out + (size_t)max(ci[u], 0) * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u] && ci[u] >= 0) {
+          c0 += w[u] / (1.f + expf(-(float)o[u][0])); c1 += w[u] / (1.f + expf(-(float)o[u][1])); c2 += w[u] / (1.f + expf(-(float)o[u][2]));
+        }
     }
     c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
     if (lane == 0) {
@@ -357,8 +416,16 @@ __global__ __launch_bounds__(64) void k_composite_out(CompOut p) {
       const float* a2 = p.tile_sums + ((size_t)p.N * t1 + (size_t)ray * t2) * 96;
       for (int ch = lane; ch < 96; ch += 64) {
         float a = 0.f;
-        for (int t = 0; t < t1; ++t) a += a1[t * 96 + ch];
-        for (int t = 0; t < t2; ++t) a += a2[t * 96 + ch];
+        // (four tiles requested at a time, added in tile order: the same sum, a quarter of the round trips)
+        auto tiles = [&](const float* q, int nt) {
+          int t = 0;
+          for (; t + 4 <= nt; t += 4) {
+            const float v0 = q[t * 96 + ch], v1 = q[(t + 1) * 96 + ch], v2 = q[(t + 2) * 96 + ch], v3 = q[(t + 3) * 96 + ch];
+            a += v0; a += v1; a += v2; a += v3;
+          }
+          for (; t < nt; ++t) a += q[t * 96 + ch];
+        };
+        tiles(a1, t1); tiles(a2, t2);
         if (ch < 64) { if (p.features) p.features[(size_t)ray * p.D + ch] = a; }
         else if (ch - 64 < p.C && p.semantic) p.semantic[(size_t)ray * p.C + ch - 64] = a;
       }
@@ -508,9 +575,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB_WPE))) vo
             ok[u] = k < S;
             rowv[u] = row_of(ray, ok[u] ? k : 0, p.N, p.S1, p.S2);
             const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            vl[u] = (hl && ok[u]) ? *(const h16x8*)(p.logits + rowv[u] * p.Cpad + 8 * cg) : zero;
-            vf[u] = (hfe && ok[u]) ? *(const h16x8*)(p.feat + rowv[u] * p.D + 8 * cg) : zero;
-            wv[u] = (need_w && ok[u]) ? p.w_row[rowv[u]] : 0.f;
+            // (unconditional loads -- the row is a valid one for every lane, the chunk clamped; see the note at part 2)
+            vl[u] = zero; vf[u] = zero;
+            if (nch_l) { const h16x8 q = *(const h16x8*)(p.logits + rowv[u] * p.Cpad + 8 * min(cg, nch_l - 1)); vl[u] = (hl && ok[u]) ? q : zero; }
+            if (nch_f) { const h16x8 q = *(const h16x8*)(p.feat + rowv[u] * p.D + 8 * min(cg, nch_f - 1)); vf[u] = (hfe && ok[u]) ? q : zero; }
+            { const float q = p.w_row[rowv[u]]; wv[u] = (need_w && ok[u]) ? q : 0.f; }
           }
 #pragma unroll
           for (int u = 0; u < CB_KU1; ++u) {
@@ -579,30 +648,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB_WPE))) vo
     }
     const int nit = (S + 63) >> 6;
     const bool keep = nit <= CB_KU;    // part 3 visits the rows of part 2: its operands are requested here when they fit the registers
-    size_t krow[CB_KU]; float kdel[CB_KU], kT[CB_KU], ksig[CB_KU], kh0[CB_KU];
+    size_t krow[CB_KU]; float kdel[CB_KU], kT[CB_KU], ksig[CB_KU]; h16 kh0h[CB_KU];
     for (int i0 = 0; i0 < nit; i0 += CB_KU) {
       int id[CB_KU]; size_t rowv[CB_KU]; bool ok[CB_KU]; float wv[CB_KU], zv[CB_KU], dv[CB_KU]; int ci[CB_KU]; h16x4 ov[CB_KU];
 #pragma unroll
       for (int u = 0; u < CB_KU; ++u) {
         const int k = lane + 64 * (i0 + u);
         ok[u] = k < S;
-        id[u] = ok[u] ? (int)p.perm[(size_t)ray * S + k] : 0;
+        const int q = (int)p.perm[(size_t)ray * S + (ok[u] ? k : 0)];
+        id[u] = ok[u] ? q : 0;
       }
+      __builtin_amdgcn_sched_barrier(0);   // (all CB_KU sample ids are requested before the first is waited for: the scheduler would sink each to its use)
+      // Every load below is UNCONDITIONAL (round 6): lanes past the ray's samples read row `id 0` of the ray -- a valid row -- and drop the
+      // value.  With `ok ? load : 0` hipcc put each load in a branch of its own and, no longer knowing how many younger loads were in
+      // flight, waited for every one of them in turn (s_waitcnt vmcnt(0)): the batching of CB_KU trips had never overlapped anything.
 #pragma unroll
       for (int u = 0; u < CB_KU; ++u) {
         rowv[u] = row_of(ray, id[u], p.N, p.S1, p.S2);
-        wv[u] = ok[u] ? p.w_row[rowv[u]] : 0.f;
-        zv[u] = ok[u] ? p.z[rowv[u]] : 0.f;
-        ci[u] = ok[u] ? p.cidx_row[rowv[u]] : -1;
-        dv[u] = (p.dots_row && ok[u]) ? p.dots_row[rowv[u]] : 0.f;
+        // (no masking either: every use below is under ok[u], and a select right behind its load is a wait right behind it)
+        wv[u] = p.w_row[rowv[u]]; zv[u] = p.z[rowv[u]]; ci[u] = p.cidx_row[rowv[u]];
+        dv[u] = 0.f;
+        if (p.dots_row) dv[u] = p.dots_row[rowv[u]];
         if (keep) {
           krow[u] = rowv[u];
-          kdel[u] = ok[u] ? p.delta_row[rowv[u]] : 0.f; kT[u] = ok[u] ? p.T_row[rowv[u]] : 0.f;
-          ksig[u] = ok[u] ? p.sigma[rowv[u]] : 0.f; kh0[u] = ok[u] ? (float)p.sigma_out[rowv[u] * 16] : 0.f;
+          kdel[u] = p.delta_row[rowv[u]]; kT[u] = p.T_row[rowv[u]]; ksig[u] = p.sigma[rowv[u]]; kh0h[u] = p.sigma_out[rowv[u] * 16];
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < CB_KU; ++u) { ov[u] = (h16x4){0, 0, 0, 0}; if (ci[u] >= 0) ov[u] = *(const h16x4*)(p.color_out + (size_t)ci[u] * 16); }
+      for (int u = 0; u < CB_KU; ++u) ov[u] = *(const h16x4*)(p.color_out + (size_t)max(ci[u], 0) * 16);   // (used under ci >= 0 only)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < CB_KU; ++u) {
         if (!ok[u]) continue;
@@ -636,7 +711,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB_WPE))) vo
     };
     if (keep) {
 #pragma unroll
-      for (int u = 0; u < CB_KU; ++u) { const int k = lane + 64 * u; if (k < S) finish(k, krow[u], kdel[u], kT[u], ksig[u], kh0[u]); }
+      for (int u = 0; u < CB_KU; ++u) { const int k = lane + 64 * u; if (k < S) finish(k, krow[u], kdel[u], kT[u], ksig[u], (float)kh0h[u]); }
     } else {
       for (int k = lane; k < S; k += 64) {
         int id = p.perm[(size_t)ray * S + k];
