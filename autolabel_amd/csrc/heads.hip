@@ -47,11 +47,14 @@ __device__ inline void build_color_row(const ColorInSrc& s, int row, int ci) {
 }
 
 // live = w > thresh (renderer: mask = weights > 1e-4).  Ballot compaction in ROW ORDER: pass 1 counts the live rows of every
-// 4096-row chunk, pass 2 re-derives the bits, takes the sum of the earlier chunks' counts as its base (<= 512 chunks at 2^21
-// rows: one coalesced read per block) and writes.  The compact order is a pure function of w_row -- the color head sees its rows,
+// 1024-row chunk, pass 2 re-derives the bits, takes the sum of the earlier chunks' counts as its base (<= 2048 chunks at 2^21
+// rows: a few coalesced reads per block) and writes.  The compact order is a pure function of w_row -- the color head sees its rows,
 // and forms its weight-gradient partial sums, in the same order every run (round 2 handed out chunk bases with a returning
 // atomic: block arrival order).
-#define COMPACT_ITERS 16
+#ifndef COMPACT_ITERS
+#define COMPACT_ITERS 4    // 64-row groups per wave: 1024-row chunks (round 6; 16 -- 64 blocks for a 1024-ray batch, each wave building its colour rows
+                           // group after group -- cost 20 us there)
+#endif
 #define COMPACT_CHUNK (256 * COMPACT_ITERS)
 __global__ __launch_bounds__(256) void k_compact_count(const float* __restrict__ w_row, int rows, float thresh, int* __restrict__ chunk_cnt) {
   __shared__ int s_cnt[4];
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void k_compact_live(const float* __restrict__ 
     for (int q = threadIdx.x; q < ch; q += 256) part += chunk_cnt[q];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    const int r0 = ch * COMPACT_CHUNK + wave * 64 * COMPACT_ITERS;  // each wave owns a contiguous 1024-row span
+    const int r0 = ch * COMPACT_CHUNK + wave * 64 * COMPACT_ITERS;  // each wave owns a contiguous span of the chunk
     unsigned bits = 0; int cnt = 0;
 #pragma unroll
     for (int i = 0; i < COMPACT_ITERS; ++i) {
