@@ -24,6 +24,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(hip.declared_symbols()) - {'aln_last_error'} <= declared, 'binding uses symbols missing from include/autolabel_hip.h'
 
 
+def test_the_drivers_build_check_runs_clean():
+    """__graft_entry__.build() is what the driver calls on CPU every round: it must pass at the tree's own ABI version (it pinned a stale
+    number for half of round 6 while the library, the bindings and the header had moved on)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    entry = importlib.import_module('__graft_entry__')
+    entry.build()
+
+
 def test_grid_desc_host_vs_c_and_error_reporting():
     from autolabel_amd import hip
     g = hip.make_grid_desc()
