@@ -498,14 +498,31 @@ __global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ w
   const size_t f1 = (size_t)NB * KSG, fl = f1 + (size_t)NB * KS;   // semantic_features: layer 1 / last layer fragments
   const size_t flo = (size_t)NB * KS0O;                             // semantic_out: last layer fragments
   const int ntiles = (rows + 31) / 32, tstride = gridDim.x * 4;
-  h16x8 xb[KSG];
+  static_assert(KSG == 1, "one geo_feat k-step");
+  // The next tile's inputs are REQUESTED while this tile is in its chain and not touched before the next trip (round 6): the raw
+  // sigma_out row (geo_chunk() shuffled it at once -- a use right behind the load is a wait right behind it, the "prefetch" waited out its
+  // own round trip), and for SUMS the tile's weights, which were loaded and converted at the top of every tile.  Unconditional loads
+  // from clamped rows / tiles (a load in a branch makes hipcc wait with vmcnt(0) at the join).
+  h16x8 xlo, xhi; float wln = 0.f; float4 wq[4];
   auto load_x = [&](int t) {
-    const int r = t * 32 + c;
+    t = min(t, ntiles - 1);
+    const int r = min(t * 32 + c, rows - 1);
+    xlo = *(const h16x8*)(sigma_out + (size_t)r * 16); xhi = *(const h16x8*)(sigma_out + (size_t)r * 16 + 8);
+    if constexpr (SUMS) {   // (rows is a multiple of 32 here: whole tiles)
+      wln = w_row[r];
 #pragma unroll
-    for (int ks = 0; ks < KSG; ++ks) {
-      const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      xb[ks] = (r < rows) ? geo_chunk(sigma_out, (size_t)r, 16 * ks + 8 * hf, G) : z;
+      for (int ks = 0; ks < 2; ++ks) { wq[2 * ks] = *(const float4*)(w_row + t * 32 + 16 * ks + 8 * hf); wq[2 * ks + 1] = *(const float4*)(w_row + t * 32 + 16 * ks + 8 * hf + 4); }
     }
+  };
+  auto geo_of = [&](h16x8 lo, h16x8 hi) __attribute__((always_inline)) {   // geo_chunk() of the raw row for this lane's half, without a divergent branch
+    h16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const h16 v0 = (j < 7) ? lo[j + 1] : hi[0], v1 = (j < 7) ? hi[j + 1] : (h16)1.0f;
+      const h16 v = hf ? v1 : v0;
+      o[j] = (8 * hf + j < G) ? v : (h16)1.0f;
+    }
+    return o;
   };
   int tile = blockIdx.x * 4 + wave;
   if (tile < ntiles) load_x(tile);
@@ -522,20 +539,22 @@ __global__ __launch_bounds__(256) void k_sem_fwd_fused(const h16* __restrict__ w
     h16x8 p[KS], geo[KSG];
     h16x8 aw[2];   // SUMS: A operand of the weighted row sum, k-step ks = rows 16 ks .. 16 ks + 15: row 0 = fp16(w), row 1 = fp16(w - row 0)
     float wl = 0.f;   // SUMS: the weight of this lane's row
-    if constexpr (SUMS) {   // (rows is a multiple of 32 here: whole tiles)
-      wl = w_row[row];
+    if constexpr (SUMS) {
+      wl = wln;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const float4 w0 = *(const float4*)(w_row + row0 + 16 * ks + 8 * hf), w1 = *(const float4*)(w_row + row0 + 16 * ks + 8 * hf + 4);
+        const float4 w0 = wq[2 * ks], w1 = wq[2 * ks + 1];
         const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const h16 hi = (h16)wv[j]; aw[ks][j] = c == 0 ? hi : (c == 1 ? (h16)(wv[j] - (float)hi) : (h16)0.f); }
       }
     }
-#pragma unroll
-    for (int ks = 0; ks < KSG; ++ks) geo[ks] = xb[ks];
+    {
+      const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      geo[0] = valid ? geo_of(xlo, xhi) : z;
+    }
+    load_x(tile + tstride);   // (clamped to the last tile when there is no next one)
     chain_layer<NB, KSG>(acc, [&](int m, int ks) { return ff[((size_t)m * KSG + ks) * 64 + lane]; }, [&](int ks) { return geo[ks]; });
-    if (tile + tstride < ntiles) load_x(tile + tstride);
     relu_pack_store<NB>(acc, p, nullptr, hf);
     chain_layer<NB, KS>(acc, [&](int m, int ks) { return ff[(f1 + (size_t)m * KS + ks) * 64 + lane]; }, [&](int ks) { return p[ks]; });
     relu_pack_store<NB>(acc, p, nullptr, hf);
