@@ -426,7 +426,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HID == 128
   };
   const int tstride = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
-  if (tile < ntiles) load_x(tile);
+  // The colour head's rows built on the fly (SRC_COLOR_IN, the render path), STAGED (round 6): load_chunk8 resolves a chunk on the spot --
+  // compact index -> sample row -> ray direction + sigma_out row -> SH-4 and the geo_feat shift, two dependent round trips and the
+  // arithmetic inside what was meant as a prefetch.  Here the sample row of tile t + 2 and the raw direction / sigma_out row of tile
+  // t + 1 are in flight while tile t is in its chain; every load is unconditional (clamped tile and row).
+  const bool staged = !PLAIN && KS0 == 2 && xs.mode == SRC_COLOR_IN && xs.idx != nullptr;   // (with the compaction's row list: a `idx ? idx[r] : r` would be a load in a branch again)
+  int ridx_n = 0; float dn[3] = {0.f, 0.f, 0.f}; h16x8 lon = {0, 0, 0, 0, 0, 0, 0, 0}, hin = lon;
+  auto stage_idx = [&](int t) { return xs.idx[min(min(t, ntiles - 1) * 32 + c, rows - 1)]; };
+  auto stage_raw = [&](int ridx) {
+    const float* d = xs.g + 3 * (size_t)(xs.gw ? ridx : row_ray(xs, ridx));
+    dn[0] = d[0]; dn[1] = d[1]; dn[2] = d[2];
+    lon = *(const h16x8*)(xs.b + (size_t)ridx * 16); hin = *(const h16x8*)(xs.b + (size_t)ridx * 16 + 8);
+  };
+  auto stage_finish = [&](bool ok) {   // chunk 0: SH-4 values 8 hf .. 8 hf + 7; chunk 1: [geo_feat, 1...] values 8 hf .. 8 hf + 7
+    float sh[16];
+    sh4_of_dir(dn, sh);
+    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    h16x8 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o0[j] = (h16)(hf ? sh[8 + j] : sh[j]);
+      const h16 v0 = (j < 7) ? lon[j + 1] : hin[0], v1 = (j < 7) ? hin[j + 1] : (h16)1.0f;
+      o1[j] = (8 * hf + j < xs.G) ? (hf ? v1 : v0) : (h16)1.0f;
+    }
+    xb[0] = ok ? o0 : z; xb[KS0 - 1] = ok ? o1 : z;
+  };
+  if (tile < ntiles) {
+    if (staged) { stage_raw(stage_idx(tile)); ridx_n = stage_idx(tile + tstride); }
+    else load_x(tile);
+  }
   for (; tile < ntiles; tile += tstride) {
     const int row = tile * 32 + c;
     const bool valid = row < rows;
@@ -436,8 +464,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HID == 128
     asm volatile("" : "+v"(fo));
     const h16x8* frag = frag0 + fo;
     f32x16 acc[NB];
+    if (staged) {
+      stage_finish(valid);
+      stage_raw(ridx_n);                          // tile t + 1: its sample row arrived a trip ago
+      ridx_n = stage_idx(tile + 2 * tstride);     // tile t + 2
+    }
     chain_layer<NB, KS0>(acc, [&](int m, int ks) { return frag[((size_t)m * KS0 + ks) * 64 + lane]; }, [&](int ks) { return xb[ks]; });
-    if (tile + tstride < ntiles) load_x(tile + tstride);
+    if (!staged && tile + tstride < ntiles) load_x(tile + tstride);
     h16x8 p[KS];
     relu_pack_store<NB>(acc, p, (valid && h1) ? h1 + (size_t)row * HID : nullptr, hf);
     if (NHID == 2) {
