@@ -585,7 +585,7 @@ __global__ __launch_bounds__(BIN_TILE) __attribute__((amdgpu_waves_per_eu(BIN_TI
   BT_DECL
   // The sorted tile of level l leaves for the record pool in 3 pieces of 16 bytes per thread (24 KB), SPREAD OVER THE
   // ARITHMETIC OF LEVEL l + 1 (round 6).  As one burst behind the last barrier of its level -- every block of the chip at about the
-  // same time -- the 743 MB of records cost the kernel 130 us of its 315 (stub: no copy-out, 185 us): the memory pipe idles while
+  // same time -- the then 743 MB of 8-byte records cost the kernel 130 us of its 315 (stub: no copy-out, 185 us): the memory pipe idles while
   // the waves compute and the waves stall on full store queues while it drains.  `sorted` is not written again before the first barrier
   // of level l + 1, which no wave reaches before its last piece has been read.
   uint32_t cp_n = 0u;          // 16-byte pieces of the level whose copy-out is pending

@@ -605,7 +605,7 @@ def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel pair from the PMC counters: rocprofv3 --pmc around a child run of this script
     (`--pmc-child`: a few launch-by-launch steps of the same step on a smaller frame set), FETCH_SIZE and WRITE_SIZE in separate
     passes as MI355X_MICROARCH.md prescribes (TCC slots); both counters are in KB.  gfx950 correction: FETCH_SIZE under-reports wide
-    coalesced streaming reads by 2x -- that is the read pattern of phase 2 (8-byte record loads, 512 B per wave instruction) and of
+    coalesced streaming reads by 2x -- that is the read pattern of phase 2 (12-byte record loads, 768 B per wave instruction) and of
     phase 1's d_enc rows, so the raw and the doubled-fetch figure are both reported; `traffic` is the raw sum (a lower bound)."""
     exe = shutil.which('rocprofv3')
     if exe is None:
