@@ -480,6 +480,51 @@ def test_binned_encode_backward_writes_the_fp16_wire_payload_itself(H):
     assert flag.item() == 1
 
 
+def test_binned_encode_backward_with_every_pair_split_across_two_slices(H):
+    """Pair records (round 6): a pair whose two corners fall into different table slices becomes two half-empty records.  Here EVERY
+    sample sits on the +x face of the box (x = +bound: cell x = res - 1 = ...111111 at the power-of-two levels, so x + 1 carries past
+    the slice width at every level of 8192 cells and more): the tiles of those levels hold twice the records the sorted LDS tile has
+    room for -- the worst case the pool's chunks are sized for -- and the overflowing half goes straight to the pool.  Same gradient as
+    fp32 autograd of the oracle's encoder, twice the records of a tile of interior samples at those levels, bit-reproducible."""
+    bound = 1.0
+    e = H.make_enc_desc('hg+freq', bound)
+    N, S = 12, 128                 # 1536 rows: three full 512-row tiles
+    rows = N * S
+    g = torch.Generator().manual_seed(21)
+    ro = torch.cat([torch.full((N, 1), 0.5), (torch.rand(N, 2, generator=g) - 0.5) * 1.6], dim=1).cuda()
+    rd = torch.nn.functional.normalize(torch.cat([torch.full((N, 1), 4.0), torch.randn(N, 2, generator=g) * 0.3], dim=1), dim=1).cuda()
+    z = (torch.rand(N, S, generator=g).sort(dim=1)[0] * 1.0 + 0.6).reshape(-1).cuda().contiguous()      # x = 0.5 + ~0.97 z >= 1.08: clamped onto the face
+    ray_of_row = torch.arange(N, device='cuda').repeat_interleave(S)
+    assert bool(((ro[ray_of_row] + rd[ray_of_row] * z[:, None])[:, 0] > bound).all())
+    d_enc = torch.zeros(rows, e.enc_pad, dtype=torch.float16, device='cuda')
+    d_enc[:, 12:44] = (torch.randn(rows, 32, generator=g) * 0.05).half().cuda()
+    ref = _grid_grad_reference(O.ModelConfig(bound=bound), ro, rd, z, ray_of_row, d_enc, bound)
+    n = int(e.grid.n_entries) * 2
+    ws = torch.zeros(int(H.lib().aln_encode_bwd_binned_ws_bytes(C.byref(e), rows)), dtype=torch.uint8, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    got = torch.zeros(n, device='cuda')
+    _binned_bwd(H, e, ro, rd, z, rows, rows, S, S, d_enc, got, flag=flag, ws=ws)
+    assert flag.item() == 0
+    assert not ((got != 0) & (ref == 0)).any(), 'an entry the oracle never touches received a gradient'
+    assert ((got - ref).abs() <= 2.0 ** -10 * ref.abs().max()).all()
+    assert (got - ref).norm() <= 1e-3 * ref.norm()
+    # record counts per level from the descriptors: the levels of 8192 cells and more hold two records per pair
+    tile = int(H.lib().aln_encode_bwd_binned_tile_rows())
+    nl, nt = int(e.grid.n_levels), (rows + tile - 1) // tile
+    pool = ws.numel() - nl * 64 * nt * 4
+    desc = ws[pool:].view(torch.int32).view(nl, 64, nt)
+    per_level = ((desc >> 13) & 0x3FFF).sum(dim=(1, 2)).cpu()
+    res = [int(e.grid.res[l]) for l in range(nl)]
+    split_levels = [l for l in range(nl) if res[l] >= 8192 and (res[l] & (res[l] - 1)) == 0]
+    assert split_levels, res
+    for l in split_levels:
+        assert int(per_level[l]) == 2 * 4 * rows, (l, res[l], int(per_level[l]))       # every pair split: 8 records per sample
+        assert int(per_level[l]) // nt == 2 * 4 * tile                                 # = a chunk's capacity, twice the LDS tile
+    again = torch.zeros(n, device='cuda')
+    _binned_bwd(H, e, ro, rd, z, rows, rows, S, S, d_enc, again)
+    assert torch.equal(again, got), 'every level must be bit-reproducible'
+
+
 def test_binned_encode_backward_two_passes_and_level_groups(H):
     """Coarse + fine pass in ONE launch (rows_pass1 / two strides) and the data-parallel level groups give the gradient fp32
     autograd computes for the two passes; a non-finite upstream gradient raises found_inf."""
